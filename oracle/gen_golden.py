@@ -1,0 +1,233 @@
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN FILES (build container only).
+
+Run:  python oracle/gen_golden.py            (needs /root/reference; never runs on the GPU box)
+
+The reference (jmaronas/TGP.pytorch, pure Python) is imported unmodified from /root/reference/code
+with the builder-written third-party stand-ins in oracle/shims on sys.path (gpytorch, pytorchlib,
+torchvision, ... are absent from this image).  Inputs come from
+oracle/tgp_oracle.synthetic_problem (seeded), are pushed into the reference's model objects, and
+the reference's outputs (ELBO/ELL/KLD, q(f) moments, all gradients, evaluation quantities, first
+Adam steps) are stored next to the inputs.  Fixtures are data only: no reference source travels.
+"""
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.dont_write_bytecode = True            # /root/reference is read-only
+sys.path.insert(0, os.path.join(HERE, "shims"))
+sys.path.insert(0, "/root/reference/code")
+sys.path.insert(0, REPO)
+warnings.simplefilter("ignore")
+
+import numpy as np                         # noqa: E402
+import torch                               # noqa: E402
+import scipy.integrate as _si              # noqa: E402
+
+_si.cumtrapz = _si.cumulative_trapezoid    # dsp/utils.py:26 imports the removed name
+_real_version = torch.__version__
+torch.__version__ = "1.7.0"                # dsp/config.py:18-25,74 hard version gate
+import dsp.config as cg                    # noqa: E402
+
+torch.__version__ = _real_version
+cg.device = "cpu"
+cg.set_maximum_precission()                # float64 like code/main.py:124
+
+from dsp.models import instance_kernel, sparse_MF_SP, sparse_MF_GP     # noqa: E402
+from dsp.models.flow import instance_flow                              # noqa: E402
+from dsp.likelihoods import GaussianNonLinearMean, GaussianLinearMean  # noqa: E402
+from dsp.flows import SAL, StepTanhL                                   # noqa: E402
+
+from oracle import tgp_oracle as orc                                   # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+IP = {"variational_distribution": {"variance_scale": 1e-5, "mean_scale": 0.0}}
+KINIT = {"length_scale": 2.0, "kernel_scale": 2.0, "noisy_variance": 1e-6}
+
+
+def build_reference_model(prob, flow):
+    """Instantiate the reference's model classes and overwrite their parameters with prob['params']."""
+    X, p = prob["X"], prob["params"]
+    N, D = X.shape
+    M = p["Z"].shape[0]
+    S = prob["xs"].shape[0]
+    K = instance_kernel("scale_rbf", ard_num_dim=D, num_multioutput=1, kernel_is_shared=False, init_params=KINIT)
+    if flow is None:
+        lik = GaussianLinearMean(out_dim=1, noise_init=0.05, noise_is_shared=False)
+        model = sparse_MF_GP(["zero", K], X, p["Z"].clone(), N, lik, 1, True, False, False, False, False, 0.0,
+                             init_params=IP)
+    else:
+        lik = GaussianNonLinearMean(out_dim=1, noise_init=0.05, noise_is_shared=False, quadrature_points=S)
+        if flow.startswith("sal"):
+            specs = SAL(int(flow[3:]))
+        elif flow.startswith("idsal"):
+            specs = SAL(int(flow[5:]), input_dependent=True, input_dim=D, num_hidden_layers=2, batch_norm=0,
+                        dropout=0.25, hidden_dim=50, hidden_activation="relu", inference="MC_dropout")
+            specs = instance_flow(specs)
+            specs.turn_off_initializer_parameters()
+        else:
+            nb, ns = (int(t) for t in flow[4:].split("x"))
+            np.random.seed(0)
+            specs = instance_flow(StepTanhL(nb, ns, add_f0=True))
+        model = sparse_MF_SP(["zero", K], X, p["Z"].clone(), N, lik, 1, True, False, False, False, False,
+                             [specs], "single", 0.0, init_params=IP)
+    with torch.no_grad():
+        model.Z.data = p["Z"].reshape(1, M, D).clone()
+        model.q_U.variational_mean.data = p["m"].reshape(1, M).clone()
+        model.q_U.chol_variational_covar.data = p["Lam"].reshape(1, M, M).clone()
+        model.covariance_function.raw_outputscale.data = p["raw_outputscale"].reshape(1).clone()
+        model.covariance_function.base_kernel.raw_lengthscale.data = p["raw_lengthscale"].reshape(1, 1, D).clone()
+        model.likelihood.log_var_noise.data = p["log_var_noise"].reshape(1, 1).clone()
+        if flow is not None:
+            load_theta(model, prob["program"], p["theta"])
+    return model
+
+
+def flow_scalar_params(model, program):
+    """Reference nn.Parameters in the order of the flat theta vector."""
+    arr = model.G_matrix[0].flow_arr
+    out = []
+    for blk, (kind, K, poff, flags) in zip(arr, program):
+        if flags & orc.FLAG_PER_ROW:
+            continue
+        if kind == orc.FLOW_STEPTANH:
+            for t in blk.flow_arr:
+                out += [t.a, t.b, t.c, t.d]
+        else:
+            out += [blk.a, blk.b]
+    return out
+
+
+def load_theta(model, program, theta):
+    for prm, val in zip(flow_scalar_params(model, program), theta):
+        prm.data = val.clone().reshape(())
+
+
+def reference_step0(prob, flow, name):
+    """ELBO/ELL/KLD + q(f) moments + every gradient from the reference model."""
+    torch.manual_seed(0)
+    model = build_reference_model(prob, flow)
+    model.set_is_training(True)
+    X, Y, p = prob["X"], prob["Y"], prob["params"]
+    captured = {}
+    if flow is not None and flow.startswith("idsal"):
+        model.eval()                         # dropout off => deterministic per-row parameters
+        hooks = []
+        for bi, blk in enumerate(model.G_matrix[0].flow_arr):
+            if hasattr(blk, "NNets_a"):
+                for nm in ("a", "b"):
+                    def hook(mod, inp, out, key=(bi, nm)):
+                        if key not in captured and out.requires_grad:
+                            out.retain_grad()
+                            captured[key] = out
+                    hooks.append(getattr(blk, "NNets_" + nm).register_forward_hook(hook))
+    elbo, ell, kld = model.ELBO(X, Y)
+    (elbo).backward()
+    out = {
+        "X": X, "Y": Y, "xs": prob["xs"], "ws": prob["ws"], "N_total": np.float64(prob["N_total"]),
+        "ELBO": elbo.detach(), "ELL": ell.detach(), "KLD": kld.detach(),
+        "g_Z": model.Z.grad[0], "g_m": model.q_U.variational_mean.grad[0],
+        "g_Lam": model.q_U.chol_variational_covar.grad[0],
+        "g_raw_outputscale": model.covariance_function.raw_outputscale.grad,
+        "g_raw_lengthscale": model.covariance_function.base_kernel.raw_lengthscale.grad.reshape(-1),
+        "g_log_var_noise": model.likelihood.log_var_noise.grad.reshape(-1),
+    }
+    for k, v in p.items():
+        out["p_" + k] = v
+    if flow is not None:
+        out["program"] = np.array(prob["program"], dtype=np.int32)
+        out["g_theta"] = torch.stack([q.grad.reshape(()) for q in flow_scalar_params(model, prob["program"])])
+    if captured:
+        keys = sorted(captured.keys())
+        out["rowp"] = torch.stack([captured[k].detach().reshape(-1) for k in keys], 1)
+        out["g_rowp"] = torch.stack([captured[k].grad.reshape(-1) for k in keys], 1)
+    with torch.no_grad():
+        mu, v = model.marginal_variational_qf_parameters(X, diagonal=True, is_duvenaud=False, init_Z=None)
+        out["mu"], out["v"] = mu.reshape(-1), v.reshape(-1)
+        if not captured:
+            # evaluation path (sparse_MF_SP.py:457-540, 637-825); skipped for the ID fixture whose
+            # per-row parameters are only defined through the captured tensors above
+            model.set_is_training(False)
+            Y_std = torch.tensor([1.7])
+            logp, (m1, m2) = model.test_log_likelihood(X, Y, return_moments=True, Y_std=Y_std, S_MC_NNet=None)
+            out["test_logp_sum"], out["pred_m1"], out["pred_m2"] = logp.reshape(-1), m1.reshape(-1), m2.reshape(-1)
+            out["Y_std"] = Y_std
+    save(name, out)
+    return model
+
+
+def reference_adam_steps(prob, flow, name, steps=5):
+    """First `steps` of Trainer_base.train's inner loop: ELBO -> (-ELBO).backward() -> Adam(lr=0.01).step()
+    (trainers/trainer_base.py:337-342, optimizers.py:12)."""
+    model = build_reference_model(prob, flow)
+    model.set_is_training(True)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    hist = []
+    for _ in range(steps):
+        elbo, ell, kld = model.ELBO(prob["X"], prob["Y"])
+        loss = -elbo
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        hist.append([elbo.item(), ell.item(), kld.item()])
+    out = {"X": prob["X"], "Y": prob["Y"], "xs": prob["xs"], "ws": prob["ws"],
+           "N_total": np.float64(prob["N_total"]), "history": np.array(hist)}
+    for k, v in prob["params"].items():
+        out["p_" + k] = v
+    if flow is not None:
+        out["program"] = np.array(prob["program"], dtype=np.int32)
+        out["final_theta"] = torch.stack([q.detach().reshape(()) for q in flow_scalar_params(model, prob["program"])])
+    out["final_Z"] = model.Z.detach()[0]
+    out["final_m"] = model.q_U.variational_mean.detach()[0]
+    save(name, out)
+
+
+def cholesky_ladder_fixture():
+    """dsp/utils.py:222-270 on a numerically singular K: which jitter the reference's ladder lands on."""
+    from dsp.utils import psd_safe_cholesky
+    g = torch.Generator().manual_seed(3)
+    B = torch.randn(12, 3, generator=g)
+    A = B @ B.t()                                  # rank 3 => plain Cholesky fails
+    L, Ap = psd_safe_cholesky(A.clone(), upper=False, jitter=None)
+    save("chol_ladder", {"A": A, "L": L, "A_used": Ap, "jitter_used": (Ap - A).diagonal().mean()})
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    arrs = {}
+    for k, v in d.items():
+        arrs[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)
+    print("wrote", name, {k: a.shape for k, a in list(arrs.items())[:4]}, "...")
+
+
+def main():
+    cases = [
+        ("tiny_svgp", dict(N=64, D=3, M=8, S=8, flow=None)),
+        ("tiny_sal2", dict(N=64, D=3, M=8, S=8, flow="sal2")),
+        ("tiny_tanh3x2", dict(N=64, D=3, M=8, S=8, flow="tanh3x2")),
+        ("tiny_idsal3", dict(N=64, D=3, M=8, S=8, flow="idsal3")),
+        ("ragged_sal2", dict(N=77, D=5, M=19, S=12, flow="sal2")),      # N, M not multiples of 16
+        ("boston_like_svgp", dict(N=455, D=13, M=5, S=20, flow=None)),  # C1 shape
+        ("med_svgp", dict(N=1024, D=4, M=100, S=32, flow=None)),        # C2 shape, fewer rows
+        ("med_sal2", dict(N=1024, D=4, M=100, S=32, flow="sal2")),      # C3 shape, fewer rows
+        ("med_tanh3x2", dict(N=1024, D=4, M=100, S=32, flow="tanh3x2")),
+    ]
+    for name, kw in cases:
+        prob = orc.synthetic_problem(kw["N"], kw["D"], kw["M"], seed=0, flow=kw["flow"], S=kw["S"])
+        reference_step0(prob, kw["flow"], name)
+    # identity-initialised TGP == SVGP known answer and KL-at-init (ii)
+    prob = orc.synthetic_problem(256, 4, 100, seed=0, flow="sal2", S=32, perturb=False)
+    reference_step0(prob, "sal2", "init_sal2_identity")
+    prob = orc.synthetic_problem(256, 4, 100, seed=0, flow=None, S=32, perturb=False)
+    reference_step0(prob, None, "init_svgp")
+    # trainer sequence
+    for name, flow in (("adam5_svgp", None), ("adam5_sal2", "sal2")):
+        prob = orc.synthetic_problem(64, 3, 8, seed=0, flow=flow, S=8)
+        reference_adam_steps(prob, flow, name)
+    cholesky_ladder_fixture()
+
+
+if __name__ == "__main__":
+    main()
