@@ -1,0 +1,176 @@
+/*
+ * tgp_hip.h -- C ABI of libtgp_hip.so: the MI355X (gfx950) implementation of the TGP
+ * sparse-variational ELBO hot path (jmaronas/TGP.pytorch, `sparse_MF_SP.ELBO` and below).
+ *
+ * The reference has no FFI of its own (it is pure Python on ATen); the boundary it offers is the
+ * model-class API.  This header is the plain-C surface that sits directly underneath that API:
+ * every entry point names the reference call site(s) it replaces (file:line relative to
+ * /root/reference/code).  The Python mirror of the reference classes (tgp/pytorch_amd) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all matrices row-major, contiguous, float64 (`_f64`; the reference's main.py runs in float64,
+ *     dsp/config.py:37-46);
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
+ *     outputs and the workspace are pre-allocated by the caller, nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered, safe
+ *     to capture into a hipGraph, and re-entrant when callers use distinct streams + workspaces;
+ *   - return value: 0 = launched; <0 = -(index of the offending argument) or TGP_E_*;
+ *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[4]):
+ *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive),
+ *       status[1] = 1 if K_MM contained a NaN (the reference raises NanError, dsp/utils.py:241-254),
+ *     so the host can replay with the reference's jitter ladder (dsp/utils.py:256-269) without a
+ *     device sync per step.  No exception crosses the ABI.
+ */
+#ifndef TGP_HIP_H
+#define TGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGP_VERSION 100
+
+/* error codes (negative return values below -64 are generic) */
+#define TGP_E_UNSUPPORTED (-100) /* shape outside this build's limits (M > 128, D > 16, ...) */
+#define TGP_E_WORKSPACE (-101)   /* workspace too small                                        */
+#define TGP_E_LDS (-102)         /* flow program too large for one CU's LDS                    */
+#define TGP_E_LAUNCH (-103)      /* hipLaunchKernel failed; see tgp_last_error()               */
+
+/* ---- flow program (models/flow.py CompositeFlow.forward :155-158) -------------------------------
+ * A flow is a sequence of `nblk` blocks; block b is four int32: {kind, K, poff, flags}.
+ *   kind   TGP_FLOW_AFFINE   g = a f + b                                   (flow.py:330-340)
+ *          TGP_FLOW_SAL      g = sinh(b asinh(f) - a), asinh = log(f+sqrt(f^2+1)) (flow.py:904-905,936-977)
+ *          TGP_FLOW_STEPTANH g = [f +] sum_k a_k + sp(b_k) tanh((f-c_k)/sp(d_k)) (flow.py:1096-1103,760-771)
+ *   K      number of tanh steps (STEPTANH only)
+ *   poff   offset of the block's parameters in `theta` (shared scalars: AFFINE {a,b}, SAL {a,b},
+ *          STEPTANH {a_k,b_k,c_k,d_k}_k) or first column in `rowp` when TGP_FLAG_PER_ROW is set
+ *   flags  TGP_FLAG_RESTRICT  set_restrictions=True: softplus on AFFINE.a / SAL.b
+ *          TGP_FLAG_ADD_F0    add_init_f0=True
+ *          TGP_FLAG_PER_ROW   input-dependent parameters, one value per data row (flow.py:949-965)
+ */
+#define TGP_FLOW_AFFINE 0
+#define TGP_FLOW_SAL 1
+#define TGP_FLOW_STEPTANH 2
+#define TGP_FLAG_RESTRICT 1
+#define TGP_FLAG_ADD_F0 2
+#define TGP_FLAG_PER_ROW 4
+
+/* likelihood selector */
+#define TGP_LIK_GAUSS 0 /* GaussianLinearMean.expected_log_prob, likelihoods/GaussianLinearMean.py:60-87       */
+#define TGP_LIK_FLOW 1  /* GaussianNonLinearMean.expected_log_prob, likelihoods/GaussianNonLinearMean.py:64-150 */
+
+typedef struct tgp_model {
+  int32_t N;       /* rows in this call (this rank's shard of the minibatch)            */
+  int32_t D;       /* input dimension (<= 16)                                           */
+  int32_t M;       /* inducing points (<= 128 in this build)                            */
+  int32_t S;       /* quadrature nodes (TGP_LIK_FLOW)                                   */
+  int32_t nblk;    /* flow blocks                                                       */
+  int32_t P;       /* shared flow scalars in theta                                      */
+  int32_t RP;      /* per-row flow parameter columns in rowp                            */
+  int32_t lik;     /* TGP_LIK_*                                                         */
+  double scale;    /* N_total / MB_global: sparse_MF_SP.ELL, models/sparse_MF_SP.py:623-626 */
+  double jitter;   /* added to diag(K_MM) before the Cholesky (0 unless retrying)       */
+  double kl_scale; /* weight of the KL gradient in this call: 1/world_size so that an
+                      all-reduce(sum) over row shards counts it once                    */
+  /* parameters (reference nn.Parameter names in brackets) */
+  const double* Z;             /* (M,D)   [Z]                                               */
+  const double* raw_ls;        /* (D)     [covariance_function.base_kernel.raw_lengthscale] */
+  const double* raw_os;        /* (1)     [covariance_function.raw_outputscale]             */
+  const double* m;             /* (M)     [q_U.variational_mean]                            */
+  const double* Lam;           /* (M,M)   [q_U.chol_variational_covar] dense, tril at use   */
+  const double* log_var_noise; /* (1)     [likelihood.log_var_noise]                        */
+  const double* theta;         /* (P)     [G_matrix.0.flow_arr.*] or NULL                   */
+  const int32_t* program;      /* (nblk,4) or NULL                                          */
+  const double* xs;            /* (S) Gauss-Hermite nodes                                   */
+  const double* wn;            /* (S) weights / sqrt(pi)                                    */
+} tgp_model;
+
+typedef struct tgp_grads {
+  double* Z;
+  double* raw_ls;
+  double* raw_os;
+  double* m;
+  double* Lam;
+  double* log_var_noise;
+  double* theta; /* (P) or NULL     */
+  double* rowp;  /* (N,RP) or NULL  */
+} tgp_grads;
+
+int tgp_version(void);
+const char* tgp_last_error(void);
+
+/* Bytes of workspace the calls below need for a problem of this shape (training is the maximum). */
+size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP);
+
+/* One fused ELBO evaluation with gradients: replaces sparse_MF_SP.ELBO (models/sparse_MF_SP.py:552-598)
+ * + loss.backward() (trainers/trainer_base.py:341) for one minibatch shard.
+ *   X (N,D), Y (N), rowp (N,RP) or NULL
+ *   out[0..3] = {ELBO_shard = ELL_shard - KL, ELL_shard, KL, 0}; gradients are d(ELL_shard - kl_scale*KL).
+ *   mu, v: optional per-row q(f) moments (NULL to skip). */
+int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
+                      const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
+ * whitened, diagonal=True).  mu, v: (N). */
+int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* K_MM assembly: gpytorch ScaleKernel(RBFKernel(ard)) as built by instance_kernel('scale_rbf'),
+ * models/utils_models.py:188-193, called at models/sparse_MF_SP.py:316.  K (M,M). */
+int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,
+                double* K, void* stream);
+
+/* K_NM assembly (models/sparse_MF_SP.py:319); K (N,M).  Diagnostic/next-row use: the training path
+ * never materialises K_NM. */
+int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int32_t N, int32_t M,
+                int32_t D, double* K, void* stream);
+
+/* Lower Cholesky with LAPACK-style info: torch.cholesky inside psd_safe_cholesky, dsp/utils.py:239.
+ * A (M,M) symmetric, L (M,M) lower (strict upper zeroed); Linv (M,M) = L^-1 or NULL. */
+int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_t* status, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* Whitened KL and its gradients: sparse_MF_SP.KLD, models/sparse_MF_SP.py:406-431. out[0] = KL. */
+int tgp_kl_whitened_f64(const double* m, const double* Lam, int32_t M, double* out, double* g_m, double* g_Lam,
+                        void* stream);
+
+/* SVGP closed-form expected log-likelihood (likelihoods/GaussianLinearMean.py:60-87 + dsp/utils.py:164-195),
+ * summed over rows and multiplied by `scale`.  out[0] = ELL, out[1] = dELL/dlog_var_noise; g_mu, g_v: (N). */
+int tgp_ell_gauss_f64(const double* Y, const double* mu, const double* v, int32_t N, const double* log_var_noise,
+                      double scale, double* out, double* g_mu, double* g_v, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* TGP Gauss-Hermite expected log-likelihood through the flow (likelihoods/GaussianNonLinearMean.py:64-150),
+ * with gradients w.r.t. mu, v, theta, rowp, log_var_noise.  out[0] = ELL, out[1] = dELL/dlog_var_noise. */
+int tgp_ell_flow_f64(const tgp_model* model, const double* Y, const double* mu, const double* v, const double* rowp,
+                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* Flow evaluation G(f), dG/df, log dG/df for f of shape (S,N) (row n uses rowp[n,:]):
+ * CompositeFlow.forward (models/flow.py:155-158) and Flow.forward_grad (:101-104); serves prediction and the
+ * WGP-style log-Jacobian (likelihoods/WarpedGaussianLinearMean.py:65-85).  Any output may be NULL. */
+int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_t N, const double* rowp, double* G,
+                      double* dG, double* logdG, void* stream);
+
+/* Evaluation path given q(f) moments: predictive moments m1, m2
+ * (GaussianNonLinearMean.marginal_moments :152-203 / GaussianLinearMean.marginal_moments :89-118) and the
+ * per-row test log-likelihood WITHOUT the -0.5*log(pi) constant (models/sparse_MF_SP.py:705-776, 786-799).
+ * Y may be NULL (then logp is not written). */
+int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, const double* rowp, const double* Y,
+                    double Y_std, double* m1, double* m2, double* logp, void* stream);
+
+/* Adam on a flat parameter buffer (torch.optim.Adam semantics, dsp/trainers/optimizers.py:12; L2 weight decay
+ * added to the gradient as torch does).  `maximize` != 0 ascends (gradients here are of +ELBO). */
+int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                 double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t maximize,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGP_HIP_H */

@@ -91,7 +91,7 @@ def test_first_adam_steps_match_reference(name, flow):
 def test_quadrature_exact_on_polynomials():
     """GH rule with S nodes integrates polynomials of degree < 2S exactly (known-answer, no oracle)."""
     xs, ws = orc.hermgauss(8)
-    mu, v = torch.tensor([0.3]), torch.tensor([1.7])
+    mu, v = torch.tensor([0.3], dtype=torch.float64), torch.tensor([1.7], dtype=torch.float64)
     f = torch.sqrt(2 * v) * xs + mu
     for k, want in ((1, 0.3), (2, 0.3 ** 2 + 1.7), (4, 0.3 ** 4 + 6 * 0.09 * 1.7 + 3 * 1.7 ** 2)):
         got = float((ws * f ** k).sum() / math.sqrt(math.pi))

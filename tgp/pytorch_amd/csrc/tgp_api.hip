@@ -1,0 +1,211 @@
+// tgp_api.hip -- the extern "C" surface of libtgp_hip.so (declared in include/tgp_hip.h).
+// Argument checking, plan/workspace bookkeeping and the launch sequence of one ELBO step:
+//   k_prep_a -> k_prep_b -> k_rows<MT,DP> -> k_reduce -> k_bwd1..5            (9 launches, no host sync)
+#include <cstdio>
+#include <cstring>
+#include "tgp_dev.hpp"
+#include "tgp_launch.hpp"
+
+namespace tgp {
+
+static thread_local char g_err[256] = "";
+
+int set_error(hipError_t e, const char* file, int line) {
+  snprintf(g_err, sizeof(g_err), "%s:%d: %s", file, line, hipGetErrorString(e));
+  return TGP_E_LAUNCH;
+}
+
+static int check_model(const tgp_model* m, bool need_lik) {
+  if (m == nullptr) return -1;
+  if (m->N < 1 || m->D < 1 || m->D > 16) return -1;
+  if (m->M < 1) return -1;
+  if (m->M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
+  if (!m->Z || !m->raw_ls || !m->raw_os || !m->m || !m->Lam || !m->log_var_noise) return -1;
+  if (need_lik && m->lik == TGP_LIK_FLOW) {
+    if (m->S < 1 || m->nblk < 0 || !m->xs || !m->wn) return -1;
+    if (m->nblk > 0 && !m->program) return -1;
+    if (m->P > 0 && !m->theta) return -1;
+  }
+  return 0;
+}
+
+}  // namespace tgp
+
+using namespace tgp;
+
+extern "C" {
+
+int tgp_version(void) { return TGP_VERSION; }
+
+const char* tgp_last_error(void) { return g_err; }
+
+size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP) {
+  Plan p;
+  if (make_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
+  size_t d = p.total;
+  const size_t lik = lik_workspace_doubles(N, P, RP);
+  if (lik > d) d = lik;
+  return d * sizeof(double);
+}
+
+int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
+                      const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (int rc = check_model(model, true)) return rc;
+  if (!X) return -2;
+  if (!Y) return -3;
+  if (model->RP > 0 && !rowp) return -4;
+  if (!out) return -5;
+  if (!grads || !grads->Z || !grads->raw_ls || !grads->raw_os || !grads->m || !grads->Lam || !grads->log_var_noise)
+    return -6;
+  if (model->P > 0 && model->lik == TGP_LIK_FLOW && !grads->theta) return -6;
+  if (model->RP > 0 && !grads->rowp) return -6;
+  if ((mu == nullptr) != (v == nullptr)) return -7;
+  if (!status) return -9;
+  if (!workspace) return -10;
+  Plan p;
+  const int nblk = model->lik == TGP_LIK_FLOW ? model->nblk : 0;
+  const int P = model->lik == TGP_LIK_FLOW ? model->P : 0;
+  const int RP = model->lik == TGP_LIK_FLOW ? model->RP : 0;
+  if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* ws = static_cast<double*>(workspace);
+  tgp_model md = *model;
+  md.nblk = nblk; md.P = P; md.RP = RP;
+  if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
+  if (int rc = launch_rows(p, md, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
+  return launch_backward_mm(p, md, *grads, out, ws, st);
+}
+
+int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_model(model, false)) return rc;
+  if (!X) return -2;
+  if (!mu) return -3;
+  if (!v) return -4;
+  if (!status) return -5;
+  if (!workspace) return -6;
+  Plan p;
+  if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* ws = static_cast<double*>(workspace);
+  tgp_model md = *model;
+  md.nblk = 0; md.P = 0; md.RP = 0; md.lik = TGP_LIK_GAUSS; md.program = nullptr;
+  if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
+  return launch_rows(p, md, X, nullptr, nullptr, nullptr, mu, v, ws, false, st);
+}
+
+int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,
+                double* K, void* stream) {
+  if (!Z) return -1;
+  if (!raw_ls) return -2;
+  if (!raw_os) return -3;
+  if (M < 1) return -4;
+  if (D < 1) return -5;
+  if (!K) return -7;
+  return launch_kmm(Z, raw_ls, raw_os, M, D, jitter, K, static_cast<hipStream_t>(stream));
+}
+
+int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int32_t N, int32_t M,
+                int32_t D, double* K, void* stream) {
+  if (!X) return -1;
+  if (!Z) return -2;
+  if (!raw_ls) return -3;
+  if (!raw_os) return -4;
+  if (N < 1) return -5;
+  if (M < 1) return -6;
+  if (D < 1) return -7;
+  if (!K) return -8;
+  return launch_knm(X, Z, raw_ls, raw_os, N, M, D, K, static_cast<hipStream_t>(stream));
+}
+
+int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_t* status, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
+  if (!A) return -1;
+  if (M < 1) return -2;
+  if (M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
+  if (!L) return -3;
+  if (!status) return -5;
+  return launch_cholesky(A, M, L, Linv, status, static_cast<hipStream_t>(stream));
+}
+
+int tgp_kl_whitened_f64(const double* m, const double* Lam, int32_t M, double* out, double* g_m, double* g_Lam,
+                        void* stream) {
+  if (!m) return -1;
+  if (!Lam) return -2;
+  if (M < 1) return -3;
+  if (!out) return -4;
+  return launch_kl(m, Lam, M, out, g_m, g_Lam, static_cast<hipStream_t>(stream));
+}
+
+int tgp_ell_gauss_f64(const double* Y, const double* mu, const double* v, int32_t N, const double* log_var_noise,
+                      double scale, double* out, double* g_mu, double* g_v, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!Y) return -1;
+  if (!mu) return -2;
+  if (!v) return -3;
+  if (N < 1) return -4;
+  if (!log_var_noise) return -5;
+  if (!out) return -7;
+  if (!workspace) return -10;
+  if (workspace_bytes < lik_workspace_doubles(N, 0, 0) * sizeof(double)) return TGP_E_WORKSPACE;
+  return launch_ell_gauss(Y, mu, v, N, log_var_noise, scale, out, g_mu, g_v, static_cast<double*>(workspace),
+                          static_cast<hipStream_t>(stream));
+}
+
+int tgp_ell_flow_f64(const tgp_model* model, const double* Y, const double* mu, const double* v, const double* rowp,
+                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (!model || model->N < 1 || model->S < 1 || !model->xs || !model->wn || !model->log_var_noise) return -1;
+  if (model->nblk > 0 && !model->program) return -1;
+  if (model->P > 0 && !model->theta) return -1;
+  if (!Y) return -2;
+  if (!mu) return -3;
+  if (!v) return -4;
+  if (model->RP > 0 && !rowp) return -5;
+  if (!out) return -6;
+  if (!workspace) return -11;
+  if (workspace_bytes < lik_workspace_doubles(model->N, model->P, model->RP) * sizeof(double)) return TGP_E_WORKSPACE;
+  return launch_ell_flow(*model, Y, mu, v, rowp, out, g_mu, g_v, g_theta, g_rowp, static_cast<double*>(workspace),
+                         static_cast<hipStream_t>(stream));
+}
+
+int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_t N, const double* rowp, double* G,
+                      double* dG, double* logdG, void* stream) {
+  if (!model) return -1;
+  if (model->nblk > 0 && !model->program) return -1;
+  if (model->P > 0 && !model->theta) return -1;
+  if (!f) return -2;
+  if (S < 1) return -3;
+  if (N < 1) return -4;
+  if (model->RP > 0 && !rowp) return -5;
+  return launch_flow_eval(*model, f, S, N, rowp, G, dG, logdG, static_cast<hipStream_t>(stream));
+}
+
+int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, const double* rowp, const double* Y,
+                    double Y_std, double* m1, double* m2, double* logp, void* stream) {
+  if (!model || model->N < 1 || !model->log_var_noise) return -1;
+  if (model->lik == TGP_LIK_FLOW && (model->S < 1 || !model->xs || !model->wn)) return -1;
+  if (!mu) return -2;
+  if (!v) return -3;
+  if (model->lik == TGP_LIK_FLOW && model->RP > 0 && !rowp) return -4;
+  return launch_predict(*model, mu, v, rowp, Y, Y_std, m1, m2, logp, static_cast<hipStream_t>(stream));
+}
+
+int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                 double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t maximize,
+                 void* stream) {
+  if (!params) return -1;
+  if (!grads) return -2;
+  if (!exp_avg) return -3;
+  if (!exp_avg_sq) return -4;
+  if (n < 1) return -5;
+  if (step < 1) return -11;
+  return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, maximize,
+                     static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

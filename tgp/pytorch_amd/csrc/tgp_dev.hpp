@@ -1,0 +1,228 @@
+// tgp_dev.hpp -- shared device helpers and the workspace layout (gfx950 only, float64).
+//
+// Wave = 64 lanes.  All dense contraction goes through v_mfma_f64_16x16x4_f64:
+//   A operand: lane l holds A[i = l&15][k = l>>4]        (one f64)
+//   B operand: lane l holds B[k = l>>4][j = l&15]        (one f64)
+//   C/D      : lane l, register r holds D[row = (l>>4) + 4r][col = l&15]
+// (layout verified on hardware with exact integer data, scratch/mfma_probe.hip).  Consequence used
+// everywhere below: accumulator register r of a 16x16 tile IS the B operand of k-step r of a product
+// that contracts over the tile's ROW index -- GEMM chains need no LDS round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/tgp_hip.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+#define TGP_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+#define TGP_ROWS_PER_BLOCK 64 /* 4 waves x 16 rows */
+#define TGP_TILE_LD 66        /* LDS row stride (f64) of the [m][64 rows] transposition tile: conflict-free ds_read_b64 */
+#define TGP_MAX_MT 8
+#define TGP_LOG_2PI_REF 1.8378770942368803 /* log(2*float32(pi)): the reference's cg.pi is a float32 tensor (dsp/config.py:71) */
+
+namespace tgp {
+
+// ---------------------------------------------------------------------------------------------------
+// problem plan: derived sizes + workspace offsets (in doubles).  Host and device agree through this.
+// ---------------------------------------------------------------------------------------------------
+struct Plan {
+  int N, D, M, S, nblk, P, RP, lik;
+  int MT, MP, DP, CT, CT16, ntri, nblocks;
+  size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
+  // workspace offsets (doubles)
+  size_t hdr, ils, ls, Zs, mpad, w, tp, tg;
+  size_t Kmm, L, J, JT, Lq, LqT, S_, Hp, Gf, Lb, LamB, Q, Y, Ks;
+  size_t red;    // reduced slab (same layout as one slab, G part unused)
+  size_t slabs;  // nblocks * slab_len
+  size_t total;  // doubles
+};
+
+// hdr slots
+enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_N = 16 };
+// slab scalar slots
+enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
+
+inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
+  if (D < 1 || D > 16) return -2;
+  if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
+  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
+  p.MT = (M + 15) / 16; p.MP = p.MT * 16;
+  p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
+  p.CT = (2 * p.DP + 1 + 15) / 16; p.CT16 = p.CT * 16;
+  p.ntri = p.MT * (p.MT + 1) / 2;
+  p.nblocks = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
+  if (p.nblocks < 1) p.nblocks = 1;
+  p.slab_G = 0;
+  p.slab_T = p.slab_G + (size_t)p.ntri * 256;
+  p.slab_S = p.slab_T + (size_t)p.MP * p.CT16;
+  p.slab_C = p.slab_S + p.MP;
+  p.slab_len = rup(p.slab_C + C_THETA + P, 16);
+  size_t o = 0;
+  const size_t mm = (size_t)p.MP * p.MP;
+  p.hdr = o; o += H_N;
+  p.ils = o; o += 16;
+  p.ls = o; o += 16;
+  p.Zs = o; o += (size_t)p.MP * p.DP;
+  p.mpad = o; o += p.MP;
+  p.w = o; o += p.MP;
+  p.tp = o; o += rup(P + 1, 16);
+  p.tg = o; o += rup(P + 1, 16);
+  p.Kmm = o; o += mm; p.L = o; o += mm; p.J = o; o += mm; p.JT = o; o += mm;
+  p.Lq = o; o += mm; p.LqT = o; o += mm; p.S_ = o; o += mm; p.Hp = o; o += mm;
+  p.Gf = o; o += mm; p.Lb = o; o += mm; p.LamB = o; o += mm; p.Q = o; o += mm; p.Y = o; o += mm; p.Ks = o; o += mm;
+  p.red = o; o += p.slab_len;
+  p.slabs = o; o += (size_t)p.nblocks * p.slab_len;
+  p.total = o;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scalar helpers (torch semantics)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }  // F.softplus, threshold 20
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+// sum over the four 16-lane groups (lanes l, l^16, l^32, l^48): every lane gets the total
+__device__ __forceinline__ double quad_sum(double x) {
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 16x16 output tile of opA(A) * opB(B) over k in [k0,k1) (multiples of 4), operands in global memory,
+// leading dimension ld.  TA: opA = A^T, TB: opB = B^T.  One wave.
+// ---------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__device__ __forceinline__ d4 tile_mm(const double* __restrict__ A, const double* __restrict__ B, int ld, int i0,
+                                      int j0, int k0, int k1, d4 acc) {
+  const int l = threadIdx.x & 63, r = l & 15, q = l >> 4;
+  for (int k = k0; k < k1; k += 4) {
+    const double a = TA ? A[(size_t)(k + q) * ld + i0 + r] : A[(size_t)(i0 + r) * ld + k + q];
+    const double b = TB ? B[(size_t)(j0 + r) * ld + k + q] : B[(size_t)(k + q) * ld + j0 + r];
+    acc = TGP_MFMA(a, b, acc);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// flows (models/flow.py).  `tp` = shared parameters after their positivity transform, `tg` = d(tp)/d(raw)
+// (both prepared once per step by k_prep_a); per-row parameters are transformed on the fly.
+// ---------------------------------------------------------------------------------------------------
+struct FlowDev {
+  const int32_t* prog;  // nblk x 4
+  int nblk;
+  const double* tp;
+  const double* tg;
+};
+
+// asinh exactly as the reference writes it (flow.py:904-905)
+__device__ __forceinline__ double asinh_ref(double f) { return log(f + sqrt(f * f + 1.0)); }
+
+// Forward through all blocks.  If stack != nullptr the input of block b is stored at stack[b*sstride]
+// (needed by flow_backward).  If dG != nullptr it receives dG/df.
+__device__ inline double flow_forward(const FlowDev& F, double f, const double* __restrict__ rp, double* stack,
+                                      int sstride, double* dG) {
+  double der = 1.0;
+  for (int b = 0; b < F.nblk; ++b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+    if (stack) stack[b * sstride] = f;
+    if (kind == TGP_FLOW_AFFINE) {
+      double a = pr ? rp[poff] : F.tp[poff];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
+      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      f = a * f + bb;
+      der *= a;
+    } else if (kind == TGP_FLOW_SAL) {
+      const double a = pr ? rp[poff] : F.tp[poff];
+      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
+      const double t = bb * asinh_ref(f) - a;
+      double g = sinh(t);
+      double gp = bb * cosh(t) / sqrt(1.0 + f * f);
+      if (flags & TGP_FLAG_ADD_F0) { g += f; gp += 1.0; }
+      f = g;
+      der *= gp;
+    } else {  // STEPTANH (shared parameters only; the reference raises NotImplementedError for per-row step flows)
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+      double g = addf ? f : 0.0, gp = addf ? 1.0 : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double a = F.tp[poff + 4 * k], bt = F.tp[poff + 4 * k + 1], c = F.tp[poff + 4 * k + 2],
+                     dt = F.tp[poff + 4 * k + 3];
+        const double th = tanh((f - c) / dt);
+        g += a + bt * th;
+        gp += bt * (1.0 - th * th) / dt;
+      }
+      f = g;
+      der *= gp;
+    }
+  }
+  if (dG) *dG = der;
+  return f;
+}
+
+// Reverse sweep for one node: `c` = d(objective)/dG on entry; returns d(objective)/df0.
+// Parameter partials are accumulated into lane-private LDS slots acc[slot*astride] (slot = poff+j for
+// shared parameters, P+poff+j for per-row ones).
+__device__ inline double flow_backward(const FlowDev& F, double c, const double* __restrict__ rp, const double* stack,
+                                       int sstride, double* acc, int astride, int P) {
+  for (int b = F.nblk - 1; b >= 0; --b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+    const int s0 = pr ? P + poff : poff;
+    const double f = stack[b * sstride];
+    if (kind == TGP_FLOW_AFFINE) {
+      double a, fa;
+      if (pr) {
+        a = rp[poff]; fa = 1.0;
+        if (flags & TGP_FLAG_RESTRICT) { fa = sigmoid_d(a); a = softplus_d(a); }
+      } else {
+        a = F.tp[poff]; fa = F.tg[poff];
+      }
+      acc[(s0 + 0) * astride] += c * f * fa;
+      acc[(s0 + 1) * astride] += c;
+      c *= a;
+    } else if (kind == TGP_FLOW_SAL) {
+      double a, bb, fb;
+      if (pr) {
+        a = rp[poff]; bb = rp[poff + 1]; fb = 1.0;
+        if (flags & TGP_FLAG_RESTRICT) { fb = sigmoid_d(bb); bb = softplus_d(bb); }
+      } else {
+        a = F.tp[poff]; bb = F.tp[poff + 1]; fb = F.tg[poff + 1];
+      }
+      const double u = asinh_ref(f);
+      const double ch = cosh(bb * u - a);
+      acc[(s0 + 0) * astride] -= c * ch;
+      acc[(s0 + 1) * astride] += c * u * ch * fb;
+      double gp = bb * ch / sqrt(1.0 + f * f);
+      if (flags & TGP_FLAG_ADD_F0) gp += 1.0;
+      c *= gp;
+    } else {
+      double gp = (flags & TGP_FLAG_ADD_F0) ? 1.0 : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const int o = poff + 4 * k;
+        const double bt = F.tp[o + 1], cc = F.tp[o + 2], dt = F.tp[o + 3];
+        const double t = (f - cc) / dt;
+        const double th = tanh(t);
+        const double se = bt * (1.0 - th * th) / dt;  // d/df of this step
+        acc[(o + 0) * astride] += c;
+        acc[(o + 1) * astride] += c * th * F.tg[o + 1];
+        acc[(o + 2) * astride] -= c * se;
+        acc[(o + 3) * astride] -= c * se * t * F.tg[o + 3];
+        gp += se;
+      }
+      c *= gp;
+    }
+  }
+  return c;
+}
+
+}  // namespace tgp

@@ -1,0 +1,290 @@
+// tgp_lik.hip -- stand-alone likelihood, flow, prediction and optimiser kernels.
+//
+// These serve the evaluation path, the operator-level API (K10/K11 of SURVEY 2.2) and
+// the trainer; the training step itself uses the fused row kernel (tgp_rows.hpp), which shares the
+// flow code in tgp_dev.hpp.  All of them are HBM/VALU-bound streaming kernels: one thread per row,
+// coalesced row-major reads, lane-private LDS accumulators, two-pass deterministic reductions.
+#include "tgp_dev.hpp"
+#include "tgp_launch.hpp"
+
+namespace tgp {
+
+#define LAUNCH_CHECK()                                              \
+  do {                                                              \
+    hipError_t e_ = hipGetLastError();                              \
+    if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
+  } while (0)
+
+size_t lik_workspace_doubles(int N, int P, int RP) {
+  const size_t nb = (size_t)(N + 255) / 256 + 1;
+  return nb * (size_t)(2 + P) + 2 * (size_t)P + 64;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SVGP closed form: likelihoods/GaussianLinearMean.py:60-87 + dsp/utils.py:164-195
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ell_gauss(const double* __restrict__ Y, const double* __restrict__ mu,
+                                                    const double* __restrict__ v, int N,
+                                                    const double* __restrict__ lvn, double scale,
+                                                    double* __restrict__ part, double* __restrict__ g_mu,
+                                                    double* __restrict__ g_v) {
+  __shared__ double red[8];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const double eta = lvn[0], einv = exp(-eta);
+  double e = 0.0, et = 0.0;
+  if (n < N) {
+    const double r = Y[n] - mu[n];
+    e = -0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * (r * r + v[n]);
+    et = -0.5 + 0.5 * einv * (r * r + v[n]);
+    if (g_mu) g_mu[n] = scale * einv * r;
+    if (g_v) g_v[n] = -0.5 * scale * einv;
+  }
+  e = wave_sum(e); et = wave_sum(et);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[4 + (threadIdx.x >> 6)] = et; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = scale * (red[0] + red[1] + red[2] + red[3]);
+    part[2 * blockIdx.x + 1] = scale * (red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+// sum `nb` partial vectors of length `len` (stride len) into out; single block
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int nb, int len,
+                                                    double* __restrict__ out, double* __restrict__ out2, int split) {
+  for (int j = threadIdx.x; j < len; j += 256) {
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(size_t)b * len + j];
+    if (j < split) out[j] = s;
+    else if (out2) out2[j - split] = s;
+  }
+}
+
+// transformed shared flow parameters into LDS (same rule as k_prep_a); whole block, ends with a barrier
+__device__ inline void flow_params_lds(const tgp_model& md, double* tp, double* tg) {
+  for (int b = threadIdx.x; b < md.nblk; b += blockDim.x) {
+    const int kind = md.program[4 * b], K = md.program[4 * b + 1], poff = md.program[4 * b + 2],
+              flags = md.program[4 * b + 3];
+    if (flags & TGP_FLAG_PER_ROW) continue;
+    const int np = kind == TGP_FLOW_STEPTANH ? 4 * K : 2;
+    for (int j = 0; j < np; ++j) {
+      const double x = md.theta[poff + j];
+      bool res;
+      if (kind == TGP_FLOW_STEPTANH) res = (j & 1);
+      else res = (flags & TGP_FLAG_RESTRICT) && j == (kind == TGP_FLOW_AFFINE ? 0 : 1);
+      tp[poff + j] = res ? softplus_d(x) : x;
+      tg[poff + j] = res ? sigmoid_d(x) : 1.0;
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), one thread per row
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, const double* __restrict__ Y,
+                                                   const double* __restrict__ mu, const double* __restrict__ v,
+                                                   const double* __restrict__ rowp, double* __restrict__ part,
+                                                   double* __restrict__ g_mu, double* __restrict__ g_v,
+                                                   double* __restrict__ g_rowp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x, P = md.P, RP = md.RP, nblk = md.nblk;
+  double* stack = sm;                                    // nblk * 256
+  double* acc = stack + (size_t)(nblk > 0 ? nblk : 1) * 256;  // (P+RP) * 256
+  double* red = acc + (size_t)(P + RP > 0 ? P + RP : 1) * 256;  // 16
+  double* tp = red + 16;                                 // P+2
+  double* tg = tp + (P + 2) / 2 * 2;                     // P+2
+  for (int i = tid; i < (P + RP) * 256; i += 256) acc[i] = 0.0;
+  flow_params_lds(md, tp, tg);
+  const int n = blockIdx.x * 256 + tid;
+  const double eta = md.log_var_noise[0], einv = exp(-eta);
+  FlowDev F{md.program, nblk, tp, tg};
+  double ellp = 0.0, etap = 0.0;
+  if (n < md.N) {
+    const double m_ = mu[n], sq = sqrt(2.0 * v[n]), y = Y[n];
+    const double* rp = rowp ? rowp + (size_t)n * RP : nullptr;
+    double cm = 0.0, cv = 0.0;
+    for (int s = 0; s < md.S; ++s) {
+      const double xsn = md.xs[s], wsn = md.wn[s];
+      const double g = flow_forward(F, m_ + sq * xsn, rp, stack + tid, 256, nullptr);
+      const double r = y - g;
+      ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+      etap += wsn * (-0.5 + 0.5 * einv * r * r);
+      const double c0 = flow_backward(F, md.scale * einv * wsn * r, rp, stack + tid, 256, acc + tid, 256, P);
+      cm += c0;
+      cv += c0 * xsn;
+    }
+    if (g_mu) g_mu[n] = cm;
+    if (g_v) g_v[n] = cv / sq;
+    if (g_rowp)
+      for (int j = 0; j < RP; ++j) g_rowp[(size_t)n * RP + j] = acc[(size_t)(P + j) * 256 + tid];
+  }
+  ellp = wave_sum(ellp); etap = wave_sum(etap);
+  if ((tid & 63) == 0) { red[tid >> 6] = ellp; red[4 + (tid >> 6)] = etap; }
+  __syncthreads();
+  double* pb = part + (size_t)blockIdx.x * (2 + P);
+  if (tid == 0) {
+    pb[0] = md.scale * (red[0] + red[1] + red[2] + red[3]);
+    pb[1] = md.scale * (red[4] + red[5] + red[6] + red[7]);
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int j = wave; j < P; j += 4) {
+    double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
+    s = wave_sum(s);
+    if (lane == 0) pb[2 + j] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// flow evaluation: G, dG/df, log dG/df over an (S,N) array (row n = idx % N)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, const double* __restrict__ f, size_t total, int N,
+                                                    const double* __restrict__ rowp, double* __restrict__ G,
+                                                    double* __restrict__ dG, double* __restrict__ logdG) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* tp = reinterpret_cast<double*>(smem_raw);
+  double* tg = tp + (md.P + 2) / 2 * 2;
+  flow_params_lds(md, tp, tg);
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  FlowDev F{md.program, md.nblk, tp, tg};
+  const double* rp = rowp ? rowp + (i % N) * md.RP : nullptr;
+  double der;
+  const double g = flow_forward(F, f[i], rp, nullptr, 0, &der);
+  if (G) G[i] = g;
+  if (dG) dG[i] = der;
+  if (logdG) logdG[i] = log(der);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prediction given q(f) moments: m1, m2 and per-row test log-likelihood (without the -0.5 log(pi) constant)
+//   flow : GaussianNonLinearMean.marginal_moments (:176-203) ; sparse_MF_SP.test_log_likelihood (:705-776)
+//   gauss: GaussianLinearMean.marginal_moments (:89-118)     ; sparse_MF_SP.py:786-799
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_predict(tgp_model md, const double* __restrict__ mu,
+                                                  const double* __restrict__ v, const double* __restrict__ rowp,
+                                                  const double* __restrict__ Y, double Y_std, double* __restrict__ m1o,
+                                                  double* __restrict__ m2o, double* __restrict__ logp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* tp = reinterpret_cast<double*>(smem_raw);
+  double* tg = tp + (md.P + 2) / 2 * 2;
+  if (md.lik == TGP_LIK_FLOW) flow_params_lds(md, tp, tg);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= md.N) return;
+  const double noise = exp(md.log_var_noise[0]);
+  if (md.lik == TGP_LIK_GAUSS) {
+    const double m1 = mu[n], m2 = noise + v[n];
+    if (m1o) m1o[n] = m1;
+    if (m2o) m2o[n] = m2;
+    if (logp && Y) {
+      const double sd = Y_std * sqrt(m2), var = sd * sd, r = Y_std * Y[n] - Y_std * m1;
+      logp[n] = -0.5 * (TGP_LOG_2PI_REF + log(var) + r * r / var);
+    }
+    return;
+  }
+  FlowDev F{md.program, md.nblk, tp, tg};
+  const double* rp = rowp ? rowp + (size_t)n * md.RP : nullptr;
+  const double m_ = mu[n], sq = sqrt(2.0 * v[n]);
+  const double sdy = Y_std * sqrt(noise), var = sdy * sdy;
+  const double yy = Y ? Y_std * Y[n] : 0.0;
+  double m1 = 0.0, e2 = 0.0, mx = -INFINITY, se = 0.0;
+  for (int s = 0; s < md.S; ++s) {
+    const double g = flow_forward(F, m_ + sq * md.xs[s], rp, nullptr, 0, nullptr);
+    const double wsn = md.wn[s];
+    m1 += wsn * g;
+    e2 += wsn * g * g;
+    if (logp && Y) {
+      // log w_s = log(wn_s) + 0.5 log(pi); the caller adds the reference's constants
+      const double r = yy - Y_std * g;
+      const double t = log(wsn) - 0.5 * (TGP_LOG_2PI_REF + log(var) + r * r / var);
+      if (t > mx) { se = se * exp(mx - t) + 1.0; mx = t; }
+      else se += exp(t - mx);
+    }
+  }
+  if (m1o) m1o[n] = m1;
+  if (m2o) m2o[n] = noise + e2 - m1 * m1;
+  if (logp && Y) logp[n] = mx + log(se);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics; dsp/trainers/optimizers.py:12)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(double* __restrict__ p, const double* __restrict__ g,
+                                               double* __restrict__ m, double* __restrict__ v, int64_t n, double lr,
+                                               double b1, double b2, double eps, double wd, double bc1, double bc2s,
+                                               double sign) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double gi = sign * g[i];
+  if (wd != 0.0) gi += wd * p[i];
+  const double mi = b1 * m[i] + (1.0 - b1) * gi;
+  const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* lvn, double scale,
+                     double* out, double* g_mu, double* g_v, double* ws, hipStream_t st) {
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(k_ell_gauss, dim3(nb), dim3(256), 0, st, Y, mu, v, N, lvn, scale, ws, g_mu, g_v);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, nb, 2, out, (double*)nullptr, 2);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+static int flow_lds(const tgp_model& md, size_t* bytes) {
+  const size_t d = (size_t)(md.nblk > 0 ? md.nblk : 1) * 256 + (size_t)(md.P + md.RP > 0 ? md.P + md.RP : 1) * 256 + 16 +
+                   2 * (size_t)(md.P + 2);
+  *bytes = d * sizeof(double);
+  return *bytes > 160 * 1024 - 64 ? TGP_E_LDS : 0;
+}
+
+int launch_ell_flow(const tgp_model& md, const double* Y, const double* mu, const double* v, const double* rowp,
+                    double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
+                    hipStream_t st) {
+  size_t lds;
+  if (int rc = flow_lds(md, &lds)) return rc;
+  static size_t lds_cur = 48 * 1024;
+  if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
+  const int nb = (md.N + 255) / 256;
+  hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_flow_eval(const tgp_model& md, const double* f, int S, int N, const double* rowp, double* G, double* dG,
+                     double* logdG, hipStream_t st) {
+  const size_t total = (size_t)S * N;
+  const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
+  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, md, f, total, N, rowp, G,
+                     dG, logdG);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_predict(const tgp_model& md, const double* mu, const double* v, const double* rowp, const double* Y,
+                   double Y_std, double* m1, double* m2, double* logp, hipStream_t st) {
+  const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
+  hipLaunchKernelGGL(k_predict, dim3((md.N + 255) / 256), dim3(256), lds, st, md, mu, v, rowp, Y, Y_std, m1, m2, logp);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                double beta1, double beta2, double eps, double weight_decay, int step, int maximize, hipStream_t st) {
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
+                     lr, beta1, beta2, eps, weight_decay, bc1, bc2s, maximize ? -1.0 : 1.0);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace tgp

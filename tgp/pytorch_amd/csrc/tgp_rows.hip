@@ -1,0 +1,33 @@
+// tgp_rows.hip -- dispatch of the fused row kernel over its compile-time tilings (MT = ceil(M/16), DP)
+#include "tgp_rows.hpp"
+#include "tgp_launch.hpp"
+
+namespace tgp {
+
+#define DECL(n) int launch_rows_mt##n(const RowArgs& a, bool train, size_t lds, hipStream_t st);
+DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7) DECL(8)
+#undef DECL
+
+int launch_rows(const Plan& p, const tgp_model& md, const double* X, const double* Y, const double* rowp,
+                double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
+  RowArgs a;
+  a.p = p;
+  a.X = X; a.Y = Y; a.rowp = rowp; a.g_rowp = g_rowp; a.mu = mu; a.v = v; a.ws = ws;
+  a.program = md.program; a.xs = md.xs; a.wn = md.wn; a.scale = md.scale;
+  const RowLds L = row_lds(p, train);
+  const size_t lds = L.total * sizeof(double);
+  if (lds > 160 * 1024 - 64) return TGP_E_LDS;
+  switch (p.MT) {
+    case 1: return launch_rows_mt1(a, train, lds, st);
+    case 2: return launch_rows_mt2(a, train, lds, st);
+    case 3: return launch_rows_mt3(a, train, lds, st);
+    case 4: return launch_rows_mt4(a, train, lds, st);
+    case 5: return launch_rows_mt5(a, train, lds, st);
+    case 6: return launch_rows_mt6(a, train, lds, st);
+    case 7: return launch_rows_mt7(a, train, lds, st);
+    case 8: return launch_rows_mt8(a, train, lds, st);
+  }
+  return TGP_E_UNSUPPORTED;
+}
+
+}  // namespace tgp

@@ -1,0 +1,316 @@
+// tgp_rows.hpp -- the fused row kernel of the ELBO step (one launch covers forward AND backward of
+// everything that scales with the number of rows).
+//
+// Replaces, per minibatch row n (reference: models/sparse_MF_SP.py:313-396, likelihoods/*.py,
+// models/flow.py and the autograd replay of all of it, trainers/trainer_base.py:341):
+//   K_n  = sigma^2 exp(-1/2 |xs_n - zs_j|^2)                 never written to HBM
+//   A    = L^-1 K_MN      (J K, lower-triangular MFMA GEMM)  reference: triangular_solve :380
+//   B    = L_q^T A        (upper-triangular MFMA GEMM)       reference: S = LqLq^T, matmul(S, rhs) :346,382
+//   mu   = m^T A ;  v = sigma^2 - sum A^2 + sum B^2          reference: :354-355, :376-382
+//   ell_n, d ell/d mu, d ell/d v, d ell/d theta, d ell/d eta  Gauss-Hermite through the flow (or closed form)
+//   Abar = m mubar^T - 2 A vbar + 2 L_q (B vbar) ; Kbar = L^-T Abar   (two more triangular MFMA GEMMs)
+//   row statistics  G = A diag(vbar) A^T, s = A mubar, T = (Kbar o K) [xs, xs^2, 1]   (MFMA, via LDS transpose)
+// One workgroup = 4 waves = 64 rows; one wave owns 16 rows and keeps K, A, B, Abar, Kbar in registers:
+// the accumulator layout of v_mfma_f64_16x16x4 is directly the B-operand layout of the next product.
+// Per-block statistics go to a slab in HBM (deterministic two-pass reduction, no atomics).
+#pragma once
+#include "tgp_dev.hpp"
+
+namespace tgp {
+
+struct RowArgs {
+  Plan p;
+  const double* X;
+  const double* Y;
+  const double* rowp;
+  double* g_rowp;
+  double* mu;
+  double* v;
+  double* ws;
+  const int32_t* program;
+  const double* xs;
+  const double* wn;
+  double scale;
+};
+
+// LDS carve-up (offsets in doubles)
+struct RowLds {
+  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, xs, wn, stack, acc, red, prog, total;
+};
+
+__host__ __device__ inline RowLds row_lds(const Plan& p, bool train) {
+  RowLds L;
+  size_t o = 0;
+  auto take = [&o](size_t n) { size_t r = o; o += (n + 1) / 2 * 2; return r; };  // keep 16-byte alignment
+  L.zs = take((size_t)p.MP * p.DP);
+  L.ils = take(16);
+  L.mv = take(p.MP);
+  L.tp = take(p.P + 1);
+  L.tg = take(p.P + 1);
+  L.xs = take(p.S + 1);
+  L.wn = take(p.S + 1);
+  L.prog = take((size_t)2 * p.nblk + 2);  // 4 int32 per block
+  L.red = take(32);
+  if (train) {
+    L.tile = take((size_t)p.MP * TGP_TILE_LD);
+    L.xt = take((size_t)TGP_ROWS_PER_BLOCK * p.CT16);
+    L.vbs = take(TGP_ROWS_PER_BLOCK);
+    L.mbs = take(TGP_ROWS_PER_BLOCK);
+    L.stack = take((size_t)(p.nblk > 0 ? p.nblk : 1) * 256);
+    L.acc = take((size_t)(p.P + p.RP > 0 ? p.P + p.RP : 1) * 256);
+  } else {
+    L.tile = L.xt = L.vbs = L.mbs = L.stack = L.acc = o;
+  }
+  L.total = o;
+  return L;
+}
+
+template <int MT, int DP, bool TRAIN>
+__global__ __launch_bounds__(256) void k_rows(RowArgs a) {
+  constexpr int MP = MT * 16;
+  constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
+  constexpr int LD = TGP_TILE_LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const Plan& p = a.p;
+  const RowLds L = row_lds(p, TRAIN);
+  double* zs = sm + L.zs;
+  double* ils = sm + L.ils;
+  double* mv = sm + L.mv;
+  double* tpL = sm + L.tp;
+  double* tgL = sm + L.tg;
+  double* xsL = sm + L.xs;
+  double* wnL = sm + L.wn;
+  int32_t* progL = reinterpret_cast<int32_t*>(sm + L.prog);
+  double* red = sm + L.red;
+  double* tile = sm + L.tile;
+  double* xt = sm + L.xt;
+  double* vbs = sm + L.vbs;
+  double* mbs = sm + L.mbs;
+  double* stack = sm + L.stack;
+  double* acc = sm + L.acc;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, q = lane >> 4;
+  const double* __restrict__ ws = a.ws;
+  const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
+
+  // ---- stage the small shared operands ----
+  for (int i = tid; i < MP * DP; i += 256) zs[i] = ws[p.Zs + i];
+  for (int i = tid; i < MP; i += 256) mv[i] = ws[p.mpad + i];
+  if (tid < 16) ils[tid] = ws[p.ils + tid];
+  if (p.lik == TGP_LIK_FLOW) {
+    for (int i = tid; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; }
+    for (int i = tid; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
+    for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.program[i];
+  }
+  if (TRAIN)
+    for (int i = tid; i < (P + RP) * 256; i += 256) acc[i] = 0.0;
+  __syncthreads();
+
+  const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
+  const int n = blockIdx.x * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
+  const bool valid = n < N;
+  const int nc = valid ? n : N - 1;
+
+  double x[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) x[d] = d < D ? a.X[(size_t)nc * D + d] * ils[d] : 0.0;
+
+  // ---- K tile in B-operand layout: Kr[ks] = K[m = 4 ks + q][row nl] ----
+  double Kr[4 * MT];
+#pragma unroll
+  for (int ks = 0; ks < 4 * MT; ++ks) {
+    const int mm = 4 * ks + q;
+    double d2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const double t = x[d] - zs[mm * DP + d];
+      d2 += t * t;
+    }
+    Kr[ks] = mm < M ? s2 * exp(-0.5 * d2) : 0.0;
+  }
+
+  // ---- A = J K : A_i = sum_{kb <= i} J[i,kb] K_kb ; A operand read from J^T (coalesced) ----
+  const double* __restrict__ JT = ws + p.JT;
+  const double* __restrict__ Jm = ws + p.J;
+  const double* __restrict__ Lq = ws + p.Lq;
+  const double* __restrict__ LqT = ws + p.LqT;
+  d4 Aa[MT], Ba[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4 * (i + 1); ++ks) c = TGP_MFMA(JT[(size_t)(4 * ks + q) * MP + 16 * i + nl], Kr[ks], c);
+    Aa[i] = c;
+  }
+  // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = i; kb < MT; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c = TGP_MFMA(Lq[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Aa[kb][r], c);
+    Ba[i] = c;
+  }
+  // ---- mu, v ----
+  double pm = 0.0, pa = 0.0, pb = 0.0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pm += mv[16 * i + 4 * r + q] * Aa[i][r];
+      pa += Aa[i][r] * Aa[i][r];
+      pb += Ba[i][r] * Ba[i][r];
+    }
+  pm = quad_sum(pm); pa = quad_sum(pa); pb = quad_sum(pb);
+  const double mu = pm, v = s2 - pa + pb;
+  if (a.mu != nullptr && q == 0 && valid) { a.mu[n] = mu; a.v[n] = v; }
+  if (!TRAIN) return;
+
+  // ---- expected log-likelihood and its adjoints ----
+  double mub = 0.0, vb = 0.0, ellp = 0.0, etap = 0.0;
+  const double y = a.Y[nc];
+  if (p.lik == TGP_LIK_GAUSS) {
+    // GaussianLinearMean.expected_log_prob (likelihoods/GaussianLinearMean.py:81-87)
+    const double r = y - mu;
+    mub = a.scale * einv * r;
+    vb = -0.5 * a.scale * einv;
+    if (q == 0) {
+      ellp = -0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * (r * r + v);
+      etap = -0.5 + 0.5 * einv * (r * r + v);
+    }
+  } else {
+    // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): nodes s = q, q+4, ...
+    FlowDev F{progL, p.nblk, tpL, tgL};
+    const double sq = sqrt(2.0 * v);
+    const double* rp = a.rowp != nullptr ? a.rowp + (size_t)nc * RP : nullptr;
+    double cm = 0.0, cv = 0.0;
+    if (valid) {
+      for (int s = q; s < p.S; s += 4) {
+        const double xsn = xsL[s], wsn = wnL[s];
+        const double g = flow_forward(F, mu + sq * xsn, rp, stack + tid, 256, nullptr);
+        const double r = y - g;
+        ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+        etap += wsn * (-0.5 + 0.5 * einv * r * r);
+        const double c0 = flow_backward(F, a.scale * einv * wsn * r, rp, stack + tid, 256, acc + tid, 256, P);
+        cm += c0;
+        cv += c0 * xsn;
+      }
+    }
+    mub = quad_sum(cm);
+    vb = quad_sum(cv) / sq;
+  }
+  if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
+
+  // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = J^T Abar ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i) Ba[i] *= vb;
+  d4 Ca[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb <= i; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c = TGP_MFMA(LqT[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Ba[kb][r], c);
+    Ca[i] = c;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ca[i][r] = mv[16 * i + 4 * r + q] * mub - 2.0 * Aa[i][r] * vb + 2.0 * Ca[i][r];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int kb = i; kb < MT; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c = TGP_MFMA(Jm[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Ca[kb][r], c);
+    Ba[i] = c;  // Kbar
+  }
+
+  double* slab = a.ws + p.slabs + (size_t)blockIdx.x * p.slab_len;
+  const int col = wave * 16 + nl;
+
+  // ---- phase 1: E = Kbar o K through LDS (transposed), T = E [xs, xs^2, 1] on MFMA ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Ba[i][r] * Kr[4 * i + r];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c) {
+    if ((c & 3) == q) {
+      double val = 0.0;
+      if (c < DP) val = x[c < DP ? c : 0];
+      else if (c < 2 * DP) val = x[(c - DP) < DP ? (c - DP) : 0] * x[(c - DP) < DP ? (c - DP) : 0];
+      else if (c == 2 * DP) val = 1.0;
+      xt[col * CT16 + c] = val;
+    }
+  }
+  __syncthreads();
+  for (int t = wave; t < MT * CT; t += 4) {
+    const int ti = t / CT, tc = t % CT;
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int nk = 0; nk < 16; ++nk)
+      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], xt[(4 * nk + q) * CT16 + 16 * tc + nl], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
+  }
+  __syncthreads();
+
+  // ---- phase 2: A through LDS, G = A diag(vbar) A^T (lower tiles), s = A mubar ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
+  if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
+  __syncthreads();
+  for (int t = wave; t < p.ntri; t += 4) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int nk = 0; nk < 16; ++nk)
+      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q] * vbs[4 * nk + q], tile[(16 * tj + nl) * LD + 4 * nk + q], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
+  }
+  for (int ti = wave; ti < MT; ti += 4) {
+    d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int nk = 0; nk < 16; ++nk)
+      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], nl == 0 ? mbs[4 * nk + q] : 0.0, c);
+    if (nl == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
+    }
+  }
+
+  // ---- scalars, flow parameter gradients ----
+  const double e1 = wave_sum(ellp), e2 = wave_sum(etap), e3 = wave_sum(q == 0 ? vb : 0.0);
+  if (lane == 0) { red[wave * 4] = e1; red[wave * 4 + 1] = e2; red[wave * 4 + 2] = e3; }
+  __syncthreads();
+  if (tid == 0) {
+    slab[p.slab_C + C_ELL] = a.scale * (red[0] + red[4] + red[8] + red[12]);
+    slab[p.slab_C + C_ETAB] = a.scale * (red[1] + red[5] + red[9] + red[13]);
+    slab[p.slab_C + C_SVB] = red[2] + red[6] + red[10] + red[14];
+    slab[p.slab_C + C_PAD] = 0.0;
+  }
+  for (int j = wave; j < P; j += 4) {
+    double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
+    s = wave_sum(s);
+    if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
+  }
+  for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
+  if (a.g_rowp != nullptr && q == 0 && valid) {
+    for (int jr = 0; jr < RP; ++jr) {
+      const double* ap = acc + (size_t)(P + jr) * 256 + wave * 64 + nl;
+      a.g_rowp[(size_t)n * RP + jr] = ap[0] + ap[16] + ap[32] + ap[48];
+    }
+  }
+}
+
+}  // namespace tgp

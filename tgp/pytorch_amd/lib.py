@@ -1,0 +1,97 @@
+"""ctypes binding of libtgp_hip.so (C ABI declared in include/tgp_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module
+raises.  PyTorch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtgp_hip.so")
+
+FLOW_AFFINE, FLOW_SAL, FLOW_STEPTANH = 0, 1, 2
+FLAG_RESTRICT, FLAG_ADD_F0, FLAG_PER_ROW = 1, 2, 4
+LIK_GAUSS, LIK_FLOW = 0, 1
+
+_dp = C.c_void_p
+
+
+class TgpModel(C.Structure):
+    _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("S", C.c_int32), ("nblk", C.c_int32),
+                ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("scale", C.c_double),
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp),
+                ("m", _dp), ("Lam", _dp), ("log_var_noise", _dp), ("theta", _dp), ("program", _dp), ("xs", _dp),
+                ("wn", _dp)]
+
+
+class TgpGrads(C.Structure):
+    _fields_ = [("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp), ("m", _dp), ("Lam", _dp), ("log_var_noise", _dp),
+                ("theta", _dp), ("rowp", _dp)]
+
+
+class TgpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "tgp_version": (C.c_int, []),
+    "tgp_last_error": (C.c_char_p, []),
+    "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
+    "tgp_elbo_step_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
+                                    C.c_size_t, _dp]),
+    "tgp_qf_moments_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_kmm_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _dp]),
+    "tgp_knm_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
+    "tgp_cholesky_f64": (C.c_int, [_dp, C.c_int32, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_kl_whitened_f64": (C.c_int, [_dp, _dp, C.c_int32, _dp, _dp, _dp, _dp]),
+    "tgp_ell_gauss_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, _dp, C.c_double, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_ell_flow_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t,
+                                   _dp]),
+    "tgp_flow_eval_f64": (C.c_int, [C.POINTER(TgpModel), _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp]),
+    "tgp_predict_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
+    "tgp_adam_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                               C.c_double, C.c_int32, C.c_int32, _dp]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+
+def load():
+    """Load libtgp_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgpError("libtgp_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C tgp/pytorch_amd/csrc` (%s)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tgp_last_error().decode() if rc == -103 else ""
+        raise TgpError("%s failed with code %d %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous float64/int32 CUDA(HIP) tensor, or NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TgpError("tensor must live on the GPU (got %s)" % t.device)
+    if not t.is_contiguous():
+        raise TgpError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,386 @@
+"""Operator layer: torch tensors in, HIP kernels underneath (through the C ABI in lib.py).
+
+`elbo_step` is the fused replacement of `sparse_MF_SP.ELBO` + `loss.backward()` for one minibatch
+(reference: code/dsp/models/sparse_MF_SP.py:552-598, code/dsp/trainers/trainer_base.py:337-341);
+`ElboFunction` wraps it as a torch.autograd.Function so the reference's trainer idiom
+(`loss = -ELBO; loss.backward(); optimizer.step()`) keeps working on the drop-in model classes.
+The other functions expose the stand-alone operators of the path.
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+class NanError(RuntimeError):
+    """Same role as gpytorch.utils.errors.NanError raised by dsp/utils.py:241-254."""
+
+
+class NotPSDError(RuntimeError):
+    pass
+
+
+class NumericalWarning(RuntimeWarning):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# quadrature nodes (gpytorch GaussHermiteQuadrature1D: numpy hermgauss) and workspace cache
+# ---------------------------------------------------------------------------------------------------
+_quad_cache = {}
+
+
+def gauss_hermite(S, device):
+    """(xs, wn = w/sqrt(pi), logw) as float64 device tensors."""
+    key = (int(S), str(device))
+    if key not in _quad_cache:
+        x, w = np.polynomial.hermite.hermgauss(int(S))
+        xs = torch.tensor(x, dtype=torch.float64, device=device)
+        wn = torch.tensor(w / math.sqrt(math.pi), dtype=torch.float64, device=device)
+        _quad_cache[key] = (xs, wn)
+    return _quad_cache[key]
+
+
+_ws_cache = {}
+
+
+def workspace(N, D, M, S, nblk, P, RP, device):
+    key = (N, D, M, S, nblk, P, RP, str(device), torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None:
+        nbytes = L.load().tgp_workspace_bytes(N, D, M, max(S, 1), nblk, P, RP)
+        if nbytes == 0:
+            raise L.TgpError("unsupported problem shape N=%d D=%d M=%d (this build: D<=16, M<=128)" % (N, D, M))
+        buf = torch.empty(nbytes // 8 + 16, dtype=torch.float64, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float64:
+        raise L.TgpError("%s must be float64 (the reference's main.py runs in float64), got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+class FlowSpec:
+    """Device-side description of a flow: program (nblk,4) int32, P shared scalars, RP per-row columns."""
+
+    def __init__(self, program, P, RP, device):
+        self.blocks = [tuple(int(v) for v in b) for b in program]
+        self.nblk = len(self.blocks)
+        self.P, self.RP = int(P), int(RP)
+        arr = np.array(self.blocks if self.blocks else [(0, 0, 0, 0)], dtype=np.int32)
+        self.program = torch.from_numpy(arr).to(device).contiguous()
+
+    def to(self, device):
+        return FlowSpec(self.blocks, self.P, self.RP, device)
+
+
+def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S):
+    md = L.TgpModel()
+    md.N, md.D = X.shape[0], X.shape[1]
+    md.M = m.numel()
+    md.scale, md.jitter, md.kl_scale = float(scale), float(jitter), float(kl_scale)
+    md.Z, md.raw_ls, md.raw_os = L.ptr(Z), L.ptr(raw_ls), L.ptr(raw_os)
+    md.m, md.Lam, md.log_var_noise = L.ptr(m), L.ptr(Lam), L.ptr(lvn)
+    keep = []
+    if flow is None:
+        md.lik, md.S, md.nblk, md.P, md.RP = L.LIK_GAUSS, 1, 0, 0, 0
+    else:
+        xs, wn = gauss_hermite(S, X.device)
+        keep += [xs, wn]
+        md.lik, md.S, md.nblk, md.P, md.RP = L.LIK_FLOW, int(S), flow.nblk, flow.P, flow.RP
+        md.program, md.xs, md.wn = L.ptr(flow.program), L.ptr(xs), L.ptr(wn)
+        md.theta = L.ptr(theta) if flow.P > 0 else None
+    return md, keep
+
+
+def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=None, rowp=None, S=None, jitter=0.0,
+              kl_scale=1.0, mb_global=None, want_moments=False):
+    """One fused ELBO evaluation + all gradients on the GPU.  Returns (out[4], grads dict, status[4], (mu, v)).
+
+    out = [ELL_shard - KL, ELL_shard, KL, 0]; grads are d(ELL_shard - kl_scale*KL)/d(param).
+    `mb_global` = global minibatch size when X is a row shard (defaults to X.shape[0])."""
+    lib = L.load()
+    X, Y = _c(X, "X"), _c(Y.reshape(-1), "Y")
+    Z, raw_ls, raw_os, m, Lam, lvn = (_c(t, n) for t, n in ((Z, "Z"), (raw_ls, "raw_ls"), (raw_os, "raw_os"), (m, "m"),
+                                                               (Lam, "Lam"), (lvn, "log_var_noise")))
+    theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
+    dev = X.device
+    N, D = X.shape
+    M = m.numel()
+    scale = float(N_total) / float(mb_global if mb_global is not None else N)
+    md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S)
+    ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev)
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
+         "m": torch.empty_like(m), "Lam": torch.empty_like(Lam), "lvn": torch.empty_like(lvn)}
+    gs = L.TgpGrads()
+    gs.Z, gs.raw_ls, gs.raw_os, gs.m, gs.Lam, gs.log_var_noise = (L.ptr(g[k]) for k in ("Z", "raw_ls", "raw_os", "m",
+                                                                                          "Lam", "lvn"))
+    if md.P > 0:
+        g["theta"] = torch.empty_like(theta)
+        gs.theta = L.ptr(g["theta"])
+    if md.RP > 0:
+        g["rowp"] = torch.empty_like(rowp)
+        gs.rowp = L.ptr(g["rowp"])
+    mu = v = None
+    if want_moments:
+        mu = torch.empty(N, dtype=torch.float64, device=dev)
+        v = torch.empty(N, dtype=torch.float64, device=dev)
+    rc = lib.tgp_elbo_step_f64(md, L.ptr(X), L.ptr(Y), L.ptr(rowp) if md.RP > 0 else None, L.ptr(out), gs, L.ptr(mu),
+                               L.ptr(v), L.ptr(status), L.ptr(ws), ws.numel() * 8, L.stream_ptr())
+    L.check(rc, "tgp_elbo_step_f64")
+    return out, g, status, (mu, v)
+
+
+def jitter_ladder(dtype=torch.float64, jitter=None):
+    """The retry values of psd_safe_cholesky (dsp/utils.py:256-269): jitter * 10^i, i = 0..2."""
+    if jitter is None:
+        jitter = 1e-6 if dtype == torch.float32 else 1e-8
+    return [jitter * (10 ** i) for i in range(3)]
+
+
+def raise_for_status(status, retrying=False):
+    """Translate the device status words into the reference's exceptions; returns True if a retry with more
+    jitter is needed."""
+    info, nan = int(status[0]), int(status[1])
+    if nan:
+        raise NanError("cholesky: K_MM contains NaN")
+    return info != 0
+
+
+def elbo_step_safe(*args, global_jitter=None, **kw):
+    """elbo_step + the reference's psd_safe_cholesky protocol (one device sync to read the status)."""
+    res = elbo_step(*args, **kw)
+    if not raise_for_status(res[2].cpu()):
+        return res
+    for jit in jitter_ladder(jitter=global_jitter):
+        kw["jitter"] = jit
+        res = elbo_step(*args, **kw)
+        if not raise_for_status(res[2].cpu()):
+            warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
+            return res
+    raise NotPSDError("K_MM not positive definite even with jitter %g (pivot %d)" % (jit, int(res[2][0])))
+
+
+class ElboFunction(torch.autograd.Function):
+    """(ELBO, ELL, KLD) = f(Z, raw_ls, raw_os, m, Lam, log_var_noise, theta, rowp); gradients flow through ELBO
+    (the reference trainer differentiates `-ELBO`, trainers/trainers_regression.py:85-86); ELL and KLD are
+    returned for logging and marked non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, X, Y, Z, raw_ls, raw_os, m, Lam, lvn, theta, rowp, cfg):
+        out, g, status, _ = elbo_step_safe(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, cfg["N_total"], flow=cfg.get("flow"),
+                                           theta=theta, rowp=rowp, S=cfg.get("S"),
+                                           kl_scale=cfg.get("kl_scale", 1.0), mb_global=cfg.get("mb_global"),
+                                           global_jitter=cfg.get("global_jitter")) \
+            if cfg.get("check_status", True) else \
+            elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, cfg["N_total"], flow=cfg.get("flow"), theta=theta,
+                      rowp=rowp, S=cfg.get("S"), kl_scale=cfg.get("kl_scale", 1.0), mb_global=cfg.get("mb_global"))
+        ctx.grads = g
+        ctx.shapes = tuple(None if t is None else t.shape for t in (Z, raw_ls, raw_os, m, Lam, lvn, theta, rowp))
+        cfg["last_status"] = status
+        elbo, ell, kld = out[0].clone(), out[1].clone(), out[2].clone()
+        ctx.mark_non_differentiable(ell, kld)
+        return elbo, ell, kld
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_ell, g_kld):
+        g = ctx.grads
+        keys = ("Z", "raw_ls", "raw_os", "m", "Lam", "lvn", "theta", "rowp")
+        res = []
+        for k, shp in zip(keys, ctx.shapes):
+            if shp is None or k not in g:
+                res.append(None)
+            else:
+                res.append((g[k] * g_elbo).reshape(shp))
+        return (None, None) + tuple(res) + (None,)
+
+
+# ---------------------------------------------------------------------------------------------------
+# stand-alone operators
+# ---------------------------------------------------------------------------------------------------
+def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True):
+    """q(f) marginals (models/sparse_MF_SP.py:274-396): returns mu, v of shape (N,)."""
+    lib = L.load()
+    X = _c(X, "X")
+    Z, raw_ls, raw_os, m, Lam = (_c(t, "param") for t in (Z, raw_ls, raw_os, m, Lam))
+    dev = X.device
+    lvn = torch.zeros(1, dtype=torch.float64, device=dev)
+    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 1.0, None, None, None)
+    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev)
+    mu = torch.empty(X.shape[0], dtype=torch.float64, device=dev)
+    v = torch.empty_like(mu)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = lib.tgp_qf_moments_f64(md, L.ptr(X), L.ptr(mu), L.ptr(v), L.ptr(status), L.ptr(ws), ws.numel() * 8,
+                                L.stream_ptr())
+    L.check(rc, "tgp_qf_moments_f64")
+    if check and raise_for_status(status.cpu()):
+        for jit in jitter_ladder():
+            md.jitter = jit
+            L.check(lib.tgp_qf_moments_f64(md, L.ptr(X), L.ptr(mu), L.ptr(v), L.ptr(status), L.ptr(ws),
+                                           ws.numel() * 8, L.stream_ptr()), "tgp_qf_moments_f64")
+            if not raise_for_status(status.cpu()):
+                warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
+                return mu, v
+        raise NotPSDError("K_MM not positive definite")
+    return mu, v
+
+
+def kmm(Z, raw_ls, raw_os, jitter=0.0):
+    lib = L.load()
+    Z, raw_ls, raw_os = _c(Z, "Z"), _c(raw_ls, "raw_ls"), _c(raw_os, "raw_os")
+    M, D = Z.shape
+    K = torch.empty(M, M, dtype=torch.float64, device=Z.device)
+    L.check(lib.tgp_kmm_f64(L.ptr(Z), L.ptr(raw_ls), L.ptr(raw_os), M, D, float(jitter), L.ptr(K), L.stream_ptr()),
+            "tgp_kmm_f64")
+    return K
+
+
+def knm(X, Z, raw_ls, raw_os):
+    lib = L.load()
+    X, Z, raw_ls, raw_os = _c(X, "X"), _c(Z, "Z"), _c(raw_ls, "raw_ls"), _c(raw_os, "raw_os")
+    N, D = X.shape
+    M = Z.shape[0]
+    K = torch.empty(N, M, dtype=torch.float64, device=X.device)
+    L.check(lib.tgp_knm_f64(L.ptr(X), L.ptr(Z), L.ptr(raw_ls), L.ptr(raw_os), N, M, D, L.ptr(K), L.stream_ptr()),
+            "tgp_knm_f64")
+    return K
+
+
+def cholesky(A, want_inverse=False):
+    """Lower Cholesky with LAPACK-style info (no jitter ladder here): returns (L, Linv or None, status)."""
+    lib = L.load()
+    A = _c(A, "A")
+    M = A.shape[0]
+    Lo = torch.empty_like(A)
+    Li = torch.empty_like(A) if want_inverse else None
+    status = torch.zeros(4, dtype=torch.int32, device=A.device)
+    L.check(lib.tgp_cholesky_f64(L.ptr(A), M, L.ptr(Lo), L.ptr(Li), L.ptr(status), None, 0, L.stream_ptr()),
+            "tgp_cholesky_f64")
+    return Lo, Li, status
+
+
+def psd_safe_cholesky(A, jitter=None):
+    """dsp/utils.py:222-270 on the GPU: returns (L, A_used)."""
+    Lo, _, status = cholesky(A)
+    if not raise_for_status(status.cpu()):
+        return Lo, A
+    Ap = A.clone()
+    prev = 0.0
+    for jit in jitter_ladder(A.dtype, jitter):
+        Ap.diagonal().add_(jit - prev)
+        prev = jit
+        Lo, _, status = cholesky(Ap)
+        if not raise_for_status(status.cpu()):
+            warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
+            return Lo, Ap
+    raise NotPSDError("matrix not positive definite even with jitter %g" % prev)
+
+
+def kl_whitened(m, Lam):
+    """Whitened KL and gradients (models/sparse_MF_SP.py:406-431): returns (KL 0-d, g_m, g_Lam)."""
+    lib = L.load()
+    m, Lam = _c(m, "m"), _c(Lam, "Lam")
+    out = torch.empty(1, dtype=torch.float64, device=m.device)
+    gm, gL = torch.empty_like(m), torch.empty_like(Lam)
+    L.check(lib.tgp_kl_whitened_f64(L.ptr(m), L.ptr(Lam), m.numel(), L.ptr(out), L.ptr(gm), L.ptr(gL),
+                                    L.stream_ptr()), "tgp_kl_whitened_f64")
+    return out[0], gm, gL
+
+
+def ell_gauss(Y, mu, v, lvn, scale=1.0):
+    """SVGP expected log-likelihood (likelihoods/GaussianLinearMean.py:60-87): (ELL, dELL/dlvn, g_mu, g_v)."""
+    lib = L.load()
+    Y, mu, v, lvn = _c(Y.reshape(-1), "Y"), _c(mu, "mu"), _c(v, "v"), _c(lvn, "lvn")
+    N = Y.numel()
+    ws = torch.empty(N // 256 * 2 + 256, dtype=torch.float64, device=Y.device)
+    out = torch.empty(2, dtype=torch.float64, device=Y.device)
+    gmu, gv = torch.empty_like(mu), torch.empty_like(v)
+    L.check(lib.tgp_ell_gauss_f64(L.ptr(Y), L.ptr(mu), L.ptr(v), N, L.ptr(lvn), float(scale), L.ptr(out), L.ptr(gmu),
+                                  L.ptr(gv), L.ptr(ws), ws.numel() * 8, L.stream_ptr()), "tgp_ell_gauss_f64")
+    return out[0], out[1], gmu, gv
+
+
+def _flow_model(N, S, flow, theta, lvn, dev, scale=1.0, lik=L.LIK_FLOW):
+    md = L.TgpModel()
+    md.N, md.D, md.M, md.S = N, 1, 1, int(S)
+    md.nblk, md.P, md.RP, md.lik = flow.nblk, flow.P, flow.RP, lik
+    md.scale, md.jitter, md.kl_scale = float(scale), 0.0, 1.0
+    xs, wn = gauss_hermite(S, dev)
+    md.program, md.xs, md.wn = L.ptr(flow.program), L.ptr(xs), L.ptr(wn)
+    md.theta = L.ptr(theta) if flow.P > 0 else None
+    md.log_var_noise = L.ptr(lvn)
+    return md, (xs, wn)
+
+
+def ell_flow(Y, mu, v, lvn, flow, theta, S, rowp=None, scale=1.0):
+    """TGP quadrature ELL with gradients (likelihoods/GaussianNonLinearMean.py:64-150).
+    Returns dict(ell, g_lvn, g_mu, g_v, g_theta, g_rowp)."""
+    lib = L.load()
+    Y, mu, v, lvn = _c(Y.reshape(-1), "Y"), _c(mu, "mu"), _c(v, "v"), _c(lvn, "lvn")
+    theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
+    dev, N = Y.device, Y.numel()
+    md, keep = _flow_model(N, S, flow, theta, lvn, dev, scale)
+    nws = (N // 256 + 2) * (2 + flow.P) + 2 * flow.P + 128
+    ws = torch.empty(nws, dtype=torch.float64, device=dev)
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    gmu, gv = torch.empty_like(mu), torch.empty_like(v)
+    gth = torch.empty(max(flow.P, 1), dtype=torch.float64, device=dev)
+    grp = torch.empty_like(rowp) if rowp is not None else None
+    L.check(lib.tgp_ell_flow_f64(md, L.ptr(Y), L.ptr(mu), L.ptr(v), L.ptr(rowp), L.ptr(out), L.ptr(gmu), L.ptr(gv),
+                                 L.ptr(gth), L.ptr(grp), L.ptr(ws), ws.numel() * 8, L.stream_ptr()),
+            "tgp_ell_flow_f64")
+    return {"ell": out[0], "g_lvn": out[1], "g_mu": gmu, "g_v": gv, "g_theta": gth[:flow.P], "g_rowp": grp}
+
+
+def flow_eval(f, flow, theta, rowp=None, want=("G", "dG", "logdG")):
+    """G(f), dG/df, log dG/df for f of shape (S,N) or (N,) (CompositeFlow.forward / forward_grad)."""
+    lib = L.load()
+    f = _c(f, "f")
+    theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
+    f2 = f.reshape(1, -1) if f.dim() == 1 else f
+    S, N = f2.shape
+    lvn = torch.zeros(1, dtype=torch.float64, device=f.device)
+    md, keep = _flow_model(N, 1, flow, theta, lvn, f.device)
+    outs = {k: (torch.empty_like(f) if k in want else None) for k in ("G", "dG", "logdG")}
+    L.check(lib.tgp_flow_eval_f64(md, L.ptr(f2), S, N, L.ptr(rowp), L.ptr(outs["G"]), L.ptr(outs["dG"]),
+                                  L.ptr(outs["logdG"]), L.stream_ptr()), "tgp_flow_eval_f64")
+    return outs
+
+
+def predict(mu, v, lvn, flow=None, theta=None, S=None, rowp=None, Y=None, Y_std=1.0):
+    """Predictive moments m1, m2 and per-row test log-likelihood kernel (see tgp_predict_f64)."""
+    lib = L.load()
+    mu, v, lvn = _c(mu, "mu"), _c(v, "v"), _c(lvn, "lvn")
+    theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
+    dev, N = mu.device, mu.numel()
+    if flow is None:
+        md = L.TgpModel()
+        md.N, md.D, md.M, md.S, md.lik = N, 1, 1, 1, L.LIK_GAUSS
+        md.log_var_noise = L.ptr(lvn)
+        keep = None
+    else:
+        md, keep = _flow_model(N, S, flow, theta, lvn, dev)
+    m1, m2 = torch.empty_like(mu), torch.empty_like(mu)
+    logp = torch.empty_like(mu) if Y is not None else None
+    Yc = _c(Y.reshape(-1), "Y") if Y is not None else None
+    L.check(lib.tgp_predict_f64(md, L.ptr(mu), L.ptr(v), L.ptr(rowp), L.ptr(Yc), float(Y_std), L.ptr(m1), L.ptr(m2),
+                                L.ptr(logp), L.stream_ptr()), "tgp_predict_f64")
+    return m1, m2, logp
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+              maximize=False):
+    """In-place Adam on flat float64 buffers (torch.optim.Adam semantics)."""
+    lib = L.load()
+    L.check(lib.tgp_adam_f64(L.ptr(params), L.ptr(grads), L.ptr(exp_avg), L.ptr(exp_avg_sq), params.numel(), lr,
+                             betas[0], betas[1], eps, weight_decay, int(step), int(bool(maximize)), L.stream_ptr()),
+            "tgp_adam_f64")
