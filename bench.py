@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- ELBO-steps/sec of the TGP sparse-variational hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = forward ELBO + backward + Adam update on one full Power-sized minibatch (reference semantics,
+code/dsp/trainers/trainer_base.py:337-342), float64 like the reference's main.py.  Default workload =
+BASELINE.json configs[2]: TGP on Power (N=8611 training rows, D=4), M=100, 3-block tanh flow (StepTanhL 3x2),
+S=32 Gauss-Hermite nodes; synthetic seeded data of that shape, data resident in HBM.
+Multi-GPU is weak scaling: every rank owns a Power-sized row shard of a W-times larger minibatch, one RCCL
+all-reduce of the flat [gradient | ELL | KL] buffer per step; `value` counts Power-sized shard-steps per second
+over the whole job.
+
+Extra objects on the JSON line (rank 0):
+  roofline      dominant kernel = the fused row kernel k_rows; achieved = algorithmic FLOP per launch
+                 / its average duration measured with HIP events on the launch stream.
+  cpu_baseline  the oracle (CPU restatement of the reference's op sequence, eager PyTorch float64 + torch Adam)
+                timed on this host's cores on a bounded number of steps of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak (AMD datasheet; the microarch guide lists no f64 row)
+
+WORKLOADS = {
+    # name: (N, D, M, S, flow, blocks B, flop-equivalents per block-node c)   [SURVEY.md 8(d)]
+    "tgp_power_tanh3x2": dict(N=8611, D=4, M=100, S=32, flow="tanh3x2", B=3, c=20),   # BASELINE.json configs[2]
+    "tgp_power_sal2": dict(N=8611, D=4, M=100, S=32, flow="sal2", B=2, c=20),          # reference default for Power TGP
+    "svgp_power": dict(N=8611, D=4, M=100, S=32, flow=None, B=0, c=0),                 # BASELINE.json configs[1]
+    "svgp_boston": dict(N=455, D=13, M=5, S=32, flow=None, B=0, c=0),                  # BASELINE.json configs[0]
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def rows_kernel_flops(w):
+    """Algorithmic FLOP of one k_rows launch: the row-dependent terms of SURVEY.md 8(d), forward x3."""
+    N, D, M, S = w["N"], w["D"], w["M"], w["S"]
+    fwd = N * M * (3 * D + 1) + 2 * M * M * N + 6 * M * N + S * N * w["B"] * w["c"]
+    return 3.0 * fwd
+
+
+def make_problem(w, seed):
+    from oracle import tgp_oracle as orc          # test infrastructure: only used to BUILD the synthetic inputs
+    return orc.synthetic_problem(w["N"], w["D"], w["M"], seed=seed, flow=w["flow"], S=w["S"])
+
+
+def cpu_baseline(prob, budget_s=15.0, max_steps=400):
+    """Oracle step (reference-shaped eager PyTorch-CPU float64 + autograd + torch Adam) on the host cores."""
+    from oracle import tgp_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in prob["params"].items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
+
+    def one():
+        elbo, _, _ = orc.elbo(prob["X"], prob["Y"], leaves["Z"], leaves["raw_lengthscale"], leaves["raw_outputscale"],
+                              leaves["m"], leaves["Lam"], leaves["log_var_noise"], prob["N_total"], prob["program"],
+                              leaves.get("theta"), prob["xs"], prob["ws"])
+        opt.zero_grad()
+        (-elbo).backward()
+        opt.step()
+    for _ in range(3):
+        one()
+    t0 = time.perf_counter()
+    n = 0
+    while n < max_steps and time.perf_counter() - t0 < budget_s:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "ELBO-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d steps of the same workload (oracle/tgp_oracle.py, float64, torch.optim.Adam), %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="tgp_power_tanh3x2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
+                                             device_id=dev)
+
+    from tgp.pytorch_amd.engine import ElboEngine
+
+    w = WORKLOADS[args.workload]
+    prob = make_problem(w, seed=rank)              # every rank: its own Power-sized shard, same parameters (seed 0)
+    params = make_problem(w, seed=0)["params"] if rank else prob["params"]
+    eng = ElboEngine(prob["X"], prob["Y"], params, N_total=float(w["N"] * world), flow_blocks=prob["program"],
+                     S=w["S"], device=dev, world_size=world, rank=rank, mb_global=w["N"] * world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (eager), capture, then the timed region --------------------------------------------------------
+    run = eng.step
+    for _ in range(min(args.warmup, 10)):
+        eng.step()
+    eng.check_status()
+    if not args.no_graph:
+        eng.capture()
+        run = eng.replay
+    for _ in range(args.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    eng.check_status()
+    elbo, ell, kl = eng.scalars()
+    if not (elbo == elbo):
+        raise SystemExit("non-finite ELBO after the timed region")
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events around the row-kernel launch, same stream -----------------
+        eng.elbo(1)
+        n_ev = min(max(args.steps // 4, 50), 500)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            eng.elbo(2)
+            b.record()
+        torch.cuda.synchronize()
+        ks = sorted(a.elapsed_time(b) for a, b in evs)
+        k_ms = sum(ks) / len(ks)
+        flop = rows_kernel_flops(w)
+        achieved = flop / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_rows_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32",
+            "value": world * args.steps / dt, "unit": "ELBO-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "rows_per_gpu": w["N"], "D": w["D"], "M": w["M"], "S": w["S"],
+                       "flow": w["flow"], "global_rows_per_step": w["N"] * world, "parallelism": "row-shard x%d" % world,
+                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo},
+            "roofline": {"bound": "mfma", "kernel": "k_rows (fused K_NM + 4 triangular GEMMs + flow quadrature + SYRK)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel_ms": k_ms, "kernel_ms_min": ks[0], "flop_per_launch": flop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,17 @@ int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, 
                       const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* Same call restricted to some of its phases (profiling / roofline measurement: bench.py brackets one phase with
+ * HIP events).  phases: bit0 = M x M prepare (K_MM, Cholesky, L^-1, KL), bit1 = fused row kernel,
+ * bit2 = slab reduction + M x M adjoint + gradient assembly.  Phases must have run in order at least once on the
+ * same workspace; tgp_elbo_step_f64 == phases 7. */
+#define TGP_PHASE_PREPARE 1u
+#define TGP_PHASE_ROWS 2u
+#define TGP_PHASE_BACKWARD 4u
+int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp,
+                             double* out, const tgp_grads* grads, double* mu, double* v, int32_t* status,
+                             void* workspace, size_t workspace_bytes, uint32_t phases, void* stream);
+
 /* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
  * whitened, diagonal=True).  mu, v: (N). */
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
@@ -169,6 +180,12 @@ int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, c
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                  double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t maximize,
                  void* stream);
+
+/* Graph-capturable Adam: the step count lives on the device (`step_dev`, int32, starts at 0) so that a captured
+ * launch stays valid across replays; the call uses step = *step_dev + 1 and then increments the counter. */
+int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int32_t maximize,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,12 @@ size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t n
 int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
                       const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
                       size_t workspace_bytes, void* stream) {
+  return tgp_elbo_step_phases_f64(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes, 7u, stream);
+}
+
+int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp,
+                             double* out, const tgp_grads* grads, double* mu, double* v, int32_t* status,
+                             void* workspace, size_t workspace_bytes, uint32_t phases, void* stream) {
   if (int rc = check_model(model, true)) return rc;
   if (!X) return -2;
   if (!Y) return -3;
@@ -73,9 +79,13 @@ int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, 
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
   md.nblk = nblk; md.P = P; md.RP = RP;
-  if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
-  if (int rc = launch_rows(p, md, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
-  return launch_backward_mm(p, md, *grads, out, ws, st);
+  if (phases & TGP_PHASE_PREPARE)
+    if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
+  if (phases & TGP_PHASE_ROWS)
+    if (int rc = launch_rows(p, md, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
+  if (phases & TGP_PHASE_BACKWARD)
+    if (int rc = launch_backward_mm(p, md, *grads, out, ws, st)) return rc;
+  return 0;
 }
 
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
@@ -206,6 +216,19 @@ int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* e
   if (step < 1) return -11;
   return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, maximize,
                      static_cast<hipStream_t>(stream));
+}
+
+int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int32_t maximize,
+                     void* stream) {
+  if (!params) return -1;
+  if (!grads) return -2;
+  if (!exp_avg) return -3;
+  if (!exp_avg_sq) return -4;
+  if (n < 1) return -5;
+  if (!step_dev) return -11;
+  return launch_adam_dev(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize,
+                         static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

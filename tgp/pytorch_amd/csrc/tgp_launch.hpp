@@ -44,6 +44,9 @@ int launch_predict(const tgp_model& md, const double* mu, const double* v, const
                    double Y_std, double* m1, double* m2, double* logp, hipStream_t st);
 int launch_adam(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                 double beta1, double beta2, double eps, double weight_decay, int step, int maximize, hipStream_t st);
+int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
+                    hipStream_t st);
 size_t lik_workspace_doubles(int N, int P, int RP);
 
 }  // namespace tgp

@@ -224,6 +224,26 @@ __global__ __launch_bounds__(256) void k_adam(double* __restrict__ p, const doub
   p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
 }
 
+// device-side step counter variant (hipGraph replay): step = *step_dev + 1, counter bumped by k_step_inc afterwards
+__global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const double* __restrict__ g,
+                                                   double* __restrict__ m, double* __restrict__ v, int64_t n, double lr,
+                                                   double b1, double b2, double eps, double wd,
+                                                   const int32_t* __restrict__ step_dev, double sign) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double step = (double)(step_dev[0] + 1);
+  const double bc1 = 1.0 - pow(b1, step), bc2s = sqrt(1.0 - pow(b2, step));
+  double gi = sign * g[i];
+  if (wd != 0.0) gi += wd * p[i];
+  const double mi = b1 * m[i] + (1.0 - b1) * gi;
+  const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
+}
+
+__global__ void k_step_inc(int32_t* step_dev) { step_dev[0] += 1; }
+
 // ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
@@ -283,6 +303,17 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
   const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n,
                      lr, beta1, beta2, eps, weight_decay, bc1, bc2s, maximize ? -1.0 : 1.0);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
+                     n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_dev);
   LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,171 @@
+"""Step engine: the reference's inner training loop (code/dsp/trainers/trainer_base.py:329-349 --
+ELBO -> (-ELBO).backward() -> Adam.step()) with everything resident on the GPU.
+
+* every trainable tensor is a view into ONE flat float64 buffer (parameters, gradients, Adam moments),
+  so the optimiser is a single launch and the multi-GPU exchange is a single all-reduce;
+* the C-ABI argument structs are built once (pointers never change), so one step is
+  `tgp_elbo_step_f64` + `tgp_adam_dev_f64` = 11 kernel launches with no host synchronisation;
+* `capture()` records that sequence into a HIP graph (torch.cuda.CUDAGraph is only the stream/graph
+  plumbing) and `replay()` re-launches it;
+* multi-GPU (one process per GPU): rows are sharded, every rank runs the same M x M work, and ONE
+  all-reduce(sum) over RCCL/xGMI of [gradients | ELL | KL/W] makes every rank's buffer complete
+  (SURVEY.md 8e); the KL gradient enters each rank with weight 1/world so the sum counts it once.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from . import ops
+
+ORDER = ("Z", "raw_ls", "raw_os", "m", "Lam", "lvn", "theta")
+
+
+class FlatParams:
+    """[Z | raw_ls | raw_os | m | Lam | lvn | theta] as views of one buffer (plus same-shaped grads/moments)."""
+
+    def __init__(self, tensors, device):
+        self.shapes = {k: tuple(tensors[k].shape) for k in ORDER if tensors.get(k) is not None}
+        self.sizes = {k: int(torch.tensor(self.shapes[k]).prod()) if len(self.shapes[k]) else 1 for k in self.shapes}
+        n = sum(self.sizes.values())
+        self.n = n
+        self.extra = 4  # [ELBO, ELL, KL, 0] ride at the end of the gradient buffer so one all-reduce carries them
+        self.data = torch.zeros(n, dtype=torch.float64, device=device)
+        self.grad = torch.zeros(n + self.extra, dtype=torch.float64, device=device)
+        self.exp_avg = torch.zeros(n, dtype=torch.float64, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float64, device=device)
+        self.offsets = {}
+        o = 0
+        for k in ORDER:
+            if k in self.shapes:
+                self.offsets[k] = o
+                self.view(k).copy_(tensors[k].to(device=device, dtype=torch.float64))
+                o += self.sizes[k]
+
+    def view(self, k, buf=None):
+        buf = self.data if buf is None else buf
+        o = self.offsets[k]
+        return buf[o:o + self.sizes[k]].view(self.shapes[k])
+
+    def gview(self, k):
+        return self.view(k, self.grad)
+
+    @property
+    def out(self):
+        return self.grad[self.n:self.n + self.extra]
+
+
+class ElboEngine:
+    def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
+                 eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
+        self.X = X.to(self.device, torch.float64).contiguous()
+        self.Y = Y.reshape(-1).to(self.device, torch.float64).contiguous()
+        self.N, self.D = self.X.shape
+        names = {"Z": "Z", "raw_ls": "raw_lengthscale", "raw_os": "raw_outputscale", "m": "m", "Lam": "Lam",
+                 "lvn": "log_var_noise", "theta": "theta"}
+        tensors = {k: params.get(v, params.get(k)) for k, v in names.items()}
+        tensors["raw_ls"] = tensors["raw_ls"].reshape(-1)
+        tensors["raw_os"] = tensors["raw_os"].reshape(-1)
+        tensors["lvn"] = tensors["lvn"].reshape(-1)
+        self.fp = FlatParams(tensors, self.device)
+        self.M = self.fp.sizes["m"]
+        self.flow = None
+        self.S = int(S) if S else 1
+        P = self.fp.sizes.get("theta", 0)
+        self.rowp = rowp.to(self.device, torch.float64).contiguous() if rowp is not None else None
+        RP = self.rowp.shape[1] if self.rowp is not None else 0
+        if flow_blocks is not None:
+            self.flow = ops.FlowSpec(flow_blocks, P, RP, self.device)
+        self.g_rowp = torch.zeros_like(self.rowp) if self.rowp is not None else None
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        mbg = mb_global if mb_global is not None else self.N
+        scale = float(N_total) / float(mbg)
+        fp = self.fp
+        self.md, self._keep = ops._model_struct(self.X, fp.view("Z"), fp.view("raw_ls"), fp.view("raw_os"), fp.view("m"),
+                                                fp.view("Lam"), fp.view("lvn"), scale, 0.0, 1.0 / self.world_size,
+                                                self.flow, fp.view("theta") if P else None, self.S)
+        self.gs = L.TgpGrads()
+        self.gs.Z, self.gs.raw_ls, self.gs.raw_os = (L.ptr(fp.gview(k)) for k in ("Z", "raw_ls", "raw_os"))
+        self.gs.m, self.gs.Lam, self.gs.log_var_noise = (L.ptr(fp.gview(k)) for k in ("m", "Lam", "lvn"))
+        if P:
+            self.gs.theta = L.ptr(fp.gview("theta"))
+        if RP:
+            self.gs.rowp = L.ptr(self.g_rowp)
+        self.ws = ops.workspace(self.N, self.D, self.M, self.md.S, self.md.nblk, self.md.P, self.md.RP, self.device)
+        self.graph = None
+        self._warm = False
+
+    # ---- one step, eager launches ------------------------------------------------------------------
+    def elbo(self, phases=7):
+        rc = self.lib.tgp_elbo_step_phases_f64(self.md, L.ptr(self.X), L.ptr(self.Y), L.ptr(self.rowp),
+                                               L.ptr(self.fp.out), self.gs, None, None, L.ptr(self.status),
+                                               L.ptr(self.ws), self.ws.numel() * 8, phases, L.stream_ptr())
+        L.check(rc, "tgp_elbo_step_phases_f64")
+        self._warm = True
+
+    def allreduce(self):
+        if self.world_size > 1:
+            # out[2] (KL) is identical on every rank: pre-divide so the sum restores it; ELBO is rebuilt after
+            self.fp.out[2].div_(self.world_size)
+            torch.distributed.all_reduce(self.fp.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self.fp.out[0] = self.fp.out[1] - self.fp.out[2]
+
+    def adam(self):
+        rc = self.lib.tgp_adam_dev_f64(L.ptr(self.fp.data), L.ptr(self.fp.grad), L.ptr(self.fp.exp_avg),
+                                       L.ptr(self.fp.exp_avg_sq), self.fp.n, self.lr, self.betas[0], self.betas[1],
+                                       self.eps, 0.0, L.ptr(self.step_dev), 1, L.stream_ptr())
+        L.check(rc, "tgp_adam_dev_f64")
+
+    def step(self):
+        self.elbo()
+        self.allreduce()
+        self.adam()
+
+    # ---- HIP graph ----------------------------------------------------------------------------------
+    def capture(self, with_allreduce=None):
+        """Capture one full step.  With world_size > 1 the all-reduce stays outside (two graphs) unless
+        with_allreduce=True."""
+        if not self._warm:
+            self.elbo()                      # first launch sets kernel attributes; must happen outside capture
+        torch.cuda.synchronize()
+        if self.world_size > 1 and not with_allreduce:
+            self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1):
+                self.elbo()
+            with torch.cuda.graph(self.g2):
+                self.adam()
+            self.graph = "split"
+        else:
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1):
+                self.elbo()
+                self.allreduce()
+                self.adam()
+            self.graph = "full"
+
+    def replay(self):
+        if self.graph == "full":
+            self.g1.replay()
+        else:
+            self.g1.replay()
+            self.allreduce()
+            self.g2.replay()
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------
+    def check_status(self):
+        """Lazy Cholesky check (one sync): raises like the reference's psd_safe_cholesky would."""
+        st = self.status.cpu()
+        if int(st[1]):
+            raise ops.NanError("cholesky: K_MM contains NaN")
+        if int(st[0]):
+            raise ops.NotPSDError("K_MM not positive definite at pivot %d (engine runs without the jitter ladder; "
+                                  "use ops.elbo_step_safe to retry with jitter)" % int(st[0]))
+
+    def scalars(self):
+        o = self.fp.out.cpu()
+        return float(o[0]), float(o[1]), float(o[2])

@@ -43,6 +43,8 @@ _SIGS = {
     "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
     "tgp_elbo_step_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
                                     C.c_size_t, _dp]),
+    "tgp_elbo_step_phases_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp,
+                                           _dp, C.c_size_t, C.c_uint32, _dp]),
     "tgp_qf_moments_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
     "tgp_kmm_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _dp]),
     "tgp_knm_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
@@ -55,6 +57,8 @@ _SIGS = {
     "tgp_predict_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
     "tgp_adam_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int32, C.c_int32, _dp]),
+    "tgp_adam_dev_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, _dp, C.c_int32, _dp]),
 }
 
 EXPORTS = tuple(_SIGS.keys())
