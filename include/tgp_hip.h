@@ -11,7 +11,8 @@
  * Conventions
  *   - all matrices row-major, contiguous, float64 (`_f64`; the reference's main.py runs in float64,
  *     dsp/config.py:37-46);
- *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr());
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()), with ONE exception:
+ *     tgp_model.program (a few int32 describing the flow) is a HOST array, read during the call;
  *     outputs and the workspace are pre-allocated by the caller, nothing is allocated inside;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered, safe
  *     to capture into a hipGraph, and re-entrant when callers use distinct streams + workspaces;
@@ -84,7 +85,7 @@ typedef struct tgp_model {
   const double* Lam;           /* (M,M)   [q_U.chol_variational_covar] dense, tril at use   */
   const double* log_var_noise; /* (1)     [likelihood.log_var_noise]                        */
   const double* theta;         /* (P)     [G_matrix.0.flow_arr.*] or NULL                   */
-  const int32_t* program;      /* (nblk,4) or NULL                                          */
+  const int32_t* program;      /* (nblk,4) HOST array (copied into the kernel arguments), NULL if none; nblk <= 64 */
   const double* xs;            /* (S) Gauss-Hermite nodes                                   */
   const double* wn;            /* (S) weights / sqrt(pi)                                    */
 } tgp_model;
@@ -181,8 +182,9 @@ int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* e
                  double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t maximize,
                  void* stream);
 
-/* Graph-capturable Adam: the step count lives on the device (`step_dev`, int32, starts at 0) so that a captured
- * launch stays valid across replays; the call uses step = *step_dev + 1 and then increments the counter. */
+/* Graph-capturable Adam: the step count lives on the device (`step_dev`, int32[2] = {step, ticket}, both start at
+ * 0) so that a captured launch stays valid across replays; the call uses step = step_dev[0] + 1 and the last
+ * workgroup to finish increments the counter. */
 int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int32_t maximize,
                      void* stream);

@@ -29,6 +29,27 @@ static int check_model(const tgp_model* m, bool need_lik) {
   return 0;
 }
 
+// host array (nblk x 4 int32) -> by-value kernel argument; validates kinds and parameter offsets
+static int make_prog(const tgp_model* m, bool flow, FlowProg& fp) {
+  fp.nblk = 0;
+  fp.nslots = 0;
+  if (!flow || m->nblk <= 0) return 0;
+  if (m->nblk > TGP_MAX_BLOCKS) return TGP_E_UNSUPPORTED;
+  if (!m->program) return -1;
+  fp.nblk = m->nblk;
+  for (int b = 0; b < m->nblk; ++b) {
+    const int kind = m->program[4 * b], K = m->program[4 * b + 1], poff = m->program[4 * b + 2],
+              flags = m->program[4 * b + 3];
+    if (kind < TGP_FLOW_AFFINE || kind > TGP_FLOW_STEPTANH) return -1;
+    const int np = kind == TGP_FLOW_STEPTANH ? 4 * K : 2;
+    if (kind == TGP_FLOW_STEPTANH && (K < 1 || (flags & TGP_FLAG_PER_ROW))) return -1;
+    if (poff < 0 || poff + np > ((flags & TGP_FLAG_PER_ROW) ? m->RP : m->P)) return -1;
+    for (int j = 0; j < 4; ++j) fp.blk[4 * b + j] = m->program[4 * b + j];
+  }
+  fp.nslots = flow_slots(fp.blk, fp.nblk);
+  return 0;
+}
+
 }  // namespace tgp
 
 using namespace tgp;
@@ -79,10 +100,14 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
   md.nblk = nblk; md.P = P; md.RP = RP;
+  FlowProg fp;
+  if (int rc = make_prog(&md, model->lik == TGP_LIK_FLOW, fp)) return rc;
+  md.program = nullptr;  // kernels use the by-value copy
+  p.nslots = fp.nslots;
   if (phases & TGP_PHASE_PREPARE)
-    if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
+    if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (phases & TGP_PHASE_ROWS)
-    if (int rc = launch_rows(p, md, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
+    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
   if (phases & TGP_PHASE_BACKWARD)
     if (int rc = launch_backward_mm(p, md, *grads, out, ws, st)) return rc;
   return 0;
@@ -103,8 +128,10 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
   md.nblk = 0; md.P = 0; md.RP = 0; md.lik = TGP_LIK_GAUSS; md.program = nullptr;
-  if (int rc = launch_prepare(p, md, ws, status, st)) return rc;
-  return launch_rows(p, md, X, nullptr, nullptr, nullptr, mu, v, ws, false, st);
+  FlowProg fp;
+  fp.nblk = 0; fp.nslots = 0;
+  if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
+  return launch_rows(p, md, fp, X, nullptr, nullptr, nullptr, mu, v, ws, false, st);
 }
 
 int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,
@@ -179,7 +206,11 @@ int tgp_ell_flow_f64(const tgp_model* model, const double* Y, const double* mu, 
   if (!out) return -6;
   if (!workspace) return -11;
   if (workspace_bytes < lik_workspace_doubles(model->N, model->P, model->RP) * sizeof(double)) return TGP_E_WORKSPACE;
-  return launch_ell_flow(*model, Y, mu, v, rowp, out, g_mu, g_v, g_theta, g_rowp, static_cast<double*>(workspace),
+  FlowProg fp;
+  if (int rc = make_prog(model, true, fp)) return rc;
+  tgp_model md = *model;
+  md.program = nullptr;
+  return launch_ell_flow(md, fp, Y, mu, v, rowp, out, g_mu, g_v, g_theta, g_rowp, static_cast<double*>(workspace),
                          static_cast<hipStream_t>(stream));
 }
 
@@ -192,7 +223,11 @@ int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_
   if (S < 1) return -3;
   if (N < 1) return -4;
   if (model->RP > 0 && !rowp) return -5;
-  return launch_flow_eval(*model, f, S, N, rowp, G, dG, logdG, static_cast<hipStream_t>(stream));
+  FlowProg fp;
+  if (int rc = make_prog(model, true, fp)) return rc;
+  tgp_model md = *model;
+  md.program = nullptr;
+  return launch_flow_eval(md, fp, f, S, N, rowp, G, dG, logdG, static_cast<hipStream_t>(stream));
 }
 
 int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, const double* rowp, const double* Y,
@@ -202,7 +237,11 @@ int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, c
   if (!mu) return -2;
   if (!v) return -3;
   if (model->lik == TGP_LIK_FLOW && model->RP > 0 && !rowp) return -4;
-  return launch_predict(*model, mu, v, rowp, Y, Y_std, m1, m2, logp, static_cast<hipStream_t>(stream));
+  FlowProg fp;
+  if (int rc = make_prog(model, model->lik == TGP_LIK_FLOW, fp)) return rc;
+  tgp_model md = *model;
+  md.program = nullptr;
+  return launch_predict(md, fp, mu, v, rowp, Y, Y_std, m1, m2, logp, static_cast<hipStream_t>(stream));
 }
 
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,

@@ -18,7 +18,22 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define TGP_ROWS_PER_BLOCK 64 /* 4 waves x 16 rows */
 #define TGP_TILE_LD 66        /* LDS row stride (f64) of the [m][64 rows] transposition tile: conflict-free ds_read_b64 */
 #define TGP_MAX_MT 8
+#define TGP_RSPLIT 4 /* the slab reduction is split in this many independent partial sums */
 #define TGP_LOG_2PI_REF 1.8378770942368803 /* log(2*float32(pi)): the reference's cg.pi is a float32 tensor (dsp/config.py:71) */
+
+// Diagnostic build only (-DTGP_STAMPS): thread 0 of block 0 writes the 100 MHz s_memrealtime counter into the
+// workspace header at phase boundaries.  The shipped library never executes a stamp.
+#ifdef TGP_STAMPS
+#define TGP_STAMP(wsp, plan, i)                                                                       \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                                          \
+      (wsp)[(plan).hdr + tgp::H_STAMP + (i)] = (double)__builtin_amdgcn_s_memrealtime();              \
+  } while (0)
+#else
+#define TGP_STAMP(wsp, plan, i) \
+  do {                          \
+  } while (0)
+#endif
 
 namespace tgp {
 
@@ -28,17 +43,21 @@ namespace tgp {
 struct Plan {
   int N, D, M, S, nblk, P, RP, lik;
   int MT, MP, DP, CT, CT16, ntri, nblocks;
+  int nslots;  // store-mode flow stack slots
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
   // workspace offsets (doubles)
   size_t hdr, ils, ls, Zs, mpad, w, tp, tg;
-  size_t Kmm, L, J, JT, Lq, LqT, S_, Hp, Gf, Lb, LamB, Q, Y, Ks;
-  size_t red;    // reduced slab (same layout as one slab, G part unused)
+  size_t Kmm, L, J, JT, Lq, LqT, S_, HpT, Q;
+  size_t Gp;     // TGP_RSPLIT partial sums of G, each expanded to a full symmetric MP x MP matrix
+  size_t redp;   // TGP_RSPLIT partial sums of the slab tail (T, s, scalars); slab layout, G part unused
+  size_t PP;     // MT x MP x PPW per-row-block partials of (Kbar_MM o K_MM) [Zs, 1]
+  int PPW;
   size_t slabs;  // nblocks * slab_len
   size_t total;  // doubles
 };
 
 // hdr slots
-enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_N = 16 };
+enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_STAMP = 8, H_N = 32 };
 // slab scalar slots
 enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 
@@ -47,7 +66,7 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
-  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
+  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik; p.nslots = 0;
   p.MT = (M + 15) / 16; p.MP = p.MT * 16;
   p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
   p.CT = (2 * p.DP + 1 + 15) / 16; p.CT16 = p.CT * 16;
@@ -70,9 +89,11 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.tp = o; o += rup(P + 1, 16);
   p.tg = o; o += rup(P + 1, 16);
   p.Kmm = o; o += mm; p.L = o; o += mm; p.J = o; o += mm; p.JT = o; o += mm;
-  p.Lq = o; o += mm; p.LqT = o; o += mm; p.S_ = o; o += mm; p.Hp = o; o += mm;
-  p.Gf = o; o += mm; p.Lb = o; o += mm; p.LamB = o; o += mm; p.Q = o; o += mm; p.Y = o; o += mm; p.Ks = o; o += mm;
-  p.red = o; o += p.slab_len;
+  p.Lq = o; o += mm; p.LqT = o; o += mm; p.S_ = o; o += mm; p.HpT = o; o += mm; p.Q = o; o += mm;
+  p.Gp = o; o += TGP_RSPLIT * mm;
+  p.redp = o; o += TGP_RSPLIT * p.slab_len;
+  p.PPW = p.DP + 2;
+  p.PP = o; o += (size_t)p.MT * p.MP * p.PPW;
   p.slabs = o; o += (size_t)p.nblocks * p.slab_len;
   p.total = o;
   return 0;
@@ -112,10 +133,42 @@ __device__ __forceinline__ d4 tile_mm(const double* __restrict__ A, const double
   return acc;
 }
 
+// Same product with caller-supplied operand fetchers fa(k), fb(k) (k = first row of the 4-deep k-step; the
+// fetcher adds the lane's own q).  Loads of 8 k-steps are issued before their MFMAs so the (L2/LDS) latency
+// of one batch overlaps the matrix pipe instead of serialising load -> mfma -> load.
+template <class FA, class FB>
+__device__ __forceinline__ d4 tile_mm_f(FA fa, FB fb, int k0, int k1, d4 acc) {
+  int k = k0;
+  for (; k + 32 <= k1; k += 32) {
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = fa(k + 4 * u); b[u] = fb(k + 4 * u); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = TGP_MFMA(a[u], b[u], acc);
+  }
+  for (; k + 16 <= k1; k += 16) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = fa(k + 4 * u); b[u] = fb(k + 4 * u); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = TGP_MFMA(a[u], b[u], acc);
+  }
+  for (; k < k1; k += 4) acc = TGP_MFMA(fa(k), fb(k), acc);
+  return acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // flows (models/flow.py).  `tp` = shared parameters after their positivity transform, `tg` = d(tp)/d(raw)
 // (both prepared once per step by k_prep_a); per-row parameters are transformed on the fly.
 // ---------------------------------------------------------------------------------------------------
+#define TGP_MAX_BLOCKS 64
+// the flow program travels to the kernels BY VALUE (kernel argument): the ABI takes it as a small host array
+struct FlowProg {
+  int32_t nblk;
+  int32_t nslots;  // store-mode stack slots (flow_slots)
+  int32_t blk[4 * TGP_MAX_BLOCKS];
+};
+
 struct FlowDev {
   const int32_t* prog;  // nblk x 4
   int nblk;
@@ -223,6 +276,177 @@ __device__ inline double flow_backward(const FlowDev& F, double c, const double*
     }
   }
   return c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "store" evaluation: NB quadrature nodes in flight per lane (independent dependency chains for the
+// single-wave-per-SIMD row kernel), forward keeps what the reverse sweep needs so that the reverse sweep
+// contains no transcendental.  Stack slots per block: AFFINE 1 {f_in}; SAL 3 {u, cosh t, g'}; STEPTANH 1+K
+// {f_in, tanh_k}.  Slot s of node u lives at stack[(s*NB + u) * sstride].
+// sinh/cosh/tanh are formed from ONE exp (+1 division): absolute error ~1e-16 * max(1, cosh), which is what the
+// residual y - G(f) needs; asinh keeps the reference's log form.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline int flow_slots(const int32_t* prog, int nblk) {
+  int s = 0;
+  for (int b = 0; b < nblk; ++b) s += prog[4 * b] == TGP_FLOW_AFFINE ? 1 : (prog[4 * b] == TGP_FLOW_SAL ? 3 : 1 + prog[4 * b + 1]);
+  return s;
+}
+
+template <int NB>
+__device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], const double* __restrict__ rp,
+                                          double* stack, int sstride) {
+  int sl = 0;
+  for (int b = 0; b < F.nblk; ++b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+    if (kind == TGP_FLOW_AFFINE) {
+      double a = pr ? rp[poff] : F.tp[poff];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
+      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        stack[(sl * NB + u) * sstride] = f[u];
+        f[u] = a * f[u] + bb;
+      }
+      sl += 1;
+    } else if (kind == TGP_FLOW_SAL) {
+      const double a = pr ? rp[poff] : F.tp[poff];
+      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const double sf = sqrt(f[u] * f[u] + 1.0);
+        const double uu = log(f[u] + sf);  // flow.py:904-905
+        const double e = exp(bb * uu - a), ei = 1.0 / e;
+        const double ch = 0.5 * (e + ei);
+        double g = 0.5 * (e - ei), gp = bb * ch / sf;
+        if (addf) { g += f[u]; gp += 1.0; }
+        stack[((sl + 0) * NB + u) * sstride] = uu;
+        stack[((sl + 1) * NB + u) * sstride] = ch;
+        stack[((sl + 2) * NB + u) * sstride] = gp;
+        f[u] = g;
+      }
+      sl += 3;
+    } else {
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+      double g[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        stack[(sl * NB + u) * sstride] = f[u];
+        g[u] = addf ? f[u] : 0.0;
+      }
+      for (int k = 0; k < K; ++k) {
+        const double a = F.tp[poff + 4 * k], bt = F.tp[poff + 4 * k + 1], c = F.tp[poff + 4 * k + 2],
+                     idt = 1.0 / F.tp[poff + 4 * k + 3];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const double th = 1.0 - 2.0 / (exp(2.0 * (f[u] - c) * idt) + 1.0);
+          stack[((sl + 1 + k) * NB + u) * sstride] = th;
+          g[u] += a + bt * th;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) f[u] = g[u];
+      sl += 1 + K;
+    }
+  }
+}
+
+// Reverse sweep for NB nodes: c[u] = d(objective)/dG on entry, d(objective)/df0 on exit.  Shared-parameter
+// partials are summed over the NB nodes, then over the four lanes that share a data row (quad_sum), and lanes
+// with q == 0 accumulate them into accq[slot * qstride]; per-row parameter partials go to the lane-private
+// accr[(poff + j) * rstride].  All lanes of the wave must call this together (cross-lane sums inside).
+template <int NB>
+__device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], const double* __restrict__ rp,
+                                           const double* stack, int sstride, int nslots, double* accq, int qstride,
+                                           bool qlead, double* accr, int rstride) {
+  int sl = nslots;
+  for (int b = F.nblk - 1; b >= 0; --b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+    if (kind == TGP_FLOW_AFFINE) {
+      sl -= 1;
+      double a, fa;
+      if (pr) {
+        a = rp[poff]; fa = 1.0;
+        if (flags & TGP_FLAG_RESTRICT) { fa = sigmoid_d(a); a = softplus_d(a); }
+      } else {
+        a = F.tp[poff]; fa = F.tg[poff];
+      }
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        pa += c[u] * stack[(sl * NB + u) * sstride];
+        pb += c[u];
+        c[u] *= a;
+      }
+      pa *= fa;
+      if (pr) {
+        accr[(poff + 0) * rstride] += pa;
+        accr[(poff + 1) * rstride] += pb;
+      } else {
+        pa = quad_sum(pa); pb = quad_sum(pb);
+        if (qlead) { accq[(poff + 0) * qstride] += pa; accq[(poff + 1) * qstride] += pb; }
+      }
+    } else if (kind == TGP_FLOW_SAL) {
+      sl -= 3;
+      double fb = 1.0;
+      if (pr) {
+        if (flags & TGP_FLAG_RESTRICT) fb = sigmoid_d(rp[poff + 1]);
+      } else {
+        fb = F.tg[poff + 1];
+      }
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const double uu = stack[((sl + 0) * NB + u) * sstride], ch = stack[((sl + 1) * NB + u) * sstride];
+        pa -= c[u] * ch;
+        pb += c[u] * uu * ch;
+        c[u] *= stack[((sl + 2) * NB + u) * sstride];
+      }
+      pb *= fb;
+      if (pr) {
+        accr[(poff + 0) * rstride] += pa;
+        accr[(poff + 1) * rstride] += pb;
+      } else {
+        pa = quad_sum(pa); pb = quad_sum(pb);
+        if (qlead) { accq[(poff + 0) * qstride] += pa; accq[(poff + 1) * qstride] += pb; }
+      }
+    } else {
+      sl -= 1 + K;
+      double gp[NB], fin[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        gp[u] = (flags & TGP_FLAG_ADD_F0) ? 1.0 : 0.0;
+        fin[u] = stack[(sl * NB + u) * sstride];
+      }
+      for (int k = 0; k < K; ++k) {
+        const int o = poff + 4 * k;
+        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = 1.0 / F.tp[o + 3];
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const double th = stack[((sl + 1 + k) * NB + u) * sstride];
+          const double se = bt * (1.0 - th * th) * idt;  // d/df of this step
+          p0 += c[u];
+          p1 += c[u] * th;
+          p2 -= c[u] * se;
+          p3 -= c[u] * se * (fin[u] - cc) * idt;
+          gp[u] += se;
+        }
+        p0 = quad_sum(p0); p1 = quad_sum(p1 * F.tg[o + 1]); p2 = quad_sum(p2); p3 = quad_sum(p3 * F.tg[o + 3]);
+        if (qlead) {
+          accq[(o + 0) * qstride] += p0;
+          accq[(o + 1) * qstride] += p1;
+          accq[(o + 2) * qstride] += p2;
+          accq[(o + 3) * qstride] += p3;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) c[u] *= gp[u];
+    }
+  }
 }
 
 }  // namespace tgp

@@ -10,8 +10,8 @@ int set_error(hipError_t e, const char* file, int line);  // records tgp_last_er
 // `cur` is the caller's per-kernel high-water mark.  Returns 0 or TGP_E_LDS.
 inline int ensure_lds(const void* func, size_t bytes, size_t* cur) {
   if (bytes <= *cur) return 0;
-  if (bytes > 160 * 1024 - 64) return TGP_E_LDS;  // leave room for the few static __shared__ words
-  const size_t want = bytes > 64 * 1024 ? 160 * 1024 - 64 : 64 * 1024;
+  if (bytes > 160 * 1024 - 1024) return TGP_E_LDS;  // leave room for the static __shared__ words
+  const size_t want = bytes > 63 * 1024 ? 160 * 1024 - 1024 : 63 * 1024;
   hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
   if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
   *cur = want;
@@ -19,7 +19,7 @@ inline int ensure_lds(const void* func, size_t bytes, size_t* cur) {
 }
 
 // tgp_mm.hip
-int launch_prepare(const Plan& p, const tgp_model& md, double* ws, int32_t* status, hipStream_t st);
+int launch_prepare(const Plan& p, const tgp_model& md, const FlowProg& fp, double* ws, int32_t* status, hipStream_t st);
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st);
 int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
                hipStream_t st);
@@ -29,18 +29,18 @@ int launch_kl(const double* m, const double* Lam, int M, double* out, double* g_
 int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* status, hipStream_t st);
 
 // tgp_rows.hip
-int launch_rows(const Plan& p, const tgp_model& md, const double* X, const double* Y, const double* rowp,
-                double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
+int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
+                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
 // tgp_lik.hip
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* log_var_noise,
                      double scale, double* out, double* g_mu, double* g_v, double* ws, hipStream_t st);
-int launch_ell_flow(const tgp_model& md, const double* Y, const double* mu, const double* v, const double* rowp,
+int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, const double* mu, const double* v, const double* rowp,
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st);
-int launch_flow_eval(const tgp_model& md, const double* f, int S, int N, const double* rowp, double* G, double* dG,
+int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, int S, int N, const double* rowp, double* G, double* dG,
                      double* logdG, hipStream_t st);
-int launch_predict(const tgp_model& md, const double* mu, const double* v, const double* rowp, const double* Y,
+int launch_predict(const tgp_model& md, const FlowProg& fp, const double* mu, const double* v, const double* rowp, const double* Y,
                    double Y_std, double* m1, double* m2, double* logp, hipStream_t st);
 int launch_adam(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                 double beta1, double beta2, double eps, double weight_decay, int step, int maximize, hipStream_t st);

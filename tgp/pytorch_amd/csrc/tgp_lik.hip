@@ -60,10 +60,9 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ pa
 }
 
 // transformed shared flow parameters into LDS (same rule as k_prep_a); whole block, ends with a barrier
-__device__ inline void flow_params_lds(const tgp_model& md, double* tp, double* tg) {
-  for (int b = threadIdx.x; b < md.nblk; b += blockDim.x) {
-    const int kind = md.program[4 * b], K = md.program[4 * b + 1], poff = md.program[4 * b + 2],
-              flags = md.program[4 * b + 3];
+__device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, double* tp, double* tg) {
+  for (int b = threadIdx.x; b < fp.nblk; b += blockDim.x) {
+    const int kind = fp.blk[4 * b], K = fp.blk[4 * b + 1], poff = fp.blk[4 * b + 2], flags = fp.blk[4 * b + 3];
     if (flags & TGP_FLAG_PER_ROW) continue;
     const int np = kind == TGP_FLOW_STEPTANH ? 4 * K : 2;
     for (int j = 0; j < np; ++j) {
@@ -81,7 +80,7 @@ __device__ inline void flow_params_lds(const tgp_model& md, double* tp, double* 
 // ---------------------------------------------------------------------------------------------------
 // TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), one thread per row
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, const double* __restrict__ Y,
+__global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, const double* __restrict__ Y,
                                                    const double* __restrict__ mu, const double* __restrict__ v,
                                                    const double* __restrict__ rowp, double* __restrict__ part,
                                                    double* __restrict__ g_mu, double* __restrict__ g_v,
@@ -95,10 +94,10 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, const double* __
   double* tp = red + 16;                                 // P+2
   double* tg = tp + (P + 2) / 2 * 2;                     // P+2
   for (int i = tid; i < (P + RP) * 256; i += 256) acc[i] = 0.0;
-  flow_params_lds(md, tp, tg);
+  flow_params_lds(md, fp, tp, tg);
   const int n = blockIdx.x * 256 + tid;
   const double eta = md.log_var_noise[0], einv = exp(-eta);
-  FlowDev F{md.program, nblk, tp, tg};
+  FlowDev F{fp.blk, nblk, tp, tg};
   double ellp = 0.0, etap = 0.0;
   if (n < md.N) {
     const double m_ = mu[n], sq = sqrt(2.0 * v[n]), y = Y[n];
@@ -138,16 +137,16 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, const double* __
 // ---------------------------------------------------------------------------------------------------
 // flow evaluation: G, dG/df, log dG/df over an (S,N) array (row n = idx % N)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, const double* __restrict__ f, size_t total, int N,
+__global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, FlowProg fp, const double* __restrict__ f, size_t total, int N,
                                                     const double* __restrict__ rowp, double* __restrict__ G,
                                                     double* __restrict__ dG, double* __restrict__ logdG) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* tp = reinterpret_cast<double*>(smem_raw);
   double* tg = tp + (md.P + 2) / 2 * 2;
-  flow_params_lds(md, tp, tg);
+  flow_params_lds(md, fp, tp, tg);
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  FlowDev F{md.program, md.nblk, tp, tg};
+  FlowDev F{fp.blk, fp.nblk, tp, tg};
   const double* rp = rowp ? rowp + (i % N) * md.RP : nullptr;
   double der;
   const double g = flow_forward(F, f[i], rp, nullptr, 0, &der);
@@ -161,14 +160,14 @@ __global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, const double* _
 //   flow : GaussianNonLinearMean.marginal_moments (:176-203) ; sparse_MF_SP.test_log_likelihood (:705-776)
 //   gauss: GaussianLinearMean.marginal_moments (:89-118)     ; sparse_MF_SP.py:786-799
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_predict(tgp_model md, const double* __restrict__ mu,
+__global__ __launch_bounds__(256) void k_predict(tgp_model md, FlowProg fp, const double* __restrict__ mu,
                                                   const double* __restrict__ v, const double* __restrict__ rowp,
                                                   const double* __restrict__ Y, double Y_std, double* __restrict__ m1o,
                                                   double* __restrict__ m2o, double* __restrict__ logp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* tp = reinterpret_cast<double*>(smem_raw);
   double* tg = tp + (md.P + 2) / 2 * 2;
-  if (md.lik == TGP_LIK_FLOW) flow_params_lds(md, tp, tg);
+  if (md.lik == TGP_LIK_FLOW) flow_params_lds(md, fp, tp, tg);
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= md.N) return;
   const double noise = exp(md.log_var_noise[0]);
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(256) void k_predict(tgp_model md, const double* __r
     }
     return;
   }
-  FlowDev F{md.program, md.nblk, tp, tg};
+  FlowDev F{fp.blk, fp.nblk, tp, tg};
   const double* rp = rowp ? rowp + (size_t)n * md.RP : nullptr;
   const double m_ = mu[n], sq = sqrt(2.0 * v[n]);
   const double sdy = Y_std * sqrt(noise), var = sdy * sdy;
@@ -228,21 +227,30 @@ __global__ __launch_bounds__(256) void k_adam(double* __restrict__ p, const doub
 __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const double* __restrict__ g,
                                                    double* __restrict__ m, double* __restrict__ v, int64_t n, double lr,
                                                    double b1, double b2, double eps, double wd,
-                                                   const int32_t* __restrict__ step_dev, double sign) {
+                                                   int32_t* __restrict__ step_dev, double sign) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   const double step = (double)(step_dev[0] + 1);
-  const double bc1 = 1.0 - pow(b1, step), bc2s = sqrt(1.0 - pow(b2, step));
-  double gi = sign * g[i];
-  if (wd != 0.0) gi += wd * p[i];
-  const double mi = b1 * m[i] + (1.0 - b1) * gi;
-  const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
+  if (i < n) {
+    const double bc1 = 1.0 - pow(b1, step), bc2s = sqrt(1.0 - pow(b2, step));
+    double gi = sign * g[i];
+    if (wd != 0.0) gi += wd * p[i];
+    const double mi = b1 * m[i] + (1.0 - b1) * gi;
+    const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrt(vi) / bc2s + eps);
+  }
+  // Every block has read step_dev[0] before it takes a ticket; the block that draws the last ticket bumps the
+  // counter for the next launch (no second kernel, valid under hipGraph replay).
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(&step_dev[1], 1);
+    if (t == (int)gridDim.x - 1) {
+      step_dev[1] = 0;
+      atomicAdd(&step_dev[0], 1);
+    }
+  }
 }
-
-__global__ void k_step_inc(int32_t* step_dev) { step_dev[0] += 1; }
 
 // ---------------------------------------------------------------------------------------------------
 // host launchers
@@ -261,10 +269,10 @@ static int flow_lds(const tgp_model& md, size_t* bytes) {
   const size_t d = (size_t)(md.nblk > 0 ? md.nblk : 1) * 256 + (size_t)(md.P + md.RP > 0 ? md.P + md.RP : 1) * 256 + 16 +
                    2 * (size_t)(md.P + 2);
   *bytes = d * sizeof(double);
-  return *bytes > 160 * 1024 - 64 ? TGP_E_LDS : 0;
+  return *bytes > 160 * 1024 - 1024 ? TGP_E_LDS : 0;
 }
 
-int launch_ell_flow(const tgp_model& md, const double* Y, const double* mu, const double* v, const double* rowp,
+int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, const double* mu, const double* v, const double* rowp,
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st) {
   size_t lds;
@@ -272,27 +280,27 @@ int launch_ell_flow(const tgp_model& md, const double* Y, const double* mu, cons
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
   const int nb = (md.N + 255) / 256;
-  hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
+  hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);
   LAUNCH_CHECK();
   return 0;
 }
 
-int launch_flow_eval(const tgp_model& md, const double* f, int S, int N, const double* rowp, double* G, double* dG,
+int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, int S, int N, const double* rowp, double* G, double* dG,
                      double* logdG, hipStream_t st) {
   const size_t total = (size_t)S * N;
   const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
-  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, md, f, total, N, rowp, G,
+  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, md, fp, f, total, N, rowp, G,
                      dG, logdG);
   LAUNCH_CHECK();
   return 0;
 }
 
-int launch_predict(const tgp_model& md, const double* mu, const double* v, const double* rowp, const double* Y,
+int launch_predict(const tgp_model& md, const FlowProg& fp, const double* mu, const double* v, const double* rowp, const double* Y,
                    double Y_std, double* m1, double* m2, double* logp, hipStream_t st) {
   const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
-  hipLaunchKernelGGL(k_predict, dim3((md.N + 255) / 256), dim3(256), lds, st, md, mu, v, rowp, Y, Y_std, m1, m2, logp);
+  hipLaunchKernelGGL(k_predict, dim3((md.N + 255) / 256), dim3(256), lds, st, md, fp, mu, v, rowp, Y, Y_std, m1, m2, logp);
   LAUNCH_CHECK();
   return 0;
 }
@@ -312,8 +320,6 @@ int launch_adam_dev(double* params, const double* grads, double* exp_avg, double
                     hipStream_t st) {
   hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
                      n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, st, step_dev);
   LAUNCH_CHECK();
   return 0;
 }

@@ -1,10 +1,10 @@
 // tgp_mm.hip -- the M x M side of the ELBO step (everything that does not scale with the rows).
 //
-// Forward  (k_prep_a, k_prep_b):  lengthscale/outputscale transforms, Zs = Z/l, K_MM, Cholesky L,
+// Forward  (k_prep_a; H' and w ride along the row-kernel launch, tgp_rows.hpp):  lengthscale/outputscale transforms, Zs = Z/l, K_MM, Cholesky L,
 //          J = L^-1, masked L_q, S = L_q L_q^T, H' = J^T (S - I), w = J^T m, KL, flow parameter transforms.
 //          Replaces models/sparse_MF_SP.py:316,330,344-346,406-431 and dsp/utils.py:222-270 (the retry
 //          ladder itself stays on the host, driven by status[]).
-// Backward (k_reduce, k_bwd1..5): slab reduction of the row statistics, then the hand-derived adjoint
+// Backward (k_reduce, k_bwd12, k_bwd34, k_bwd5): slab reduction of the row statistics, then the hand-derived adjoint
 //          (restructured -- see DESIGN.md section 3):
 //            Lbar   = -tril(w s^T + 2 H' G)            Lambar = 2 tril(G L_q) - kl (L_q - diag(1/Lam_ii))
 //            Q      = Phi(L^T Lbar) + Phi(.)^T         Kbar_MM = 1/2 J^T Q J
@@ -16,234 +16,333 @@
 namespace tgp {
 
 // ---------------------------------------------------------------------------------------------------
-// k_prep_a: block 0 = transforms + K_MM + Cholesky + inverse (+KL, flow params); blocks 1.. = S tiles
+// k_prep_a  (grid = 2 + MT*MT workgroups of 512 threads)
+//   block 0      : K_MM into LDS, blocked left-looking Cholesky + blocked triangular inverse (8 waves, MFMA)
+//   block 1      : parameter transforms, Zs, padded m, flow parameter transforms, KL, header scalars
+//   block 2 + t  : 16x16 tile t of {Lq, Lq^T, K_MM -> HBM} and the S = Lq Lq^T tile (one MFMA chain)
 // ---------------------------------------------------------------------------------------------------
-#define PREP_THREADS 1024
+#define PREP_THREADS 512
 
-__global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, double* __restrict__ ws,
+// uniform broadcast of lane `src`'s double (src compile-time constant after unrolling)
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) from the hardware estimate v_rsq_f64 plus two Newton steps (y <- y (1.5 - 0.5 d y^2)): the diagonal
+// tile factorisation is ONE serial dependency chain, so the ~40-instruction 1.0/sqrt(d) sequence was its main cost.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// Cholesky of one 16x16 diagonal tile + its inverse, executed by ONE wave; lane i (< 16) owns row i.
+//   in : a[c] = A[i][c] (lower part valid)
+//   out: a[c] = L[i][c] ; x[r] = (L^-1)[r][lane] (column `lane` of the inverse) ; returns first bad pivot (0 = ok)
+__device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], int lane) {
+  double dinv[16];
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double d = bcast_lane(a[k], k);
+    if (!(d > 0.0) && bad == 0) bad = k + 1;  // uniform; also catches NaN
+    const double rinv = rsqrt_nr(d);
+    dinv[k] = rinv;
+    a[k] = (lane == k) ? d * rinv : a[k] * rinv;  // column k of L (rows >= k meaningful)
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) a[j] = fma(-a[k], bcast_lane(a[k], j), a[j]);  // a_ij -= L_ik L_jk (rows i >= j)
+  }
+  // forward substitution for column `lane` of X = L^-1:  x_i = -(sum_{k<i} L_ik x_k) / L_ii,  x_lane = 1/L_lane,lane
+  // (two partial sums halve the dependent-add chain)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < i; k += 2) {
+      s0 = fma(bcast_lane(a[k], i), x[k], s0);
+      if (k + 1 < i) s1 = fma(bcast_lane(a[k + 1], i), x[k + 1], s1);
+    }
+    x[i] = (lane == i) ? dinv[i] : (lane < i ? -(s0 + s1) * dinv[i] : 0.0);
+  }
+  return bad;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, FlowProg fp, double* __restrict__ ws,
                                                          int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x;
-  const int M = p.M, D = p.D, MP = p.MP, DP = p.DP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, MT = p.MT;
 
-  if (blockIdx.x > 0) {
-    // ---- S = Lq Lq^T tile, Lq = tril(Lam) masked on load (models/sparse_MF_SP.py:344-346) ----
-    if (tid >= 64) return;
-    const int t = blockIdx.x - 1, ti = t / p.MT, tj = t % p.MT;
-    const int r = tid & 15, q = tid >> 4;
-    const int i = ti * 16 + r, j = tj * 16 + r;
-    d4 acc = {0, 0, 0, 0};
-    const int kend = (ti < tj ? ti : tj) * 16 + 16;  // Lq[i,k] = 0 for k > i
-    for (int k = 0; k < kend; k += 4) {
-      const int kk = k + q;
-      const double a = (i < M && kk <= i) ? md.Lam[(size_t)i * M + kk] : 0.0;
-      const double b = (j < M && kk <= j) ? md.Lam[(size_t)j * M + kk] : 0.0;
-      acc = TGP_MFMA(a, b, acc);
+  if (blockIdx.x >= 2) {
+    // ---------------- tile blocks: Lq, Lq^T, K_MM copies + S = Lq Lq^T (sparse_MF_SP.py:316,344-346) ------------
+    const int t = blockIdx.x - 2, ti = t / MT, tj = t % MT;
+    if (tid < 256) {
+      const int rr = tid >> 4, cc = tid & 15, row = ti * 16 + rr, col = tj * 16 + cc;
+      double lq = 0.0, k = 0.0;
+      if (row < M && col < M) {
+        if (col <= row) lq = md.Lam[(size_t)row * M + col];
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double il = 1.0 / softplus_d(md.raw_ls[d]);
+          const double tt = md.Z[(size_t)row * D + d] * il - md.Z[(size_t)col * D + d] * il;
+          d2 += tt * tt;
+        }
+        k = softplus_d(md.raw_os[0]) * exp(-0.5 * d2);
+      }
+      ws[p.Lq + (size_t)row * MP + col] = lq;
+      ws[p.LqT + (size_t)col * MP + row] = lq;
+      ws[p.Kmm + (size_t)row * MP + col] = k;
     }
-    double* S = ws + p.S_;
+    if (wave == 4) {  // S tile on a wave that did no copy work
+      const int i = ti * 16 + r, j = tj * 16 + r;
+      d4 acc = {0, 0, 0, 0};
+      const int kend = (ti < tj ? ti : tj) * 16 + 16;  // Lq[i,k] = 0 for k > i
+      for (int k = 0; k < kend; k += 4) {
+        const int kk = k + q;
+        const double a = (i < M && kk <= i) ? md.Lam[(size_t)i * M + kk] : 0.0;
+        const double b = (j < M && kk <= j) ? md.Lam[(size_t)j * M + kk] : 0.0;
+        acc = TGP_MFMA(a, b, acc);
+      }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) S[(size_t)(ti * 16 + q + 4 * rr) * MP + tj * 16 + r] = acc[rr];
+      for (int rr = 0; rr < 4; ++rr) ws[p.S_ + (size_t)(ti * 16 + q + 4 * rr) * MP + tj * 16 + r] = acc[rr];
+    }
     return;
   }
 
-  // ---------------- block 0 ----------------
-  const int LD = MP + 1;                 // padded LDS leading dimension
-  double* A = sm;                        // MP x LD : K_MM -> L (lower) ; J^T is built in the strict upper part
-  double* dinv = sm + (size_t)MP * LD;   // MP : 1 / L_ii
-  double* zs = dinv + MP;                // MP x DP
-  double* red = zs + (size_t)MP * DP;    // 32 : block reduction scratch
-  __shared__ int s_info, s_nan;
-  double* hdr = ws + p.hdr;
-
-  if (tid == 0) { s_info = 0; s_nan = 0; }
-  // transforms: lengthscale = softplus(raw) (gpytorch Positive constraint), outputscale likewise
-  if (tid < 16) {
-    double l = 1.0;
-    if (tid < D) l = softplus_d(md.raw_ls[tid]);
-    ws[p.ls + tid] = l;
-    ws[p.ils + tid] = tid < D ? 1.0 / l : 0.0;
-    red[tid] = tid < D ? 1.0 / l : 0.0;
+  if (blockIdx.x == 1) {
+    // ---------------- transforms, padded copies, flow parameter transforms, KL, header ---------------------------
+    __shared__ double red1[16];
+    double* hdr = ws + p.hdr;
+    if (tid < 16) {
+      const double l = tid < D ? softplus_d(md.raw_ls[tid]) : 1.0;  // gpytorch Positive constraint = softplus
+      ws[p.ls + tid] = l;
+      ws[p.ils + tid] = tid < D ? 1.0 / l : 0.0;
+    }
+    for (int i = tid; i < MP * DP; i += PREP_THREADS) {
+      const int mrow = i / DP, d = i % DP;
+      ws[p.Zs + i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * (1.0 / softplus_d(md.raw_ls[d])) : 0.0;
+    }
+    for (int i = tid; i < MP; i += PREP_THREADS) ws[p.mpad + i] = i < M ? md.m[i] : 0.0;
+    {
+      for (int b = tid; b < fp.nblk; b += PREP_THREADS) {
+        const int kind = fp.blk[4 * b], K = fp.blk[4 * b + 1], poff = fp.blk[4 * b + 2], flags = fp.blk[4 * b + 3];
+        if (flags & TGP_FLAG_PER_ROW) continue;
+        const int np = kind == TGP_FLOW_STEPTANH ? 4 * K : 2;
+        for (int j = 0; j < np; ++j) {
+          const double x = md.theta[poff + j];
+          bool res;
+          if (kind == TGP_FLOW_STEPTANH) res = (j & 1);  // b_k, d_k: TanhFlow set_restrictions=True (flow.py:1075)
+          else res = (flags & TGP_FLAG_RESTRICT) && j == (kind == TGP_FLOW_AFFINE ? 0 : 1);
+          ws[p.tp + poff + j] = res ? softplus_d(x) : x;
+          ws[p.tg + poff + j] = res ? sigmoid_d(x) : 1.0;
+        }
+      }
+    }
+    // whitened KL (models/sparse_MF_SP.py:406-431)
+    double kl_part = 0.0;
+    for (int i = tid; i < M * M; i += PREP_THREADS) {
+      const int rr = i / M, cc = i % M;
+      if (cc <= rr) {
+        const double x = md.Lam[i];
+        kl_part += x * x;
+        if (cc == rr) kl_part -= log(x * x);
+      }
+    }
+    for (int i = tid; i < M; i += PREP_THREADS) kl_part += md.m[i] * md.m[i];
+    kl_part = wave_sum(kl_part);
+    if (lane == 0) red1[wave] = kl_part;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int i = 0; i < PREP_THREADS / 64; ++i) s += red1[i];
+      hdr[H_S2] = softplus_d(md.raw_os[0]);
+      hdr[H_KL] = 0.5 * (s - (double)M);
+      hdr[H_ETA] = md.log_var_noise[0];
+      hdr[H_EINV] = exp(-md.log_var_noise[0]);  // 1/positive_transform (dsp/utils.py:39-41, 'exp')
+      hdr[H_SIG_OS] = sigmoid_d(md.raw_os[0]);
+    }
+    return;
   }
+
+  // ---------------- block 0: blocked Cholesky (torch.cholesky, dsp/utils.py:239) + inverse ------------------------
+#ifdef TGP_STAMPS
+  double tph[4] = {0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
+#define PSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tph[i] += (double)(tn_ - tlast); tlast = tn_; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+  const int LD = MP + 1;
+  double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
+  double* Dt = sm + (size_t)MP * LD;         // MT x 256: inverses of the diagonal tiles (row-major, zero above diag)
+  double* zs = Dt;                           // overlay: scaled inducing points, only needed to build K_MM
+  __shared__ int s_info, s_nan;
+  __shared__ double s_ils[16];
+  if (tid == 0) { s_info = 0; s_nan = 0; }
+  if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   __syncthreads();
   const double s2 = softplus_d(md.raw_os[0]);
   for (int i = tid; i < MP * DP; i += PREP_THREADS) {
     const int mrow = i / DP, d = i % DP;
-    const double z = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * red[d] : 0.0;
-    zs[i] = z;
-    ws[p.Zs + i] = z;
+    zs[i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * s_ils[d] : 0.0;
   }
-  for (int i = tid; i < MP; i += PREP_THREADS) ws[p.mpad + i] = i < M ? md.m[i] : 0.0;
-  // flow parameter transforms (softplus where the reference applies it) and their derivatives
-  if (md.program != nullptr) {
-    for (int b = tid; b < p.nblk; b += PREP_THREADS) {
-      const int kind = md.program[4 * b], K = md.program[4 * b + 1], poff = md.program[4 * b + 2],
-                flags = md.program[4 * b + 3];
-      if (flags & TGP_FLAG_PER_ROW) continue;
-      if (kind == TGP_FLOW_AFFINE || kind == TGP_FLOW_SAL) {
-        const int jr = kind == TGP_FLOW_AFFINE ? 0 : 1;  // the restricted parameter: affine.a / SAL.b
-        for (int j = 0; j < 2; ++j) {
-          const double x = md.theta[poff + j];
-          const bool res = (flags & TGP_FLAG_RESTRICT) && j == jr;
-          ws[p.tp + poff + j] = res ? softplus_d(x) : x;
-          ws[p.tg + poff + j] = res ? sigmoid_d(x) : 1.0;
-        }
-      } else {
-        for (int j = 0; j < 4 * K; ++j) {
-          const double x = md.theta[poff + j];
-          const bool res = (j & 1);  // b_k, d_k: TanhFlow set_restrictions=True inside StepFlow (flow.py:1075)
-          ws[p.tp + poff + j] = res ? softplus_d(x) : x;
-          ws[p.tg + poff + j] = res ? sigmoid_d(x) : 1.0;
-        }
-      }
-    }
-  }
-  // masked Lq / Lq^T copies, KL pieces
-  double kl_part = 0.0;
-  for (int i = tid; i < MP * MP; i += PREP_THREADS) {
-    const int r = i / MP, c = i % MP;
-    double x = 0.0;
-    if (r < M && c <= r) {
-      x = md.Lam[(size_t)r * M + c];
-      kl_part += x * x;
-      if (c == r) kl_part -= log(x * x);
-    }
-    ws[p.Lq + i] = x;
-    ws[p.LqT + (size_t)c * MP + r] = x;
-  }
-  for (int i = tid; i < M; i += PREP_THREADS) kl_part += md.m[i] * md.m[i];
-  __syncthreads();  // zs visible
-  // K_MM (gpytorch ScaleKernel(RBFKernel): sigma^2 exp(-1/2 |zs_i - zs_j|^2)); identity on the padding
+  __syncthreads();
+  // lower triangle only (the factorisation never reads above the diagonal; the strict-upper TILES later receive
+  // J^T); one wave per row, lanes across columns: no integer division, conflict-free LDS rows
   bool has_nan = false;
-  for (int i = tid; i < MP * MP; i += PREP_THREADS) {
-    const int r = i / MP, c = i % MP;
-    double k;
-    if (r < M && c < M) {
-      double d2 = 0.0;
-      for (int d = 0; d < DP; ++d) {
-        const double t = zs[r * DP + d] - zs[c * DP + d];
-        d2 += t * t;
+  for (int rr = wave; rr < MP; rr += PREP_THREADS / 64) {
+    for (int cc = lane; cc <= rr; cc += 64) {
+      double k;
+      if (rr < M) {
+        double d2 = 0.0;
+        for (int d = 0; d < DP; ++d) {
+          const double tt = zs[rr * DP + d] - zs[cc * DP + d];
+          d2 += tt * tt;
+        }
+        k = s2 * exp(-0.5 * d2);
+        has_nan |= (k != k);
+        if (rr == cc) k += md.jitter;
+      } else {
+        k = (rr == cc) ? 1.0 : 0.0;  // identity on the padding keeps L and L^-1 well defined
       }
-      k = s2 * exp(-0.5 * d2);
-      has_nan |= (k != k);
-      ws[p.Kmm + i] = k;
-      if (r == c) k += md.jitter;
-    } else {
-      k = (r == c) ? 1.0 : 0.0;
-      ws[p.Kmm + i] = 0.0;
+      A[rr * LD + cc] = k;
     }
-    A[r * LD + c] = k;
   }
   if (has_nan) s_nan = 1;
-  // KL block reduction
-  kl_part = wave_sum(kl_part);
-  if ((tid & 63) == 0) red[16 + (tid >> 6)] = kl_part;
   __syncthreads();
-  if (tid == 0) {
-    double s = 0.0;
-    for (int i = 0; i < PREP_THREADS / 64; ++i) s += red[16 + i];
-    hdr[H_S2] = s2;
-    hdr[H_KL] = 0.5 * (s - (double)M);
-    hdr[H_ETA] = md.log_var_noise[0];
-    hdr[H_EINV] = exp(-md.log_var_noise[0]);  // 1/positive_transform (dsp/utils.py:39-41, 'exp')
-    hdr[H_SIG_OS] = sigmoid_d(md.raw_os[0]);
-  }
+  PSTAMP(0);
 
-  // ---- Cholesky, right-looking, in LDS (torch.cholesky at dsp/utils.py:239) ----
-  for (int j = 0; j < M; ++j) {
-    __syncthreads();
-    const double d = A[j * LD + j];
-    if (!(d > 0.0)) {  // also catches NaN
-      if (tid == 0 && s_info == 0) s_info = j + 1;
+  for (int j = 0; j < MT; ++j) {
+    const int j0 = 16 * j;
+    // phase 1: left-looking update of block column j:  A_ij -= sum_{kb<j} L_i,kb L_j,kb^T   (tiles i >= j)
+    if (j > 0) {
+      for (int i = j + wave; i < MT; i += PREP_THREADS / 64) {
+        const int i0 = 16 * i;
+        d4 acc = {0, 0, 0, 0};
+        acc = tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; },
+                        0, j0, acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + j0 + r] -= acc[rr];
+      }
+      __syncthreads();
     }
-    const double dj = sqrt(d);
-    const double inv = 1.0 / dj;
-    __syncthreads();
-    for (int i = j + tid; i < M; i += PREP_THREADS) A[i * LD + j] = (i == j) ? dj : A[i * LD + j] * inv;
-    __syncthreads();
-    // trailing update of the lower triangle: rows i > j, cols j < k <= i
-    const int rem = M - j - 1;
-    for (int e = tid; e < rem * rem; e += PREP_THREADS) {
-      const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-      if (k <= i) A[i * LD + k] -= A[i * LD + j] * A[k * LD + j];
+    PSTAMP(1);
+    // phase 2: wave 0 factors the diagonal tile and inverts it
+    if (wave == 0) {
+      double a[16], x[16];
+      const int li = lane & 15;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
+      const int bad = potrf_trtri16(a, x, li);
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
+          Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
+        }
+      }
+      if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
     }
+    __syncthreads();
+    PSTAMP(2);
+    // phase 3: panel  L_ij = A_ij Dinv_j^T (i > j)  and row-block j of J = L^-1:  J_jc = -Dinv_j sum_{c<=kb<j} L_j,kb J_kb,c
+    for (int t = wave; t < MT - 1; t += PREP_THREADS / 64) {
+      if (t < MT - 1 - j) {
+        const int i0 = 16 * (j + 1 + t);
+        d4 acc = {0, 0, 0, 0};
+        acc = tile_mm_f([&](int k) { return A[(i0 + r) * LD + j0 + k + q]; },
+                        [&](int k) { return Dt[j * 256 + r * 16 + k + q]; }, 0, 16, acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + j0 + r] = acc[rr];
+      } else {
+        const int c = t - (MT - 1 - j), c0 = 16 * c;  // c in [0, j)
+        d4 acc = {0, 0, 0, 0};
+        // kb == c: J_cc = Dinv_c
+        acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; },
+                        [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; }, 0, 16, acc);
+        // kb > c: J_kb,c lives transposed in the upper tiles
+        acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
+                        c0 + 16, j0, acc);
+        d4 out = {0, 0, 0, 0};
+        double dj[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dj[s] = Dt[j * 256 + r * 16 + 4 * s + q];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out = TGP_MFMA(dj[s], acc[s], out);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
+      }
+    }
+    __syncthreads();
+    PSTAMP(3);
   }
-  __syncthreads();
-  if (tid < MP) dinv[tid] = 1.0 / A[tid * LD + tid];
-  __syncthreads();
-  // ---- J = L^-1 by forward substitution, one thread per column c; column c of J is stored as row c of
-  //      the strict upper triangle of A (J^T), the diagonal is dinv.  x_i = -(sum_{c<=k<i} L_ik x_k)/L_ii ----
-  if (tid < M) {
-    const int c = tid;
-    for (int i = c + 1; i < M; ++i) {
-      double s = A[i * LD + c] * dinv[c];
-      for (int k = c + 1; k < i; ++k) s += A[i * LD + k] * A[c * LD + k];
-      A[c * LD + i] = -s * dinv[i];
+  // ---- write L, J, J^T tile by tile (one wave per 16x16 tile, 128-byte row segments) ----
+  for (int t = wave; t < MT * MT; t += PREP_THREADS / 64) {
+    const int ti = t / MT, tj = t % MT;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      double l = 0.0, jv = 0.0;
+      if (ti == tj) {
+        if (cc <= rr) l = A[rr * LD + cc];
+        jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
+      } else if (tj < ti) {
+        l = A[rr * LD + cc];
+        jv = A[cc * LD + rr];
+      }
+      ws[p.L + (size_t)rr * MP + cc] = l;
+      ws[p.J + (size_t)rr * MP + cc] = jv;
+      // J^T tile (ti, tj) = transpose of J tile (tj, ti)
+      double jt = 0.0;
+      if (ti == tj) jt = Dt[ti * 256 + (cc & 15) * 16 + (rr & 15)];
+      else if (ti < tj) jt = A[rr * LD + cc];
+      ws[p.JT + (size_t)rr * MP + cc] = jt;
     }
-  }
-  __syncthreads();
-  // ---- write L, J, J^T (padding = identity) ----
-  for (int i = tid; i < MP * MP; i += PREP_THREADS) {
-    const int r = i / MP, c = i % MP;
-    double l = 0.0, jv = 0.0;
-    if (c < r) { l = A[r * LD + c]; jv = A[c * LD + r]; }
-    else if (c == r) { l = A[r * LD + r]; jv = dinv[r]; }
-    ws[p.L + i] = l;
-    ws[p.J + i] = jv;
-    ws[p.JT + (size_t)c * MP + r] = jv;
   }
   if (tid == 0) {
     status[0] = s_info;
     status[1] = s_nan;
   }
+#ifdef TGP_STAMPS
+  if (tid == 0) {
+    unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 4; ++i) ws[p.hdr + H_STAMP + 12 + i] = tph[i];
+    ws[p.hdr + H_STAMP + 16] = (double)(tn_ - tlast);
+  }
+#endif
 }
 
 size_t prep_a_lds_bytes(const Plan& p) {
-  return ((size_t)p.MP * (p.MP + 1) + p.MP + (size_t)p.MP * p.DP + 32) * sizeof(double);
+  size_t dt = (size_t)p.MT * 256, zs = (size_t)p.MP * p.DP;
+  return ((size_t)p.MP * (p.MP + 1) + (dt > zs ? dt : zs) + 16) * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_prep_b: H' = J^T S - J^T (tiles), w = J^T m (last block)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_prep_b(Plan p, double* __restrict__ ws) {
-  const int MP = p.MP, MT = p.MT;
-  const int l = threadIdx.x, r = l & 15, q = l >> 4;
-  const double* J = ws + p.J;
-  if ((int)blockIdx.x == MT * MT) {
-    const double* mp = ws + p.mpad;
-    for (int i = l; i < MP; i += 64) {
-      double s = 0.0;
-      for (int k = i; k < MP; ++k) s += J[(size_t)k * MP + i] * mp[k];
-      ws[p.w + i] = s;
-    }
-    return;
-  }
-  const int ti = blockIdx.x / MT, tj = blockIdx.x % MT;
-  d4 acc = {0, 0, 0, 0};
-  acc = tile_mm<true, false>(J, ws + p.S_, MP, ti * 16, tj * 16, ti * 16, MP, acc);  // (J^T)[i,k] = 0 for k < i
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = ti * 16 + q + 4 * rr, col = tj * 16 + r;
-    ws[p.Hp + (size_t)row * MP + col] = acc[rr] - J[(size_t)col * MP + row];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_reduce: sum the per-block slabs of the row kernel; G tiles are expanded to a full symmetric matrix
+// k_reduce: sum the per-block slabs of the row kernel in TGP_RSPLIT independent partial sums (grid.y);
+// the G tiles are expanded to full symmetric matrices.  Consumers add the partials (fixed order).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.slab_len) return;
+  const int part = blockIdx.y;
+  const int b0 = (int)((long long)p.nblocks * part / TGP_RSPLIT), b1 = (int)((long long)p.nblocks * (part + 1) / TGP_RSPLIT);
   const double* sl = ws + p.slabs + e;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = 0;
-  for (; b + 4 <= p.nblocks; b += 4) {
-    s0 += sl[(size_t)b * p.slab_len];
-    s1 += sl[(size_t)(b + 1) * p.slab_len];
-    s2 += sl[(size_t)(b + 2) * p.slab_len];
-    s3 += sl[(size_t)(b + 3) * p.slab_len];
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = sl[(size_t)(b + u) * p.slab_len];
+    s0 += t[0] + t[4]; s1 += t[1] + t[5]; s2 += t[2] + t[6]; s3 += t[3] + t[7];
   }
-  for (; b < p.nblocks; ++b) s0 += sl[(size_t)b * p.slab_len];
+  for (; b < b1; ++b) s0 += sl[(size_t)b * p.slab_len];
   const double s = (s0 + s1) + (s2 + s3);
   if (e < p.slab_T) {
     // tile t = (ti,tj), ti >= tj, row-major over the lower triangle of tiles
@@ -251,162 +350,213 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
-    double* G = ws + p.Gf;
+    double* G = ws + p.Gp + (size_t)part * p.MP * p.MP;
     G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col] = s;
     G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row] = s;
   } else {
-    ws[p.red + e] = s;
+    ws[p.redp + (size_t)part * p.slab_len + e] = s;
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_bwd1: Lbar = -tril(w s^T + 2 H' G)   and   LamB = 2 tril(G Lq)     (grid: 2 * MT*MT waves)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_bwd1(Plan p, double* __restrict__ ws) {
-  const int MP = p.MP, MT = p.MT;
-  const int l = threadIdx.x, r = l & 15, q = l >> 4;
-  const int op = blockIdx.x / (MT * MT), t = blockIdx.x % (MT * MT);
-  const int ti = t / MT, tj = t % MT;
-  double* out = ws + (op == 0 ? p.Lb : p.LamB);
-  d4 acc = {0, 0, 0, 0};
-  if (ti >= tj) {
-    if (op == 0) acc = tile_mm<false, false>(ws + p.Hp, ws + p.Gf, MP, ti * 16, tj * 16, 0, MP, acc);
-    else acc = tile_mm<true, false>(ws + p.Gf, ws + p.Lq, MP, ti * 16, tj * 16, tj * 16, MP, acc);  // G symmetric; Lq[k,j]=0 for k<j
-  }
-  const double* w = ws + p.w;
-  const double* sv = ws + p.red + p.slab_S;
+__device__ __forceinline__ double red_tail(const Plan& p, const double* __restrict__ ws, size_t e) {
+  double s = 0.0;
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int row = ti * 16 + q + 4 * rr, col = tj * 16 + r;
-    double x = 0.0;
-    if (col <= row) x = (op == 0) ? -(w[row] * sv[col] + 2.0 * acc[rr]) : 2.0 * acc[rr];
-    out[(size_t)row * MP + col] = x;
-  }
+  for (int part = 0; part < TGP_RSPLIT; ++part) s += ws[p.redp + (size_t)part * p.slab_len + e];
+  return s;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bwd2: Q = Phi(L^T Lbar) + Phi(L^T Lbar)^T   (lower tiles computed, mirrored on store)
+// k_bwd12 (grid = MT workgroups, one per column block c; 8 waves)
+//   Gs    = G(:, c)  (sum of the partials, staged in LDS)
+//   Lbar(:, c) = -tril(w s^T + 2 H' G)(:, c)                      -> LDS
+//   dELBO/dLam(c-rows, :) = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)) -> final gradient (strict upper = 0)
+//   Q(i, c) = [Phi(L^T Lbar) + Phi(L^T Lbar)^T](i, c), i >= c      -> HBM, mirrored
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_bwd2(Plan p, double* __restrict__ ws) {
-  const int MP = p.MP;
-  const int l = threadIdx.x, r = l & 15, q = l >> 4;
-  int ti = 0;
-  const int t = blockIdx.x;
-  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-  const int tj = t - ti * (ti + 1) / 2;
-  const double* L = ws + p.L;
-  const double* Lb = ws + p.Lb;
+#define BWD_THREADS 512
+
+__global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp_grads g, double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const int MP = p.MP, MT = p.MT, M = p.M;
+  double* Gs = sm;                   // MP x 16
+  double* LbL = Gs + (size_t)MP * 16;  // MP x 16
+  double* svL = LbL + (size_t)MP * 16; // 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int c = blockIdx.x, c0 = 16 * c;
+  const double* __restrict__ Gp = ws + p.Gp;
+  const size_t mm = (size_t)MP * MP;
+  for (int i = tid; i < MP * 16; i += BWD_THREADS) {
+    const int row = i >> 4, cc = i & 15;
+    double s = 0.0;
+#pragma unroll
+    for (int part = 0; part < TGP_RSPLIT; ++part) s += Gp[part * mm + (size_t)row * MP + c0 + cc];
+    Gs[i] = s;
+    LbL[i] = 0.0;
+  }
+  if (tid < 16) svL[tid] = red_tail(p, ws, p.slab_S + c0 + tid);
+  __syncthreads();
+  const double* __restrict__ HpT = ws + p.HpT;
+  const double* __restrict__ Lq = ws + p.Lq;
+  const double* __restrict__ Lm = ws + p.L;
+  const double* __restrict__ w = ws + p.w;
+  // ---- Lbar tiles (i >= c) and Lam-gradient tiles (all j) ----
+  for (int t = wave; t < (MT - c) + MT; t += BWD_THREADS / 64) {
+    if (t < MT - c) {
+      const int i0 = 16 * (c + t);
+      d4 acc = {0, 0, 0, 0};
+      acc = tile_mm_f([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
+                      [&](int k) { return Gs[(k + q) * 16 + r]; }, 0, MP, acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = i0 + q + 4 * rr, col = c0 + r;
+        LbL[row * 16 + r] = (col <= row) ? -(w[row] * svL[r] + 2.0 * acc[rr]) : 0.0;
+      }
+    } else {
+      // X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
+      const int j = t - (MT - c), j0 = 16 * j;
+      d4 acc = {0, 0, 0, 0};
+      if (j <= c)
+        acc = tile_mm_f([&](int k) { return Lq[(size_t)(k + q) * MP + j0 + r]; },
+                        [&](int k) { return Gs[(k + q) * 16 + r]; }, j0, MP, acc);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = c0 + r, col = j0 + q + 4 * rr;  // transposed store
+        if (row < M && col < M) {
+          double x = 0.0;
+          if (col <= row) {
+            const double lam = md.Lam[(size_t)row * M + col];
+            x = 2.0 * acc[rr] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);
+          }
+          g.Lam[(size_t)row * M + col] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- Q(i, c) = Phi(M1) + Phi(M1)^T with M1 = L^T Lbar ;  (L^T)[i,k] = L[k,i] = 0 for k < i ----
   double* Q = ws + p.Q;
-  d4 acc = {0, 0, 0, 0};
-  acc = tile_mm<true, false>(L, Lb, MP, ti * 16, tj * 16, ti * 16, MP, acc);  // (L^T)[i,k] = L[k,i] = 0 for k < i
-  if (ti != tj) {
+  for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
+    const int i = c + t, i0 = 16 * i;
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
+                    [&](int k) { return LbL[(k + q) * 16 + r]; }, i0, MP, acc);
+    if (i != c) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = ti * 16 + q + 4 * rr, col = tj * 16 + r;
-      Q[(size_t)row * MP + col] = acc[rr];
-      Q[(size_t)col * MP + row] = acc[rr];
-    }
-  } else {
-    d4 tr = {0, 0, 0, 0};  // (L^T Lbar)^T tile = Lbar^T L
-    tr = tile_mm<true, false>(Lb, L, MP, ti * 16, tj * 16, ti * 16, MP, tr);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = i0 + q + 4 * rr, col = c0 + r;
+        Q[(size_t)row * MP + col] = acc[rr];
+        Q[(size_t)col * MP + row] = acc[rr];
+      }
+    } else {
+      d4 tr = {0, 0, 0, 0};  // M1^T tile = Lbar^T L
+      tr = tile_mm_f([&](int k) { return LbL[(k + q) * 16 + r]; },
+                     [&](int k) { return Lm[(size_t)(k + q) * MP + c0 + r]; }, c0, MP, tr);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int rl = q + 4 * rr;
-      const double x = (r <= rl) ? acc[rr] : tr[rr];  // below/on diagonal: M1[r][c]; above: M1[c][r]
-      Q[(size_t)(ti * 16 + rl) * MP + tj * 16 + r] = x;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int rl = q + 4 * rr;
+        Q[(size_t)(c0 + rl) * MP + c0 + r] = (r <= rl) ? acc[rr] : tr[rr];
+      }
     }
   }
 }
 
-// k_bwd3: Y = J^T Q ;  k_bwd4: Ks = 1/2 Y J
-__global__ __launch_bounds__(64) void k_bwd3(Plan p, double* __restrict__ ws) {
-  const int MP = p.MP, MT = p.MT;
-  const int l = threadIdx.x, r = l & 15, q = l >> 4;
-  const int ti = blockIdx.x / MT, tj = blockIdx.x % MT;
-  d4 acc = {0, 0, 0, 0};
-  acc = tile_mm<true, false>(ws + p.J, ws + p.Q, MP, ti * 16, tj * 16, ti * 16, MP, acc);
+// ---------------------------------------------------------------------------------------------------
+// k_bwd34 (grid = MT workgroups, one per row block i; 8 waves)
+//   Y(i, :) = (J^T Q)(i, :)                  -> LDS
+//   Ks(i, j) = 1/2 (Y J)(i, j)  = dELL/dK_MM  (never stored)
+//   PP[i][col][d] = sum_{rows in block i} (Ks o K_MM)[row][col] * [Zs[row][d], 1]   (ARD-RBF parameter partials)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Yl = reinterpret_cast<double*>(smem_raw);  // MT x 256
+  const int MP = p.MP, MT = p.MT, DP = p.DP, PPW = p.PPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int i = blockIdx.x, i0 = 16 * i;
+  const double* __restrict__ J = ws + p.J;
+  const double* __restrict__ Q = ws + p.Q;
+  for (int kb = wave; kb < MT; kb += BWD_THREADS / 64) {
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f([&](int k) { return J[(size_t)(k + q) * MP + i0 + r]; },
+                    [&](int k) { return Q[(size_t)(k + q) * MP + 16 * kb + r]; }, i0, MP, acc);
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) ws[p.Y + (size_t)(ti * 16 + q + 4 * rr) * MP + tj * 16 + r] = acc[rr];
-}
-
-__global__ __launch_bounds__(64) void k_bwd4(Plan p, double* __restrict__ ws) {
-  const int MP = p.MP, MT = p.MT;
-  const int l = threadIdx.x, r = l & 15, q = l >> 4;
-  const int ti = blockIdx.x / MT, tj = blockIdx.x % MT;
-  d4 acc = {0, 0, 0, 0};
-  acc = tile_mm<false, false>(ws + p.Y, ws + p.J, MP, ti * 16, tj * 16, tj * 16, MP, acc);  // J[k,j] = 0 for k < j
+    for (int rr = 0; rr < 4; ++rr) Yl[kb * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
+  }
+  __syncthreads();
+  const double* __restrict__ Kmm = ws + p.Kmm;
+  const double* __restrict__ Zs = ws + p.Zs;
+  for (int jb = wave; jb < MT; jb += BWD_THREADS / 64) {
+    const int j0 = 16 * jb;
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f([&](int k) { return Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q]; },
+                    [&](int k) { return J[(size_t)(k + q) * MP + j0 + r]; }, j0, MP, acc);  // J[k,j] = 0 for k < j
+    double ep[4];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) ws[p.Ks + (size_t)(ti * 16 + q + 4 * rr) * MP + tj * 16 + r] = 0.5 * acc[rr];
+    for (int rr = 0; rr < 4; ++rr) ep[rr] = 0.5 * acc[rr] * Kmm[(size_t)(i0 + q + 4 * rr) * MP + j0 + r];
+    double cs = quad_sum((ep[0] + ep[1]) + (ep[2] + ep[3]));
+    double* out = ws + p.PP + ((size_t)i * MP + j0 + r) * PPW;
+    if (q == 0) out[DP] = cs;
+    for (int d = 0; d < DP; ++d) {
+      double s = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s += ep[rr] * Zs[(i0 + q + 4 * rr) * DP + d];
+      s = quad_sum(s);
+      if (q == 0) out[d] = s;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bwd5: assemble every output gradient + the scalars (single block)
+// k_bwd5: assemble the remaining gradients + the scalars (single block; everything here is O(M D))
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g, double* __restrict__ out,
                                                double* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* term = reinterpret_cast<double*>(smem_raw);  // M x (D+1): per-(j,d) lengthscale terms, column D = cs_j + T0_j
   const int tid = threadIdx.x;
-  const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, CT16 = p.CT16;
-  __shared__ double lsacc[16];
-  __shared__ double wsum[8];
+  const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, CT16 = p.CT16, PPW = p.PPW, MT = p.MT;
   const double* hdr = ws + p.hdr;
   const double s2 = hdr[H_S2];
-  const double* Ks = ws + p.Ks;
-  const double* Kmm = ws + p.Kmm;
   const double* Zs = ws + p.Zs;
-  const double* T = ws + p.red + p.slab_T;  // [MP][CT16]: cols [0,DP) = T1, [DP,2DP) = T2, 2DP = T0
-  const double* C = ws + p.red + p.slab_C;
-  if (tid < 16) lsacc[tid] = 0.0;
-  __syncthreads();
-  double ep_sum = 0.0;  // sum_ij Ks*Kmm + sum_j T0_j
-  for (int it = tid; it < M * D; it += 256) {
-    const int j = it / D, d = it % D;
-    const double zj = Zs[j * DP + d];
-    const double t0 = T[j * CT16 + 2 * DP], t1 = T[j * CT16 + d], t2 = T[j * CT16 + DP + d];
-    double zsb = t1 - zj * t0;
-    double lt = t2 - 2.0 * zj * t1 + zj * zj * t0;
-    double es = 0.0;
-    for (int i = 0; i < M; ++i) {
-      const double ep = Ks[(size_t)i * MP + j] * Kmm[(size_t)i * MP + j];
-      const double dz = Zs[i * DP + d] - zj;
-      zsb += 2.0 * ep * dz;
-      lt += ep * dz * dz;
-      es += ep;
+  for (int it = tid; it < M * (D + 1); it += 256) {
+    const int j = it / (D + 1), d = it % (D + 1);
+    double cs = 0.0;
+    for (int ib = 0; ib < MT; ++ib) cs += ws[p.PP + ((size_t)ib * MP + j) * PPW + DP];
+    const double t0 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
+    if (d == D) {
+      term[it] = cs + t0;
+    } else {
+      double R = 0.0;
+      for (int ib = 0; ib < MT; ++ib) R += ws[p.PP + ((size_t)ib * MP + j) * PPW + d];
+      const double t1 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + d);
+      const double t2 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + d);
+      const double zj = Zs[j * DP + d];
+      // dELL/dzs_jd = [T1 - zs T0] (rows) + 2 sum_i Ep_ij (zs_id - zs_jd) (K_MM, Ep symmetric)
+      g.Z[j * D + d] = (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d];
+      // lengthscale: sum_n E (xs - zs)^2 + sum_ij Ep_ij (zs_id - zs_jd)^2 ; second = 2 sum_j zs_jd (zs_jd cs_j - R_jd)
+      term[it] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
     }
-    g.Z[it] = zsb * ws[p.ils + d];
-    atomicAdd(&lsacc[d], lt);
-    if (d == 0) ep_sum += es + t0;
   }
-  ep_sum = wave_sum(ep_sum);
-  if ((tid & 63) == 0) wsum[tid >> 6] = ep_sum;
   __syncthreads();
-  if (tid < D) g.raw_ls[tid] = lsacc[tid] * ws[p.ils + tid] * sigmoid_d(md.raw_ls[tid]);
-  if (tid == 0) {
-    const double tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const double s2b = C[C_SVB] + tot / s2;
-    g.raw_os[0] = s2b * hdr[H_SIG_OS];
-    g.log_var_noise[0] = C[C_ETAB];
-    const double ell = C[C_ELL], kl = hdr[H_KL];
-    out[0] = ell - kl;
-    out[1] = ell;
-    out[2] = kl;
-    out[3] = 0.0;
-  }
-  // m: sbar = A mubar summed over rows, minus the KL part (KL' = m)
-  const double* sv = ws + p.red + p.slab_S;
-  for (int i = tid; i < M; i += 256) g.m[i] = sv[i] - md.kl_scale * md.m[i];
-  // Lam: tril only; strict upper triangle receives exactly zero (mask at use, sparse_MF_SP.py:344-345)
-  const double* LamB = ws + p.LamB;
-  for (int it = tid; it < M * M; it += 256) {
-    const int r = it / M, c = it % M;
-    double x = 0.0;
-    if (c <= r) {
-      const double lam = md.Lam[it];
-      x = LamB[(size_t)r * MP + c] - md.kl_scale * (c == r ? lam - 1.0 / lam : lam);
+  if (tid <= D) {
+    double s = 0.0;
+    for (int j = 0; j < M; ++j) s += term[j * (D + 1) + tid];
+    if (tid < D) {
+      g.raw_ls[tid] = s * ws[p.ils + tid] * sigmoid_d(md.raw_ls[tid]);
+    } else {
+      const double s2b = red_tail(p, ws, p.slab_C + C_SVB) + s / s2;
+      g.raw_os[0] = s2b * hdr[H_SIG_OS];
+      g.log_var_noise[0] = red_tail(p, ws, p.slab_C + C_ETAB);
+      const double ell = red_tail(p, ws, p.slab_C + C_ELL), kl = hdr[H_KL];
+      out[0] = ell - kl;
+      out[1] = ell;
+      out[2] = kl;
+      out[3] = 0.0;
     }
-    g.Lam[it] = x;
   }
+  // m: sbar = A mubar summed over rows, minus the KL part (dKL/dm = m)
+  for (int i = tid; i < M; i += 256) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
   if (g.theta != nullptr)
-    for (int i = tid; i < p.P; i += 256) g.theta[i] = C[C_THETA + i];
+    for (int i = tid; i < p.P; i += 256) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -544,29 +694,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_chol_only(const double* __rest
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-int launch_prepare(const Plan& p, const tgp_model& md, double* ws, int32_t* status, hipStream_t st) {
+int launch_prepare(const Plan& p, const tgp_model& md, const FlowProg& fp, double* ws, int32_t* status,
+                   hipStream_t st) {
   const size_t lds = prep_a_lds_bytes(p);
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_prep_a), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(k_prep_a, dim3(1 + p.MT * p.MT), dim3(PREP_THREADS), lds, st, p, md, ws, status);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_prep_b, dim3(p.MT * p.MT + 1), dim3(64), 0, st, p, ws);
+  hipLaunchKernelGGL(k_prep_a, dim3(2 + p.MT * p.MT), dim3(PREP_THREADS), lds, st, p, md, fp, ws, status);
   LAUNCH_CHECK();
   return 0;
 }
 
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256)), dim3(256), 0, st, p, ws);
+  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd1, dim3(2 * p.MT * p.MT), dim3(64), 0, st, p, ws);
+  hipLaunchKernelGGL(k_bwd12, dim3(p.MT), dim3(BWD_THREADS), (size_t)(2 * p.MP * 16 + 16) * sizeof(double), st, p, md, g, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd2, dim3(p.ntri), dim3(64), 0, st, p, ws);
+  hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), (size_t)p.MT * 256 * sizeof(double), st, p, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd3, dim3(p.MT * p.MT), dim3(64), 0, st, p, ws);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd4, dim3(p.MT * p.MT), dim3(64), 0, st, p, ws);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), 0, st, p, md, g, out, ws);
+  hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), (size_t)p.M * (p.D + 1) * sizeof(double), st, p, md, g, out, ws);
   LAUNCH_CHECK();
   return 0;
 }

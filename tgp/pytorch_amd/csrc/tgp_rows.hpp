@@ -18,6 +18,8 @@
 
 namespace tgp {
 
+#define TGP_NODES_IN_FLIGHT 4
+
 struct RowArgs {
   Plan p;
   const double* X;
@@ -27,7 +29,7 @@ struct RowArgs {
   double* mu;
   double* v;
   double* ws;
-  const int32_t* program;
+  FlowProg prog;
   const double* xs;
   const double* wn;
   double scale;
@@ -38,7 +40,10 @@ struct RowLds {
   size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, xs, wn, stack, acc, red, prog, total;
 };
 
-__host__ __device__ inline RowLds row_lds(const Plan& p, bool train) {
+// mode: 0 = moments only, 1 = training, flow in "store" mode (2 nodes in flight), 2 = training, flow recomputed in
+// the reverse sweep (fallback when the store-mode stack does not fit in LDS); nslots = flow_slots(program)
+__host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
+  const bool train = mode != 0;
   RowLds L;
   size_t o = 0;
   auto take = [&o](size_t n) { size_t r = o; o += (n + 1) / 2 * 2; return r; };  // keep 16-byte alignment
@@ -56,24 +61,35 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, bool train) {
     L.xt = take((size_t)TGP_ROWS_PER_BLOCK * p.CT16);
     L.vbs = take(TGP_ROWS_PER_BLOCK);
     L.mbs = take(TGP_ROWS_PER_BLOCK);
-    L.stack = take((size_t)(p.nblk > 0 ? p.nblk : 1) * 256);
-    L.acc = take((size_t)(p.P + p.RP > 0 ? p.P + p.RP : 1) * 256);
+    if (mode == 1) {
+      // store-mode stack (TGP_NODES_IN_FLIGHT nodes per lane) shares its space with the transposition tile / the
+      // operand panels: the flow phase runs strictly between GEMM 2 and GEMM 3
+      const size_t st = (size_t)(nslots > 0 ? nslots : 1) * TGP_NODES_IN_FLIGHT * 256;
+      if (st > (size_t)p.MP * TGP_TILE_LD) take(st - (size_t)p.MP * TGP_TILE_LD);
+      L.stack = L.tile;
+      L.acc = take((size_t)(p.P > 0 ? p.P : 1) * 64 + (size_t)p.RP * 256);  // [P][64] quad-reduced + [RP][256] per lane
+    } else {
+      L.stack = take((size_t)(p.nblk > 0 ? p.nblk : 1) * 256);
+      L.acc = take((size_t)(p.P + p.RP > 0 ? p.P + p.RP : 1) * 256);
+    }
   } else {
-    L.tile = L.xt = L.vbs = L.mbs = L.stack = L.acc = o;
+    L.tile = take((size_t)p.MP * 32);  // only the two operand panels (2 x MP x 16)
+    L.xt = L.vbs = L.mbs = L.stack = L.acc = o;
   }
   L.total = o;
   return L;
 }
 
-template <int MT, int DP, bool TRAIN>
+template <int MT, int DP, int MODE>
 __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
+  constexpr bool TRAIN = MODE != 0;
   constexpr int MP = MT * 16;
   constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
   constexpr int LD = TGP_TILE_LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const Plan& p = a.p;
-  const RowLds L = row_lds(p, TRAIN);
+  const RowLds L = row_lds(p, MODE, a.prog.nslots);
   double* zs = sm + L.zs;
   double* ils = sm + L.ils;
   double* mv = sm + L.mv;
@@ -94,6 +110,34 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   const double* __restrict__ ws = a.ws;
   const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
 
+  if (TRAIN && (int)blockIdx.x >= p.nblocks) {
+    // ---- passenger blocks: H'^T = (J^T (S - I))^T tiles and w = J^T m, needed only by the backward M x M chain;
+    //      they run on CUs the row tiles leave idle instead of costing a launch of their own ----
+    const int t = blockIdx.x - p.nblocks;
+    const double* __restrict__ Jg = ws + p.J;
+    if (t == MT * MT) {
+      for (int i = tid; i < MP; i += 256) {
+        double s = 0.0;
+        for (int k = i; k < MP; ++k) s += Jg[(size_t)k * MP + i] * ws[p.mpad + k];
+        a.ws[p.w + i] = s;
+      }
+      return;
+    }
+    if (wave != 0) return;
+    const int ti = t / MT, tj = t % MT;
+    const double* __restrict__ Sg = ws + p.S_;
+    d4 hacc = {0, 0, 0, 0};
+    hacc = tile_mm_f([&](int k) { return Jg[(size_t)(k + q) * MP + 16 * ti + nl]; },
+                    [&](int k) { return Sg[(size_t)(k + q) * MP + 16 * tj + nl]; }, 16 * ti, MP, hacc);  // (J^T)[i,k]=0, k<i
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 16 * ti + q + 4 * rr, col = 16 * tj + nl;
+      a.ws[p.HpT + (size_t)col * MP + row] = hacc[rr] - Jg[(size_t)col * MP + row];
+    }
+    return;
+  }
+
+  TGP_STAMP(a.ws, p, 0);
   // ---- stage the small shared operands ----
   for (int i = tid; i < MP * DP; i += 256) zs[i] = ws[p.Zs + i];
   for (int i = tid; i < MP; i += 256) mv[i] = ws[p.mpad + i];
@@ -101,12 +145,15 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   if (p.lik == TGP_LIK_FLOW) {
     for (int i = tid; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; }
     for (int i = tid; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
-    for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.program[i];
+    for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
   }
-  if (TRAIN)
-    for (int i = tid; i < (P + RP) * 256; i += 256) acc[i] = 0.0;
+  if (TRAIN) {
+    const int nacc = MODE == 1 ? P * 64 + RP * 256 : (P + RP) * 256;
+    for (int i = tid; i < nacc; i += 256) acc[i] = 0.0;
+  }
   __syncthreads();
 
+  TGP_STAMP(a.ws, p, 1);
   const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
   const int n = blockIdx.x * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
   const bool valid = n < N;
@@ -130,29 +177,74 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     Kr[ks] = mm < M ? s2 * exp(-0.5 * d2) : 0.0;
   }
 
-  // ---- A = J K : A_i = sum_{kb <= i} J[i,kb] K_kb ; A operand read from J^T (coalesced) ----
+  TGP_STAMP(a.ws, p, 2);
+  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
+  //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
+  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out;
+  //      the global load of panel p+1 is in flight while panel p feeds the matrix pipe.
   const double* __restrict__ JT = ws + p.JT;
   const double* __restrict__ Jm = ws + p.J;
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ LqT = ws + p.LqT;
+  double* pan = tile;  // 2 x (MP x 16)
+  double stg[MT];
+  // lower-type panel i: rows [0, 16(i+1)); upper-type: rows [16 i, MP)
+  auto issue = [&](const double* __restrict__ Mt, int i, bool lower) {
+    const int r0 = lower ? 0 : 16 * i, r1 = lower ? 16 * (i + 1) : MP;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int row = r0 + (tid >> 4) + 16 * u;
+      if (row < r1) stg[u] = Mt[(size_t)row * MP + 16 * i + (tid & 15)];
+    }
+  };
+  auto commit = [&](double* buf, int i, bool lower) {
+    const int r0 = lower ? 0 : 16 * i, r1 = lower ? 16 * (i + 1) : MP;
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+      const int row = r0 + (tid >> 4) + 16 * u;
+      if (row < r1) buf[row * 16 + (tid & 15)] = stg[u];
+    }
+  };
+
   d4 Aa[MT], Ba[MT];
+  // ---- A = J K : A_i = sum_{kb <= i} J[i,kb] K_kb  (A operand = rows of J^T) ----
+  issue(JT, 0, true);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    d4 c = {0, 0, 0, 0};
+    double* buf = pan + (i & 1) * (MP * 16);
+    commit(buf, i, true);
+    __syncthreads();
+    if (i + 1 < MT) issue(JT, i + 1, true);
+    else issue(Lq, 0, false);
+    // two independent accumulator chains: a single dependent chain of v_mfma_f64_16x16x4 issues at about half
+    // the rate of the matrix pipe (measured ~140 cycles per MFMA instead of 64)
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < 4 * (i + 1); ++ks) c = TGP_MFMA(JT[(size_t)(4 * ks + q) * MP + 16 * i + nl], Kr[ks], c);
-    Aa[i] = c;
+    for (int ks = 0; ks < 4 * (i + 1); ks += 2) {
+      c = TGP_MFMA(buf[(4 * ks + q) * 16 + nl], Kr[ks], c);
+      c2 = TGP_MFMA(buf[(4 * ks + 4 + q) * 16 + nl], Kr[ks + 1], c2);
+    }
+    Aa[i] = c + c2;
   }
+  TGP_STAMP(a.ws, p, 3);
   // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    d4 c = {0, 0, 0, 0};
+    double* buf = pan + ((MT + i) & 1) * (MP * 16);
+    commit(buf, i, false);
+    __syncthreads();
+    if (i + 1 < MT) issue(Lq, i + 1, false);
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int kb = i; kb < MT; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c = TGP_MFMA(Lq[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Aa[kb][r], c);
-    Ba[i] = c;
+    for (int kb = i; kb < MT; ++kb) {
+      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Aa[kb][0], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Aa[kb][1], c2);
+      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Aa[kb][2], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Aa[kb][3], c2);
+    }
+    Ba[i] = c + c2;
   }
+  TGP_STAMP(a.ws, p, 4);
   // ---- mu, v ----
   double pm = 0.0, pa = 0.0, pb = 0.0;
 #pragma unroll
@@ -168,6 +260,7 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   if (a.mu != nullptr && q == 0 && valid) { a.mu[n] = mu; a.v[n] = v; }
   if (!TRAIN) return;
 
+  TGP_STAMP(a.ws, p, 5);
   // ---- expected log-likelihood and its adjoints ----
   double mub = 0.0, vb = 0.0, ellp = 0.0, etap = 0.0;
   const double y = a.Y[nc];
@@ -181,12 +274,45 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
       etap = -0.5 + 0.5 * einv * (r * r + v);
     }
   } else {
-    // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): nodes s = q, q+4, ...
+    // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): this lane takes the
+    // quadrature nodes s = q, q+4, q+8, ... of its row
     FlowDev F{progL, p.nblk, tpL, tgL};
     const double sq = sqrt(2.0 * v);
     const double* rp = a.rowp != nullptr ? a.rowp + (size_t)nc * RP : nullptr;
     double cm = 0.0, cv = 0.0;
-    if (valid) {
+    if (MODE == 1) {
+      // NB nodes in flight per lane (independent dependency chains); every lane runs the same trip count
+      // (cross-lane sums inside the reverse sweep), out-of-range nodes and padding rows carry weight 0
+      constexpr int NB = TGP_NODES_IN_FLIGHT;
+      double* accq = acc + wave * 16 + nl;
+      double* accr = acc + (size_t)P * 64 + tid;
+      const int ntrip = (p.S + 4 * NB - 1) / (4 * NB);
+      __syncthreads();  // the stack aliases the operand panels: all waves must be done with GEMM 2
+      for (int it = 0; it < ntrip; ++it) {
+        double xn[NB], wq[NB], f[NB], c[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const int sn = q + 4 * (NB * it + u);
+          xn[u] = xsL[sn < p.S ? sn : 0];
+          wq[u] = (valid && sn < p.S) ? wnL[sn] : 0.0;
+          f[u] = mu + sq * xn[u];
+        }
+        flow_forward_store<NB>(F, f, rp, stack + tid, 256);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const double r = y - f[u];
+          ellp += wq[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+          etap += wq[u] * (-0.5 + 0.5 * einv * r * r);
+          c[u] = a.scale * einv * wq[u] * r;
+        }
+        flow_backward_store<NB>(F, c, rp, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          cm += c[u];
+          cv += c[u] * xn[u];
+        }
+      }
+    } else if (valid) {
       for (int s = q; s < p.S; s += 4) {
         const double xsn = xsL[s], wsn = wnL[s];
         const double g = flow_forward(F, mu + sq * xsn, rp, stack + tid, 256, nullptr);
@@ -203,18 +329,29 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   }
   if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
 
+  TGP_STAMP(a.ws, p, 6);
   // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = J^T Abar ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) Ba[i] *= vb;
   d4 Ca[MT];
+  __syncthreads();  // every wave is done with the forward panels before they are overwritten
+  issue(LqT, 0, true);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    d4 c = {0, 0, 0, 0};
+    double* buf = pan + (i & 1) * (MP * 16);
+    commit(buf, i, true);
+    __syncthreads();
+    if (i + 1 < MT) issue(LqT, i + 1, true);
+    else issue(Jm, 0, false);
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int kb = 0; kb <= i; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c = TGP_MFMA(LqT[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Ba[kb][r], c);
-    Ca[i] = c;
+    for (int kb = 0; kb <= i; ++kb) {
+      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Ba[kb][0], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Ba[kb][1], c2);
+      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Ba[kb][2], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Ba[kb][3], c2);
+    }
+    Ca[i] = c + c2;
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -222,14 +359,23 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     for (int r = 0; r < 4; ++r) Ca[i][r] = mv[16 * i + 4 * r + q] * mub - 2.0 * Aa[i][r] * vb + 2.0 * Ca[i][r];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    d4 c = {0, 0, 0, 0};
+    double* buf = pan + ((MT + i) & 1) * (MP * 16);
+    commit(buf, i, false);
+    __syncthreads();
+    if (i + 1 < MT) issue(Jm, i + 1, false);
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int kb = i; kb < MT; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c = TGP_MFMA(Jm[(size_t)(16 * kb + 4 * r + q) * MP + 16 * i + nl], Ca[kb][r], c);
-    Ba[i] = c;  // Kbar
+    for (int kb = i; kb < MT; ++kb) {
+      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Ca[kb][0], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Ca[kb][1], c2);
+      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Ca[kb][2], c);
+      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Ca[kb][3], c2);
+    }
+    Ba[i] = c + c2;  // Kbar
   }
+  __syncthreads();  // panels dead: the region becomes the transposition tile
 
+  TGP_STAMP(a.ws, p, 7);
   double* slab = a.ws + p.slabs + (size_t)blockIdx.x * p.slab_len;
   const int col = wave * 16 + nl;
 
@@ -251,15 +397,19 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   __syncthreads();
   for (int t = wave; t < MT * CT; t += 4) {
     const int ti = t / CT, tc = t % CT;
-    d4 c = {0, 0, 0, 0};
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int nk = 0; nk < 16; ++nk)
+    for (int nk = 0; nk < 16; nk += 2) {
       c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], xt[(4 * nk + q) * CT16 + 16 * tc + nl], c);
+      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q], xt[(4 * nk + 4 + q) * CT16 + 16 * tc + nl], c2);
+    }
+    c += c2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
   }
   __syncthreads();
 
+  TGP_STAMP(a.ws, p, 8);
   // ---- phase 2: A through LDS, G = A diag(vbar) A^T (lower tiles), s = A mubar ----
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -271,24 +421,32 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
-    d4 c = {0, 0, 0, 0};
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int nk = 0; nk < 16; ++nk)
+    for (int nk = 0; nk < 16; nk += 2) {
       c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q] * vbs[4 * nk + q], tile[(16 * tj + nl) * LD + 4 * nk + q], c);
+      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q] * vbs[4 * nk + 4 + q],
+                    tile[(16 * tj + nl) * LD + 4 * nk + 4 + q], c2);
+    }
+    c += c2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
   }
   for (int ti = wave; ti < MT; ti += 4) {
-    d4 c = {0, 0, 0, 0};
+    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
 #pragma unroll
-    for (int nk = 0; nk < 16; ++nk)
+    for (int nk = 0; nk < 16; nk += 2) {
       c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], nl == 0 ? mbs[4 * nk + q] : 0.0, c);
+      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q], nl == 0 ? mbs[4 * nk + 4 + q] : 0.0, c2);
+    }
+    c += c2;
     if (nl == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
     }
   }
 
+  TGP_STAMP(a.ws, p, 9);
   // ---- scalars, flow parameter gradients ----
   const double e1 = wave_sum(ellp), e2 = wave_sum(etap), e3 = wave_sum(q == 0 ? vb : 0.0);
   if (lane == 0) { red[wave * 4] = e1; red[wave * 4 + 1] = e2; red[wave * 4 + 2] = e3; }
@@ -299,15 +457,24 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     slab[p.slab_C + C_SVB] = red[2] + red[6] + red[10] + red[14];
     slab[p.slab_C + C_PAD] = 0.0;
   }
-  for (int j = wave; j < P; j += 4) {
-    double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
-    s = wave_sum(s);
-    if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
+  if (MODE == 1) {
+    for (int j = wave; j < P; j += 4) {
+      const double s = wave_sum(acc[j * 64 + lane]);
+      if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
+    }
+  } else {
+    for (int j = wave; j < P; j += 4) {
+      double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
+      s = wave_sum(s);
+      if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
+    }
   }
+  TGP_STAMP(a.ws, p, 10);
   for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
   if (a.g_rowp != nullptr && q == 0 && valid) {
+    const double* rbase = MODE == 1 ? acc + (size_t)P * 64 : acc + (size_t)P * 256;
     for (int jr = 0; jr < RP; ++jr) {
-      const double* ap = acc + (size_t)(P + jr) * 256 + wave * 64 + nl;
+      const double* ap = rbase + (size_t)jr * 256 + wave * 64 + nl;
       a.g_rowp[(size_t)n * RP + jr] = ap[0] + ap[16] + ap[32] + ap[48];
     }
   }

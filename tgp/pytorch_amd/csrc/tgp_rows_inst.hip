@@ -11,22 +11,32 @@
 
 namespace tgp {
 
-template <int DP, bool TRAIN>
+template <int DP, int MODE>
 static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
-  auto kern = k_rows<TGP_MT, DP, TRAIN>;
+  constexpr bool TRAIN = MODE != 0;
+  auto kern = k_rows<TGP_MT, DP, MODE>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.p.nblocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.p.nblocks + (TRAIN ? a.p.MT * a.p.MT + 1 : 0)), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   return 0;
 }
 
-int CAT(launch_rows_mt, TGP_MT)(const RowArgs& a, bool train, size_t lds, hipStream_t st) {
+template <int DP>
+static int launch_dp(const RowArgs& a, int mode, size_t lds, hipStream_t st) {
+  switch (mode) {
+    case 0: return launch_one<DP, 0>(a, lds, st);
+    case 1: return launch_one<DP, 1>(a, lds, st);
+    default: return launch_one<DP, 2>(a, lds, st);
+  }
+}
+
+int CAT(launch_rows_mt, TGP_MT)(const RowArgs& a, int mode, size_t lds, hipStream_t st) {
   switch (a.p.DP) {
-    case 4: return train ? launch_one<4, true>(a, lds, st) : launch_one<4, false>(a, lds, st);
-    case 8: return train ? launch_one<8, true>(a, lds, st) : launch_one<8, false>(a, lds, st);
-    default: return train ? launch_one<16, true>(a, lds, st) : launch_one<16, false>(a, lds, st);
+    case 4: return launch_dp<4>(a, mode, lds, st);
+    case 8: return launch_dp<8>(a, mode, lds, st);
+    default: return launch_dp<16>(a, mode, lds, st);
   }
 }
 

@@ -81,7 +81,7 @@ class ElboEngine:
             self.flow = ops.FlowSpec(flow_blocks, P, RP, self.device)
         self.g_rowp = torch.zeros_like(self.rowp) if self.rowp is not None else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=self.device)
         self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
         mbg = mb_global if mb_global is not None else self.N
         scale = float(N_total) / float(mbg)

@@ -74,8 +74,13 @@ class FlowSpec:
         self.blocks = [tuple(int(v) for v in b) for b in program]
         self.nblk = len(self.blocks)
         self.P, self.RP = int(P), int(RP)
-        arr = np.array(self.blocks if self.blocks else [(0, 0, 0, 0)], dtype=np.int32)
-        self.program = torch.from_numpy(arr).to(device).contiguous()
+        # host array: the C ABI copies the program into the kernel arguments
+        self.program = np.ascontiguousarray(np.array(self.blocks if self.blocks else [(0, 0, 0, 0)], dtype=np.int32))
+
+    @property
+    def program_ptr(self):
+        import ctypes
+        return ctypes.c_void_p(self.program.ctypes.data)
 
     def to(self, device):
         return FlowSpec(self.blocks, self.P, self.RP, device)
@@ -95,7 +100,7 @@ def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, fl
         xs, wn = gauss_hermite(S, X.device)
         keep += [xs, wn]
         md.lik, md.S, md.nblk, md.P, md.RP = L.LIK_FLOW, int(S), flow.nblk, flow.P, flow.RP
-        md.program, md.xs, md.wn = L.ptr(flow.program), L.ptr(xs), L.ptr(wn)
+        md.program, md.xs, md.wn = flow.program_ptr, L.ptr(xs), L.ptr(wn)
         md.theta = L.ptr(theta) if flow.P > 0 else None
     return md, keep
 
@@ -315,7 +320,7 @@ def _flow_model(N, S, flow, theta, lvn, dev, scale=1.0, lik=L.LIK_FLOW):
     md.nblk, md.P, md.RP, md.lik = flow.nblk, flow.P, flow.RP, lik
     md.scale, md.jitter, md.kl_scale = float(scale), 0.0, 1.0
     xs, wn = gauss_hermite(S, dev)
-    md.program, md.xs, md.wn = L.ptr(flow.program), L.ptr(xs), L.ptr(wn)
+    md.program, md.xs, md.wn = flow.program_ptr, L.ptr(xs), L.ptr(wn)
     md.theta = L.ptr(theta) if flow.P > 0 else None
     md.log_var_noise = L.ptr(lvn)
     return md, (xs, wn)
