@@ -1,0 +1,107 @@
+"""CPU: host-side mirror of the reference API -- parameter names, flow compilation, optimiser groups, data path."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tgp_oracle as orc
+
+
+@pytest.fixture(scope="module", autouse=True)
+def f64():
+    from tgp.pytorch_amd import config as cg
+    old = torch.get_default_dtype()
+    cg.set_maximum_precission()
+    cg.device = "cpu"
+    yield
+    torch.set_default_dtype(old)
+
+
+def build(flow_specs=None, M=10, D=4):
+    from tgp.pytorch_amd.kernels import instance_kernel
+    from tgp.pytorch_amd.likelihoods import GaussianLinearMean, GaussianNonLinearMean
+    from tgp.pytorch_amd.models import sparse_MF_GP, sparse_MF_SP
+    X = torch.randn(50, D)
+    K = instance_kernel("scale_rbf", ard_num_dim=D, num_multioutput=1, kernel_is_shared=False,
+                        init_params={"length_scale": 2.0, "kernel_scale": 2.0})
+    ip = {"variational_distribution": {"variance_scale": 1e-5, "mean_scale": 0.0}}
+    if flow_specs is None:
+        return sparse_MF_GP(["zero", K], X, X[:M].clone(), 50, GaussianLinearMean(1, 0.05, False), 1, True, False, False,
+                            False, False, 0.0, init_params=ip)
+    return sparse_MF_SP(["zero", K], X, X[:M].clone(), 50, GaussianNonLinearMean(1, 0.05, False, 32), 1, True, False,
+                        False, False, False, [flow_specs], "single", 0.0, init_params=ip)
+
+
+def test_parameter_names_match_reference_appendix_b():
+    from tgp.pytorch_amd.flows import SAL
+    names = dict(build(SAL(2)).named_parameters())
+    for n, shape in (("Z", (1, 10, 4)), ("likelihood.log_var_noise", (1, 1)), ("q_U.variational_mean", (1, 10)),
+                     ("q_U.chol_variational_covar", (1, 10, 10)), ("covariance_function.raw_outputscale", (1,)),
+                     ("covariance_function.base_kernel.raw_lengthscale", (1, 1, 4)), ("G_matrix.0.flow_arr.0.a", ()),
+                     ("G_matrix.0.flow_arr.3.b", ())):
+        assert tuple(names[n].shape) == shape, n
+    svgp = dict(build(None).named_parameters())
+    assert not any("G_matrix" in n for n in svgp)
+    # initial values (main.py:95-110): l = 2, s2 = 2 through softplus, noise 0.05 through exp, Lq = sqrt(1e-5) I
+    sp = torch.nn.functional.softplus
+    assert torch.allclose(sp(svgp["covariance_function.base_kernel.raw_lengthscale"]), torch.tensor(2.0))
+    assert torch.allclose(sp(svgp["covariance_function.raw_outputscale"]), torch.tensor(2.0))
+    assert torch.allclose(svgp["likelihood.log_var_noise"].exp(), torch.tensor(0.05))
+    assert torch.allclose(torch.diagonal(svgp["q_U.chol_variational_covar"][0]), torch.tensor(1e-5).sqrt())
+
+
+def test_flow_compilation_matches_oracle_program():
+    from tgp.pytorch_amd.flow import compile_flow, instance_flow
+    from tgp.pytorch_amd.flows import SAL, StepTanhL
+    spec, theta, nets = compile_flow(instance_flow(SAL(2)))
+    prog, th = orc.sal_program(2)
+    assert spec.blocks == prog and [float(p) for p in theta] == th.tolist() and not nets
+    np.random.seed(0)
+    spec, theta, _ = compile_flow(instance_flow(StepTanhL(3, 2, add_f0=True)))
+    prog, th = orc.steptanh_program(3, 2, np.random.default_rng(0))
+    assert spec.blocks == prog and len(theta) == th.numel() == 30
+    idf = instance_flow(SAL(3, input_dependent=True, input_dim=4, num_hidden_layers=2, batch_norm=0, dropout=0.25,
+                            hidden_dim=50, hidden_activation="relu", inference="MC_dropout"))
+    with pytest.raises(AssertionError):
+        compile_flow(idf)                      # the reference insists on turn_off_initializer_parameters() first
+    idf.turn_off_initializer_parameters()
+    spec, theta, nets = compile_flow(idf)
+    assert spec.blocks == orc.sal_program(3, per_row=True)[0] and len(nets) == 6 and len(theta) == 6
+    names = [n for n, _ in idf.named_parameters()]
+    assert all(("NNets" in n) or n.endswith((".a", ".b")) for n in names) and sum("NNets" in n for n in names) == 36
+
+
+def test_optimizer_groups_follow_main_py():
+    from tgp.pytorch_amd.flow import instance_flow
+    from tgp.pytorch_amd.flows import SAL
+    from tgp.pytorch_amd.trainers import Trainer_SP_regression
+    idf = instance_flow(SAL(3, input_dependent=True, input_dim=4, num_hidden_layers=2, dropout=0.25, hidden_dim=50,
+                            hidden_activation="relu", inference="MC_dropout"))
+    idf.turn_off_initializer_parameters()
+    model = build(idf)
+    tr = Trainer_SP_regression(model, [[], None, None], 1e20, False, False, torch.ones(1), -1, 100, True)
+    sched = [[0.01, n] for n, _ in model.named_parameters() if "G_matrix" in n and "NNets" not in n]
+    sched.append([0.01, 1e-5, "NNets"])
+    groups = tr._param_groups(sched, 0.01)
+    wd = {g["weight_decay"]: len(g["params"]) for g in groups}
+    assert wd[1e-5] == 36                                   # 6 MLPs x 3 layers x (weight, bias)
+    assert sum(len(g["params"]) for g in groups) == len(list(model.parameters()))
+    with pytest.raises(ValueError):
+        tr._param_groups([[0.01, "NNets"], [0.01, 1e-5, "NNets"]], 0.01)
+
+
+def test_device_loader_protocol_and_normalisation():
+    from tgp.pytorch_amd.data import return_dataset
+    loaders, dc = return_dataset("synthetic_power", 10000, seed=1, options={"shuffle_train": True})
+    assert dc["N_tr"] == 8611 and dc["Dx"] == 4 and dc["X_te"].shape[0] == 957
+    (x, y), = list(loaders[0])                              # full batch: one step per epoch (main.py:74)
+    assert x.shape == (8611, 4) and y.shape == (8611, 1) and len(loaders[0]) == 1
+    assert abs(float(x.mean())) < 1e-12 and abs(float(y.std()) - 1.0) < 1e-9
+    small, _ = return_dataset("synthetic_boston", 100, seed=2)
+    assert sum(b[0].shape[0] for b in small[0]) == 455 and len(small[0]) == 5
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from tgp.pytorch_amd import lib as L
+    m = build(None)
+    with pytest.raises(L.TgpError):
+        m.ELBO(torch.randn(5, 4), torch.randn(5, 1))

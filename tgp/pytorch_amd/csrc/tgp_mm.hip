@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
+    // Diagonal tiles: the MFMA result (a_i vbar) . a_j is not bitwise equal to (a_j vbar) . a_i, so keep the lower
+    // half and mirror it -- G is then exactly symmetric and no element has two writers (run-to-run reproducible).
+    if (ti == tj && col > row) return;
     double* G = ws + p.Gp + (size_t)part * p.MP * p.MP;
     G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col] = s;
     G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row] = s;

@@ -21,6 +21,24 @@ from . import ops
 ORDER = ("Z", "raw_ls", "raw_os", "m", "Lam", "lvn", "theta")
 
 
+def allreduce_flat(grad, n, world_size, group=None):
+    """The ONE exchange of the data-parallel step: all-reduce(sum) of [gradients(n) | ELBO, ELL, KL, 0].
+    Every rank enters with gradients of (ELL_shard - KL/world) and out = [ELL_shard - KL, ELL_shard, KL, 0]; KL is
+    identical on all ranks, so it is pre-divided and the sum restores it; ELBO is rebuilt from the reduced parts.
+    Works on any backend (RCCL on the GPUs, gloo in the CPU tests)."""
+    if world_size > 1:
+        out = grad[n:n + 4]
+        out[2].div_(world_size)
+        torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=group)
+        out[0] = out[1] - out[2]
+    return grad
+
+
+def shard_rows(N, world_size, rank):
+    """Contiguous row shard [lo, hi) of rank `rank`."""
+    return (N * rank) // world_size, (N * (rank + 1)) // world_size
+
+
 class FlatParams:
     """[Z | raw_ls | raw_os | m | Lam | lvn | theta] as views of one buffer (plus same-shaped grads/moments)."""
 
@@ -109,11 +127,7 @@ class ElboEngine:
         self._warm = True
 
     def allreduce(self):
-        if self.world_size > 1:
-            # out[2] (KL) is identical on every rank: pre-divide so the sum restores it; ELBO is rebuilt after
-            self.fp.out[2].div_(self.world_size)
-            torch.distributed.all_reduce(self.fp.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            self.fp.out[0] = self.fp.out[1] - self.fp.out[2]
+        allreduce_flat(self.fp.grad, self.fp.n, self.world_size, self.pg)
 
     def adam(self):
         rc = self.lib.tgp_adam_dev_f64(L.ptr(self.fp.data), L.ptr(self.fp.grad), L.ptr(self.fp.exp_avg),

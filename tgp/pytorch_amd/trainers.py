@@ -1,0 +1,145 @@
+"""Trainer with the reference's constructor/`train`/`compute_metrics` surface
+(code/dsp/trainers/trainer_base.py:250-391, trainers_regression.py:30-338).
+
+Per minibatch: model.set_is_training(True) -> loss = -ELBO -> zero_grad -> backward -> optimizer.step()
+(trainer_base.py:334-345), Adam lr as given, `optimisation_schedule` = (percentages, specifications) with
+specifications entries [lr, name_substring] or [lr, weight_decay, name_substring] (main.py:274-298 puts the
+'NNets' weights in a weight-decay group).  Data stay wherever the loader yields them; use data.DeviceLoader
+to keep the split resident in HBM (removes the reference's per-step H2D copy and per-row collation).
+`inference_in_cpu` is accepted for signature compatibility and ignored: metrics are computed on the GPU.
+"""
+import time
+from collections import OrderedDict
+
+import numpy
+import torch
+
+from . import config as cg
+
+
+def return_optimizer(opt, parameters, lr):
+    """dsp/trainers/optimizers.py:10-22."""
+    if opt == "adam":
+        return torch.optim.Adam(parameters, lr, amsgrad=False)
+    if opt == "adam_W":
+        return torch.optim.AdamW(parameters, lr, amsgrad=False)
+    if opt == "sgd":
+        return torch.optim.SGD(parameters, lr)
+    raise ValueError("opt must be adam, adam_W or sgd")
+
+
+class Trainer_SP_regression:
+    def __init__(self, model, data_loaders, validate_each, plot, track, Y_std, plot_each, S_test,
+                 inference_in_cpu=False):
+        self.model = model
+        self.train_loader, self.valid_loader, self.test_loader = (list(data_loaders) + [None, None])[:3]
+        self.is_valid, self.is_test = self.valid_loader is not None, self.test_loader is not None
+        self.num_outputs = model.out_dim
+        self.validate_each = validate_each
+        self.S_test = S_test
+        self.inference_in_cpu = inference_in_cpu
+        assert len(Y_std.shape) == 1 and Y_std.shape[0] == self.num_outputs
+        self.Y_std = Y_std
+        self.optimizer = None
+        self.loss_arr, self.ELL_arr, self.KLD_arr = [], [], []
+        self.total_trainer_epochs = 0
+
+    # ---- optimiser groups (trainer_base.py:106-248) ---------------------------------------------------
+    def _param_groups(self, specs, lr_all):
+        named = OrderedDict(self.model.named_parameters())
+        taken, groups = set(), []
+        for sp in (specs or []):
+            if len(sp) == 3:
+                lr, wd, key = sp
+            elif len(sp) == 2:
+                (lr, key), wd = sp, 0.0
+            else:
+                raise ValueError("Parameters should be specified as [lr, param] or [lr, weight_decay, param]")
+            names = [n for n in named if key in n]
+            for n in names:
+                if n in taken:
+                    raise ValueError("Got repeated parameter {}".format(n))
+            taken.update(names)
+            if lr != 0.0 and names:
+                for g in groups:
+                    if g["lr"] == lr and g["weight_decay"] == wd:
+                        g["params"] += [named[n] for n in names]
+                        break
+                else:
+                    groups.append({"params": [named[n] for n in names], "lr": lr, "weight_decay": wd})
+        rest = [p for n, p in named.items() if n not in taken]
+        if rest:
+            groups.append({"params": rest, "lr": lr_all, "weight_decay": 0.0})
+        return groups
+
+    def ELBO_call(self, x, y):
+        loss, elogl, kld = self.model.ELBO(x, y)
+        loss = -loss
+        self.param_elbo = [loss, elogl, kld]
+        return loss
+
+    def train(self, epochs, lr_ALL, opt, keep_parameter_groups, lr_groups=None, optimisation_schedule=None):
+        if optimisation_schedule is None:
+            optimisation_schedule = ([1.0], [None])
+        percentages, specifications = optimisation_schedule
+        if abs(sum(percentages) - 1.0) > 1e-12:
+            raise ValueError("percentages must sum 1, got {}".format(sum(percentages)))
+        for per, specs in zip(percentages, specifications):
+            groups = self._param_groups(specs, lr_ALL)
+            if self.optimizer is None or not keep_parameter_groups:
+                self.optimizer = return_optimizer(opt, groups, lr_ALL)
+            for ep in range(int(epochs * per)):
+                t0 = time.time()
+                acc = [0.0, 0.0, 0.0]
+                nb = 0
+                for x, y in self.train_loader:
+                    x, y = x.to(cg.device), y.to(cg.device)
+                    assert x.dim() == 2 and y.dim() == 2, "x and y must be (MB,D) and (MB,D')"
+                    self.model.set_is_training(True)
+                    loss = self.ELBO_call(x, y)
+                    self.optimizer.zero_grad()
+                    loss.backward()
+                    self.optimizer.step()
+                    self.model.set_is_training(False)
+                    lv = loss.item()
+                    self.loss_arr.append(lv)
+                    self.ELL_arr.append(self.param_elbo[1].item())
+                    self.KLD_arr.append(self.param_elbo[2].item())
+                    acc[0] += -lv
+                    acc[1] += self.ELL_arr[-1]
+                    acc[2] += self.KLD_arr[-1]
+                    nb += 1
+                self.total_trainer_epochs += 1
+                if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
+                    print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
+                        ep + 1, epochs, acc[0] / nb, acc[1] / nb, acc[2] / nb, time.time() - t0))
+        if not keep_parameter_groups:
+            self.optimizer = None
+
+    # ---- metrics (trainers_regression.py:108-224, 317-338) ----------------------------------------------
+    def performance_metrics(self, X, Y):
+        self.model.set_is_training(False)
+        logp, (m1, _m2) = self.model.test_log_likelihood(X, Y, return_moments=True, Y_std=self.Y_std.to(X.device),
+                                                         S_MC_NNet=self.S_test if self.model.fully_bayesian else None)
+        samples, _, _ = self.model.sample_from_predictive_distribution(X, S=self.S_test)      # (Dy,S,N,1)
+        q = numpy.quantile(samples.to("cpu").numpy(), [0.025, 0.975], axis=1)                  # (2,Dy,N,1)
+        y = Y[:, 0].to("cpu")
+        cover = ((y >= torch.tensor(q[0, 0, :, 0])) & (y <= torch.tensor(q[1, 0, :, 0]))).float().sum().item()
+        se = ((m1.reshape(-1) - Y[:, 0]) ** 2).sum().item()
+        return float(logp.reshape(-1)[0]), se, cover
+
+    def _loader_metrics(self, loader):
+        tot, lp, se, cov = 0.0, 0.0, 0.0, 0.0
+        for x, y in loader:
+            x, y = x.to(cg.device), y.to(cg.device)
+            a, b, c = self.performance_metrics(x, y)
+            lp, se, cov, tot = lp + a, se + b, cov + c, tot + x.size(0)
+        ystd = float(self.Y_std.reshape(-1)[0])
+        return lp / tot, ystd * numpy.sqrt(se / tot), cov / tot
+
+    def compute_metrics(self):
+        """(logL, rmse, coverage) for train, valid, test -- nine floats like the reference."""
+        out = list(self._loader_metrics(self.train_loader))
+        out += list(self._loader_metrics(self.valid_loader)) if self.is_valid else [0.0, 0.0, 0.0]
+        out += list(self._loader_metrics(self.test_loader)) if self.is_test else [0.0, 0.0, 0.0]
+        return tuple(out)
