@@ -328,3 +328,31 @@ def test_predictive_sampling_shapes_and_moments():
     m1, m2, _, _ = model.predictive_distribution(X)
     err = (samples.mean(1).reshape(-1) - m1.reshape(-1)).abs() / m2.reshape(-1).sqrt()
     assert float(err.max()) < 0.35                    # |mean of 400 draws - m1| within ~7 standard errors
+
+
+def test_flow_initialiser_runs_on_the_hip_kernels():
+    """initializers.find_forward_params (code/dsp/initializers/initializers.py:29-109): MSE and its gradient come from
+    the 1-node quadrature kernel; check them against autograd of the oracle flow, and that Adam drives the
+    StepTanhL flow towards the identity map."""
+    from tgp.pytorch_amd.flow import compile_flow, instance_flow
+    from tgp.pytorch_amd.flows import StepTanhL
+    from tgp.pytorch_amd.initializers import find_forward_params, flow_mse_and_grads
+    np.random.seed(0)
+    flow = instance_flow(StepTanhL(3, 2, add_f0=True))
+    x = torch.linspace(-3, 3, 500, dtype=torch.float64)
+    mse, grads, theta_list = flow_mse_and_grads(flow, x.to(DEV), x.to(DEV))
+    spec = compile_flow(flow)[0]
+    th = torch.stack([p.detach().reshape(()) for p in theta_list]).clone().requires_grad_(True)
+    ref = ((orc.flow_forward(x, spec.blocks, th) - x) ** 2).mean()
+    ref.backward()
+    assert rel_err(mse.cpu(), ref.detach()) < 1e-10
+    assert rel_err(torch.stack([g.reshape(()) for g in grads]).cpu(), th.grad) < 1e-9
+
+    def fn():
+        np.random.seed(1)
+        return instance_flow(StepTanhL(3, 2, add_f0=True))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fitted, curve = find_forward_params(x.numpy(), x.numpy().copy(), fn, num_restarts=1, num_epochs=300)
+    assert curve[-1] < 0.05 * curve[0]

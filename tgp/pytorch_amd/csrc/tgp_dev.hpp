@@ -179,8 +179,7 @@ struct FlowDev {
 // asinh exactly as the reference writes it (flow.py:904-905)
 __device__ __forceinline__ double asinh_ref(double f) { return log(f + sqrt(f * f + 1.0)); }
 
-// Forward through all blocks.  If stack != nullptr the input of block b is stored at stack[b*sstride]
-// (needed by flow_backward).  If dG != nullptr it receives dG/df.
+// Forward through all blocks (evaluation / prediction).  If dG != nullptr it receives dG/df.
 __device__ inline double flow_forward(const FlowDev& F, double f, const double* __restrict__ rp, double* stack,
                                       int sstride, double* dG) {
   double der = 1.0;
@@ -220,62 +219,6 @@ __device__ inline double flow_forward(const FlowDev& F, double f, const double* 
   }
   if (dG) *dG = der;
   return f;
-}
-
-// Reverse sweep for one node: `c` = d(objective)/dG on entry; returns d(objective)/df0.
-// Parameter partials are accumulated into lane-private LDS slots acc[slot*astride] (slot = poff+j for
-// shared parameters, P+poff+j for per-row ones).
-__device__ inline double flow_backward(const FlowDev& F, double c, const double* __restrict__ rp, const double* stack,
-                                       int sstride, double* acc, int astride, int P) {
-  for (int b = F.nblk - 1; b >= 0; --b) {
-    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
-    const bool pr = flags & TGP_FLAG_PER_ROW;
-    const int s0 = pr ? P + poff : poff;
-    const double f = stack[b * sstride];
-    if (kind == TGP_FLOW_AFFINE) {
-      double a, fa;
-      if (pr) {
-        a = rp[poff]; fa = 1.0;
-        if (flags & TGP_FLAG_RESTRICT) { fa = sigmoid_d(a); a = softplus_d(a); }
-      } else {
-        a = F.tp[poff]; fa = F.tg[poff];
-      }
-      acc[(s0 + 0) * astride] += c * f * fa;
-      acc[(s0 + 1) * astride] += c;
-      c *= a;
-    } else if (kind == TGP_FLOW_SAL) {
-      double a, bb, fb;
-      if (pr) {
-        a = rp[poff]; bb = rp[poff + 1]; fb = 1.0;
-        if (flags & TGP_FLAG_RESTRICT) { fb = sigmoid_d(bb); bb = softplus_d(bb); }
-      } else {
-        a = F.tp[poff]; bb = F.tp[poff + 1]; fb = F.tg[poff + 1];
-      }
-      const double u = asinh_ref(f);
-      const double ch = cosh(bb * u - a);
-      acc[(s0 + 0) * astride] -= c * ch;
-      acc[(s0 + 1) * astride] += c * u * ch * fb;
-      double gp = bb * ch / sqrt(1.0 + f * f);
-      if (flags & TGP_FLAG_ADD_F0) gp += 1.0;
-      c *= gp;
-    } else {
-      double gp = (flags & TGP_FLAG_ADD_F0) ? 1.0 : 0.0;
-      for (int k = 0; k < K; ++k) {
-        const int o = poff + 4 * k;
-        const double bt = F.tp[o + 1], cc = F.tp[o + 2], dt = F.tp[o + 3];
-        const double t = (f - cc) / dt;
-        const double th = tanh(t);
-        const double se = bt * (1.0 - th * th) / dt;  // d/df of this step
-        acc[(o + 0) * astride] += c;
-        acc[(o + 1) * astride] += c * th * F.tg[o + 1];
-        acc[(o + 2) * astride] -= c * se;
-        acc[(o + 3) * astride] -= c * se * t * F.tg[o + 3];
-        gp += se;
-      }
-      c *= gp;
-    }
-  }
-  return c;
 }
 
 // ---------------------------------------------------------------------------------------------------

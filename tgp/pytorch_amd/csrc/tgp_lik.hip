@@ -87,49 +87,54 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
                                                    double* __restrict__ g_rowp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x, P = md.P, RP = md.RP, nblk = md.nblk;
-  double* stack = sm;                                    // nblk * 256
-  double* acc = stack + (size_t)(nblk > 0 ? nblk : 1) * 256;  // (P+RP) * 256
-  double* red = acc + (size_t)(P + RP > 0 ? P + RP : 1) * 256;  // 16
-  double* tp = red + 16;                                 // P+2
-  double* tg = tp + (P + 2) / 2 * 2;                     // P+2
-  for (int i = tid; i < (P + RP) * 256; i += 256) acc[i] = 0.0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = md.P, RP = md.RP;
+  double* stack = sm;                                                 // nslots * 256
+  double* accq = stack + (size_t)(fp.nslots > 0 ? fp.nslots : 1) * 256;  // P * 64 (shared parameters, quad-reduced)
+  double* accr = accq + (size_t)(P > 0 ? P : 1) * 64;                 // RP * 256 (per-row parameters, lane-private)
+  double* red = accr + (size_t)RP * 256;                              // 16
+  double* tp = red + 16;                                              // P+2
+  double* tg = tp + (P + 2) / 2 * 2;                                  // P+2
+  for (int i = tid; i < P * 64 + RP * 256; i += 256) accq[i] = 0.0;
   flow_params_lds(md, fp, tp, tg);
   const int n = blockIdx.x * 256 + tid;
+  const bool valid = n < md.N;
+  const int nc = valid ? n : md.N - 1;
   const double eta = md.log_var_noise[0], einv = exp(-eta);
-  FlowDev F{fp.blk, nblk, tp, tg};
-  double ellp = 0.0, etap = 0.0;
-  if (n < md.N) {
-    const double m_ = mu[n], sq = sqrt(2.0 * v[n]), y = Y[n];
-    const double* rp = rowp ? rowp + (size_t)n * RP : nullptr;
-    double cm = 0.0, cv = 0.0;
-    for (int s = 0; s < md.S; ++s) {
-      const double xsn = md.xs[s], wsn = md.wn[s];
-      const double g = flow_forward(F, m_ + sq * xsn, rp, stack + tid, 256, nullptr);
-      const double r = y - g;
-      ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
-      etap += wsn * (-0.5 + 0.5 * einv * r * r);
-      const double c0 = flow_backward(F, md.scale * einv * wsn * r, rp, stack + tid, 256, acc + tid, 256, P);
-      cm += c0;
-      cv += c0 * xsn;
-    }
+  FlowDev F{fp.blk, fp.nblk, tp, tg};
+  double ellp = 0.0, etap = 0.0, cm = 0.0, cv = 0.0;
+  const double m_ = mu[nc], sq = sqrt(2.0 * v[nc]), y = Y[nc];
+  const double* rp = rowp ? rowp + (size_t)nc * RP : nullptr;
+  // every lane runs all S nodes (the reverse sweep sums shared-parameter partials across the 4 lanes of a quad;
+  // here those are 4 different rows, which is what the total over rows needs); padding rows carry weight 0
+  for (int s = 0; s < md.S; ++s) {
+    const double xsn = md.xs[s], wsn = valid ? md.wn[s] : 0.0;
+    double f[1] = {m_ + sq * xsn}, c[1];
+    flow_forward_store<1>(F, f, rp, stack + tid, 256);
+    const double r = y - f[0];
+    ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+    etap += wsn * (-0.5 + 0.5 * einv * r * r);
+    c[0] = md.scale * einv * wsn * r;
+    flow_backward_store<1>(F, c, rp, stack + tid, 256, fp.nslots, accq + wave * 16 + (lane & 15), 64, (lane >> 4) == 0,
+                           accr + tid, 256);
+    cm += c[0];
+    cv += c[0] * xsn;
+  }
+  if (valid) {
     if (g_mu) g_mu[n] = cm;
     if (g_v) g_v[n] = cv / sq;
     if (g_rowp)
-      for (int j = 0; j < RP; ++j) g_rowp[(size_t)n * RP + j] = acc[(size_t)(P + j) * 256 + tid];
+      for (int j = 0; j < RP; ++j) g_rowp[(size_t)n * RP + j] = accr[(size_t)j * 256 + tid];
   }
   ellp = wave_sum(ellp); etap = wave_sum(etap);
-  if ((tid & 63) == 0) { red[tid >> 6] = ellp; red[4 + (tid >> 6)] = etap; }
+  if (lane == 0) { red[wave] = ellp; red[4 + wave] = etap; }
   __syncthreads();
   double* pb = part + (size_t)blockIdx.x * (2 + P);
   if (tid == 0) {
     pb[0] = md.scale * (red[0] + red[1] + red[2] + red[3]);
     pb[1] = md.scale * (red[4] + red[5] + red[6] + red[7]);
   }
-  const int wave = tid >> 6, lane = tid & 63;
   for (int j = wave; j < P; j += 4) {
-    double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
-    s = wave_sum(s);
+    const double s = wave_sum(accq[j * 64 + lane]);
     if (lane == 0) pb[2 + j] = s;
   }
 }
@@ -265,8 +270,8 @@ int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, 
   return 0;
 }
 
-static int flow_lds(const tgp_model& md, size_t* bytes) {
-  const size_t d = (size_t)(md.nblk > 0 ? md.nblk : 1) * 256 + (size_t)(md.P + md.RP > 0 ? md.P + md.RP : 1) * 256 + 16 +
+static int flow_lds(const tgp_model& md, int nslots, size_t* bytes) {
+  const size_t d = (size_t)(nslots > 0 ? nslots : 1) * 256 + (size_t)(md.P > 0 ? md.P : 1) * 64 + (size_t)md.RP * 256 + 16 +
                    2 * (size_t)(md.P + 2);
   *bytes = d * sizeof(double);
   return *bytes > 160 * 1024 - 1024 ? TGP_E_LDS : 0;
@@ -276,7 +281,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st) {
   size_t lds;
-  if (int rc = flow_lds(md, &lds)) return rc;
+  if (int rc = flow_lds(md, fp.nslots, &lds)) return rc;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
   const int nb = (md.N + 255) / 256;

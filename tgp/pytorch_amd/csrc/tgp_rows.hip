@@ -22,7 +22,7 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
     lds = row_lds(p, 1, fp.nslots).total * sizeof(double);
     if (lds > lim) {
       mode = 2;
-      lds = row_lds(p, 2, 0).total * sizeof(double);
+      lds = row_lds(p, 2, fp.nslots).total * sizeof(double);
     }
   }
   if (lds > lim) return TGP_E_LDS;

@@ -40,8 +40,8 @@ struct RowLds {
   size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, xs, wn, stack, acc, red, prog, total;
 };
 
-// mode: 0 = moments only, 1 = training, flow in "store" mode (2 nodes in flight), 2 = training, flow recomputed in
-// the reverse sweep (fallback when the store-mode stack does not fit in LDS); nslots = flow_slots(program)
+// mode: 0 = moments only; 1 = training, TGP_NODES_IN_FLIGHT quadrature nodes in flight per lane; 2 = training, one
+// node in flight (fallback when the 4-node stack of a long flow does not fit in LDS); nslots = flow_slots(program)
 __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
   const bool train = mode != 0;
   RowLds L;
@@ -61,17 +61,13 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
     L.xt = take((size_t)TGP_ROWS_PER_BLOCK * p.CT16);
     L.vbs = take(TGP_ROWS_PER_BLOCK);
     L.mbs = take(TGP_ROWS_PER_BLOCK);
-    if (mode == 1) {
-      // store-mode stack (TGP_NODES_IN_FLIGHT nodes per lane) shares its space with the transposition tile / the
-      // operand panels: the flow phase runs strictly between GEMM 2 and GEMM 3
-      const size_t st = (size_t)(nslots > 0 ? nslots : 1) * TGP_NODES_IN_FLIGHT * 256;
-      if (st > (size_t)p.MP * TGP_TILE_LD) take(st - (size_t)p.MP * TGP_TILE_LD);
-      L.stack = L.tile;
-      L.acc = take((size_t)(p.P > 0 ? p.P : 1) * 64 + (size_t)p.RP * 256);  // [P][64] quad-reduced + [RP][256] per lane
-    } else {
-      L.stack = take((size_t)(p.nblk > 0 ? p.nblk : 1) * 256);
-      L.acc = take((size_t)(p.P + p.RP > 0 ? p.P + p.RP : 1) * 256);
-    }
+    // the flow stack (nodes-in-flight x slots x 256 lanes) shares its space with the transposition tile / the operand
+    // panels: the flow phase runs strictly between GEMM 2 and GEMM 3
+    // (tile, xt, vbs, mbs are contiguous and all dead during the flow phase: the stack may cover all of them)
+    const size_t st = (size_t)(nslots > 0 ? nslots : 1) * (mode == 1 ? TGP_NODES_IN_FLIGHT : 1) * 256;
+    if (L.tile + st > o) take(L.tile + st - o);
+    L.stack = L.tile;
+    L.acc = take((size_t)(p.P > 0 ? p.P : 1) * 64 + (size_t)p.RP * 256);  // [P][64] quad-reduced + [RP][256] per lane
   } else {
     L.tile = take((size_t)p.MP * 32);  // only the two operand panels (2 x MP x 16)
     L.xt = L.vbs = L.mbs = L.stack = L.acc = o;
@@ -148,7 +144,7 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
   }
   if (TRAIN) {
-    const int nacc = MODE == 1 ? P * 64 + RP * 256 : (P + RP) * 256;
+    const int nacc = P * 64 + RP * 256;
     for (int i = tid; i < nacc; i += 256) acc[i] = 0.0;
   }
   __syncthreads();
@@ -280,10 +276,10 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     const double sq = sqrt(2.0 * v);
     const double* rp = a.rowp != nullptr ? a.rowp + (size_t)nc * RP : nullptr;
     double cm = 0.0, cv = 0.0;
-    if (MODE == 1) {
+    {
       // NB nodes in flight per lane (independent dependency chains); every lane runs the same trip count
       // (cross-lane sums inside the reverse sweep), out-of-range nodes and padding rows carry weight 0
-      constexpr int NB = TGP_NODES_IN_FLIGHT;
+      constexpr int NB = MODE == 1 ? TGP_NODES_IN_FLIGHT : 1;
       double* accq = acc + wave * 16 + nl;
       double* accr = acc + (size_t)P * 64 + tid;
       const int ntrip = (p.S + 4 * NB - 1) / (4 * NB);
@@ -311,17 +307,6 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
           cm += c[u];
           cv += c[u] * xn[u];
         }
-      }
-    } else if (valid) {
-      for (int s = q; s < p.S; s += 4) {
-        const double xsn = xsL[s], wsn = wnL[s];
-        const double g = flow_forward(F, mu + sq * xsn, rp, stack + tid, 256, nullptr);
-        const double r = y - g;
-        ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
-        etap += wsn * (-0.5 + 0.5 * einv * r * r);
-        const double c0 = flow_backward(F, a.scale * einv * wsn * r, rp, stack + tid, 256, acc + tid, 256, P);
-        cm += c0;
-        cv += c0 * xsn;
       }
     }
     mub = quad_sum(cm);
@@ -457,22 +442,14 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     slab[p.slab_C + C_SVB] = red[2] + red[6] + red[10] + red[14];
     slab[p.slab_C + C_PAD] = 0.0;
   }
-  if (MODE == 1) {
-    for (int j = wave; j < P; j += 4) {
-      const double s = wave_sum(acc[j * 64 + lane]);
-      if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
-    }
-  } else {
-    for (int j = wave; j < P; j += 4) {
-      double s = acc[j * 256 + lane] + acc[j * 256 + 64 + lane] + acc[j * 256 + 128 + lane] + acc[j * 256 + 192 + lane];
-      s = wave_sum(s);
-      if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
-    }
+  for (int j = wave; j < P; j += 4) {
+    const double s = wave_sum(acc[j * 64 + lane]);
+    if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
   }
   TGP_STAMP(a.ws, p, 10);
   for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
   if (a.g_rowp != nullptr && q == 0 && valid) {
-    const double* rbase = MODE == 1 ? acc + (size_t)P * 64 : acc + (size_t)P * 256;
+    const double* rbase = acc + (size_t)P * 64;
     for (int jr = 0; jr < RP; ++jr) {
       const double* ap = rbase + (size_t)jr * 256 + wave * 64 + nl;
       a.g_rowp[(size_t)n * RP + jr] = ap[0] + ap[16] + ap[32] + ap[48];
