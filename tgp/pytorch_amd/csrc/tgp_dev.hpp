@@ -44,6 +44,7 @@ struct Plan {
   int N, D, M, S, nblk, P, RP, lik;
   int MT, MP, DP, CT, CT16, ntri, nblocks;
   int nslots;  // store-mode flow stack slots
+  int zs_lds;  // k_prep_a keeps Zs in LDS (set by the launcher from the LDS budget)
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
   // workspace offsets (doubles)
   size_t hdr, ils, ls, Zs, mpad, w, tp, tg;
@@ -66,7 +67,7 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
-  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik; p.nslots = 0;
+  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik; p.nslots = 0; p.zs_lds = 0;
   p.MT = (M + 15) / 16; p.MP = p.MT * 16;
   p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
   p.CT = (2 * p.DP + 1 + 15) / 16; p.CT16 = p.CT * 16;
@@ -104,6 +105,37 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }  // F.softplus, threshold 20
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// exp(x) with a SHORT dependency chain.  A dependent f64 FMA costs ~32 cycles on gfx950 (measured,
+// scratch/mfma_rate.hip) and the row kernel runs one wave per SIMD, so the ~25-deep chain of the library exp is
+// what the K tiles and the flow quadrature were waiting on.  Cody-Waite reduction x = k ln2 + r, |r| <= 0.347,
+// degree-13 Taylor polynomial evaluated by Estrin's scheme (depth 4), scaled by v_ldexp_f64.
+// Truncation r^14/14! < 5e-18; total error a few ulp.  Arguments are clamped to the finite range.
+__device__ __forceinline__ double exp_fast(double x) {
+  x = fmin(fmax(x, -745.0), 709.0);
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+  const double p01 = 1.0 + r;
+  const double p23 = fma(r, 1.0 / 6.0, 0.5);
+  const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+  const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
+  const double pab = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+  const double pcd = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+  const double q0 = fma(p23, r2, p01), q1 = fma(p67, r2, p45), q2 = fma(pab, r2, p89);
+  const double s0 = fma(q1, r4, q0), s1 = fma(pcd, r4, q2);
+  return ldexp(fma(s1, r8, s0), (int)k);
+}
+
+// 1/x from v_rcp_f64 + two Newton steps (no v_div_scale / v_div_fixup: operands here are finite, normal, non-zero)
+__device__ __forceinline__ double rcp_fast(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
@@ -145,6 +177,9 @@ __device__ __forceinline__ d4 tile_mm_f(FA fa, FB fb, int k0, int k1, d4 acc) {
     for (int u = 0; u < 8; ++u) { a[u] = fa(k + 4 * u); b[u] = fb(k + 4 * u); }
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc = TGP_MFMA(a[u], b[u], acc);
+    // pin the batch shape: every load (LDS or global) of the batch before its 8 MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100 | 0x020, 24, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
   }
   for (; k + 16 <= k1; k += 16) {
     double a[4], b[4];
@@ -261,9 +296,9 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       for (int u = 0; u < NB; ++u) {
         const double sf = sqrt(f[u] * f[u] + 1.0);
         const double uu = log(f[u] + sf);  // flow.py:904-905
-        const double e = exp(bb * uu - a), ei = 1.0 / e;
+        const double e = exp_fast(bb * uu - a), ei = rcp_fast(e);
         const double ch = 0.5 * (e + ei);
-        double g = 0.5 * (e - ei), gp = bb * ch / sf;
+        double g = 0.5 * (e - ei), gp = bb * ch * rcp_fast(sf);
         if (addf) { g += f[u]; gp += 1.0; }
         stack[((sl + 0) * NB + u) * sstride] = uu;
         stack[((sl + 1) * NB + u) * sstride] = ch;
@@ -281,10 +316,10 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       }
       for (int k = 0; k < K; ++k) {
         const double a = F.tp[poff + 4 * k], bt = F.tp[poff + 4 * k + 1], c = F.tp[poff + 4 * k + 2],
-                     idt = 1.0 / F.tp[poff + 4 * k + 3];
+                     idt = rcp_fast(F.tp[poff + 4 * k + 3]);
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-          const double th = 1.0 - 2.0 / (exp(2.0 * (f[u] - c) * idt) + 1.0);
+          const double th = 1.0 - 2.0 * rcp_fast(exp_fast(2.0 * (f[u] - c) * idt) + 1.0);
           stack[((sl + 1 + k) * NB + u) * sstride] = th;
           g[u] += a + bt * th;
         }
@@ -366,7 +401,7 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
       }
       for (int k = 0; k < K; ++k) {
         const int o = poff + 4 * k;
-        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = 1.0 / F.tp[o + 3];
+        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = rcp_fast(F.tp[o + 3]);
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {

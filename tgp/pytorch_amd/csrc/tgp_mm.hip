@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
           const double tt = md.Z[(size_t)row * D + d] * il - md.Z[(size_t)col * D + d] * il;
           d2 += tt * tt;
         }
-        k = softplus_d(md.raw_os[0]) * exp(-0.5 * d2);
+        k = softplus_d(md.raw_os[0]) * exp_fast(-0.5 * d2);
       }
       ws[p.Lq + (size_t)row * MP + col] = lq;
       ws[p.LqT + (size_t)col * MP + row] = lq;
@@ -182,107 +182,146 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   const int LD = MP + 1;
   double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
   double* Dt = sm + (size_t)MP * LD;         // MT x 256: inverses of the diagonal tiles (row-major, zero above diag)
-  double* zs = Dt;                           // overlay: scaled inducing points, only needed to build K_MM
+  double* zs = Dt + (size_t)MT * 256;        // MP x DP scaled inducing points, present when p.zs_lds (LDS budget allows)
   __shared__ int s_info, s_nan;
   __shared__ double s_ils[16];
   if (tid == 0) { s_info = 0; s_nan = 0; }
   if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   __syncthreads();
   const double s2 = softplus_d(md.raw_os[0]);
-  for (int i = tid; i < MP * DP; i += PREP_THREADS) {
-    const int mrow = i / DP, d = i % DP;
-    zs[i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * s_ils[d] : 0.0;
+  const bool zl = p.zs_lds != 0;
+  if (zl) {
+    for (int i = tid; i < MP * DP; i += PREP_THREADS) {
+      const int mrow = i / DP, d = i % DP;
+      zs[i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * s_ils[d] : 0.0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  // lower triangle only (the factorisation never reads above the diagonal; the strict-upper TILES later receive
-  // J^T); one wave per row, lanes across columns: no integer division, conflict-free LDS rows
+  // K_MM element (lower triangle only: the factorisation never reads above the diagonal; the strict-upper TILES later
+  // receive J^T); identity on the padding keeps L and L^-1 well defined
   bool has_nan = false;
-  for (int rr = wave; rr < MP; rr += PREP_THREADS / 64) {
-    for (int cc = lane; cc <= rr; cc += 64) {
-      double k;
-      if (rr < M) {
-        double d2 = 0.0;
+  auto kmm_elem = [&](int rr, int cc) {
+    double k;
+    if (rr < M) {
+      double d2 = 0.0;
+      if (zl) {
         for (int d = 0; d < DP; ++d) {
           const double tt = zs[rr * DP + d] - zs[cc * DP + d];
           d2 += tt * tt;
         }
-        k = s2 * exp(-0.5 * d2);
-        has_nan |= (k != k);
-        if (rr == cc) k += md.jitter;
-      } else {
-        k = (rr == cc) ? 1.0 : 0.0;  // identity on the padding keeps L and L^-1 well defined
+      } else {  // M = 128 with D > 8: no LDS left next to A; read Z through L1/L2
+        for (int d = 0; d < D; ++d) {
+          const double tt = (md.Z[(size_t)rr * D + d] - md.Z[(size_t)cc * D + d]) * s_ils[d];
+          d2 += tt * tt;
+        }
       }
-      A[rr * LD + cc] = k;
+      k = s2 * exp_fast(-0.5 * d2);
+      has_nan |= (k != k);
+      if (rr == cc) k += md.jitter;
+    } else {
+      k = (rr == cc) ? 1.0 : 0.0;
     }
+    return k;
+  };
+  // left-looking tile: acc = sum_{k < kend} L[i-tile rows, k] * L[j-tile rows, k]   (both operands in LDS)
+  auto ll_sum = [&](int i0, int j0, int kend) {
+    d4 acc = {0, 0, 0, 0};
+    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, 0,
+                     kend, acc);
+  };
+  // panel tile (i, c): L_ic = (A_ic - sum_{k<c} L_ik L_ck^T) Dinv_c^T ; own tile, read fully before it is rewritten
+  auto panel_tile = [&](int i, int c) {
+    const int i0 = 16 * i, c0 = 16 * c;
+    const d4 upd = ll_sum(i0, c0, c0);
+    double av[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];   // updated A_ic, C/D layout
+    // (A_ic Dinv_c^T)[row][col] = sum_k A_ic[row][k] Dinv_c[col][k]: A-operand needs A_ic[row = r][k = 4s + q] -> go
+    // through the tile itself: write the updated tile back, then read it in A-operand layout (same wave only)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = av[rr];
+    __builtin_amdgcn_wave_barrier();
+    d4 acc = {0, 0, 0, 0};
+    double a4[4], b4[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(i0 + r) * LD + c0 + 4 * s4 + q]; b4[s4] = Dt[c * 256 + r * 16 + 4 * s4 + q]; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(a4[s4], b4[s4], acc);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = acc[rr];
+  };
+  // inverse tile (j, c), c < j:  J_jc = -Dinv_j sum_{c<=kb<j} L_j,kb J_kb,c   (stored transposed in the upper tile (c, j))
+  auto inv_tile = [&](int j, int c) {
+    const int j0 = 16 * j, c0 = 16 * c;
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; }, [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; },
+                    0, 16, acc);                                                       // kb == c: J_cc = Dinv_c
+    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
+                    c0 + 16, j0, acc);                                                 // kb > c: transposed upper tiles
+    double dj[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) dj[s4] = Dt[j * 256 + r * 16 + 4 * s4 + q];
+    d4 out = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) out = TGP_MFMA(dj[s4], acc[s4], out);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
+  };
+
+  // ---- blocked Cholesky + inverse with LOOKAHEAD, one barrier per block column --------------------------------------
+  // iteration j:  wave 0 (the critical chain)  : panel tile (j, j-1) of step j-1, diagonal update, potrf + trtri of tile j
+  //               waves 1..7 (off the chain)   : iteration 0: fill K_MM below tile (0,0);
+  //                                              iteration j >= 1: the other panel tiles (i > j, j-1) and the inverse
+  //                                              tiles (j-1, c < j-1) of step j-1
+  for (int j = 0; j <= MT; ++j) {
+    const int j0 = 16 * j;
+    if (wave == 0) {
+      if (j < MT) {
+        if (j == 0) {
+          for (int e = lane; e < 256; e += 64) {
+            const int rr = e >> 4, cc = e & 15;
+            if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
+          }
+          __builtin_amdgcn_wave_barrier();
+        } else {
+          panel_tile(j, j - 1);
+          __builtin_amdgcn_wave_barrier();
+          const d4 upd = ll_sum(j0, j0, j0);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
+          __builtin_amdgcn_wave_barrier();
+        }
+        double a[16], x[16];
+        const int li = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
+        const int bad = potrf_trtri16(a, x, li);
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
+            Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
+          }
+        }
+        if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
+      }
+    } else if (j == 0) {
+      for (int rr = 16 + (wave - 1); rr < MP; rr += PREP_THREADS / 64 - 1)
+        for (int cc = lane; cc <= rr; cc += 64) A[rr * LD + cc] = kmm_elem(rr, cc);
+    } else {
+      // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2  (at most MT-2 <= 6 tiles for 7 waves)
+      const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
+      for (int t = wave - 1; t < npanel + (j - 1); t += PREP_THREADS / 64 - 1) {
+        if (t < npanel) panel_tile(j + 1 + t, j - 1);
+        else inv_tile(j - 1, t - npanel);
+      }
+    }
+    __syncthreads();
+    PSTAMP(j < 4 ? j : 3);
   }
   if (has_nan) s_nan = 1;
   __syncthreads();
-  PSTAMP(0);
-
-  for (int j = 0; j < MT; ++j) {
-    const int j0 = 16 * j;
-    // phase 1: left-looking update of block column j:  A_ij -= sum_{kb<j} L_i,kb L_j,kb^T   (tiles i >= j)
-    if (j > 0) {
-      for (int i = j + wave; i < MT; i += PREP_THREADS / 64) {
-        const int i0 = 16 * i;
-        d4 acc = {0, 0, 0, 0};
-        acc = tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; },
-                        0, j0, acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + j0 + r] -= acc[rr];
-      }
-      __syncthreads();
-    }
-    PSTAMP(1);
-    // phase 2: wave 0 factors the diagonal tile and inverts it
-    if (wave == 0) {
-      double a[16], x[16];
-      const int li = lane & 15;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
-      const int bad = potrf_trtri16(a, x, li);
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
-          Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
-        }
-      }
-      if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
-    }
-    __syncthreads();
-    PSTAMP(2);
-    // phase 3: panel  L_ij = A_ij Dinv_j^T (i > j)  and row-block j of J = L^-1:  J_jc = -Dinv_j sum_{c<=kb<j} L_j,kb J_kb,c
-    for (int t = wave; t < MT - 1; t += PREP_THREADS / 64) {
-      if (t < MT - 1 - j) {
-        const int i0 = 16 * (j + 1 + t);
-        d4 acc = {0, 0, 0, 0};
-        acc = tile_mm_f([&](int k) { return A[(i0 + r) * LD + j0 + k + q]; },
-                        [&](int k) { return Dt[j * 256 + r * 16 + k + q]; }, 0, 16, acc);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + j0 + r] = acc[rr];
-      } else {
-        const int c = t - (MT - 1 - j), c0 = 16 * c;  // c in [0, j)
-        d4 acc = {0, 0, 0, 0};
-        // kb == c: J_cc = Dinv_c
-        acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; },
-                        [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; }, 0, 16, acc);
-        // kb > c: J_kb,c lives transposed in the upper tiles
-        acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
-                        c0 + 16, j0, acc);
-        d4 out = {0, 0, 0, 0};
-        double dj[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dj[s] = Dt[j * 256 + r * 16 + 4 * s + q];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) out = TGP_MFMA(dj[s], acc[s], out);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
-      }
-    }
-    __syncthreads();
-    PSTAMP(3);
-  }
   // ---- write L, J, J^T tile by tile (one wave per 16x16 tile, 128-byte row segments) ----
   for (int t = wave; t < MT * MT; t += PREP_THREADS / 64) {
     const int ti = t / MT, tj = t % MT;
@@ -320,8 +359,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 }
 
 size_t prep_a_lds_bytes(const Plan& p) {
-  size_t dt = (size_t)p.MT * 256, zs = (size_t)p.MP * p.DP;
-  return ((size_t)p.MP * (p.MP + 1) + (dt > zs ? dt : zs) + 16) * sizeof(double);
+  return ((size_t)p.MP * (p.MP + 1) + (size_t)p.MT * 256 + (p.zs_lds ? (size_t)p.MP * p.DP : 0) + 16) * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -697,8 +735,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_chol_only(const double* __rest
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-int launch_prepare(const Plan& p, const tgp_model& md, const FlowProg& fp, double* ws, int32_t* status,
+int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, double* ws, int32_t* status,
                    hipStream_t st) {
+  Plan p = p_in;
+  p.zs_lds = 1;
+  if (prep_a_lds_bytes(p) > 160 * 1024 - 1024) p.zs_lds = 0;
   const size_t lds = prep_a_lds_bytes(p);
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_prep_a), lds, &lds_cur)) return rc;

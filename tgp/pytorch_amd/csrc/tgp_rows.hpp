@@ -76,8 +76,37 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
   return L;
 }
 
+// One output tile of a triangular GEMM of the row kernel: NSTEPS k-steps (4 rows of the operand panel each) starting
+// at k-step `step0`.  `a0` = &panel[q*16 + nl] (k-step s is 64 doubles further), fb(s) = B operand of local step s.
+// Operands are read from LDS in batches of 8 BEFORE their MFMAs (left to itself hipcc emits ds_read -> wait -> mfma
+// one by one: ~120 cycles per MFMA instead of 64); two accumulator chains hide the dependent-issue latency.
+// (nsteps is a constant after the caller's tile loop is unrolled; MAXSTEPS bounds the unrolling.)
+template <int MAXSTEPS, class FB>
+__device__ __forceinline__ d4 mfma_chain(const double* a0, int step0, int nsteps, FB fb) {
+  d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+#pragma unroll
+  for (int s0 = 0; s0 < MAXSTEPS; s0 += 8) {
+    double av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < nsteps) av[u] = a0[(step0 + s0 + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (s0 + u < nsteps) {
+        if (u & 1) c2 = TGP_MFMA(av[u], fb(s0 + u), c2);
+        else c = TGP_MFMA(av[u], fb(s0 + u), c);
+      }
+    // pin the shape of this batch in the emitted code: all LDS reads first, then the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  }
+  return c + c2;
+}
+
+// One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
+// scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
 template <int MT, int DP, int MODE>
-__global__ __launch_bounds__(256) void k_rows(RowArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_rows(RowArgs a) {
   constexpr bool TRAIN = MODE != 0;
   constexpr int MP = MT * 16;
   constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
@@ -159,6 +188,42 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
 #pragma unroll
   for (int d = 0; d < DP; ++d) x[d] = d < D ? a.X[(size_t)nc * D + d] * ils[d] : 0.0;
 
+  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
+  //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
+  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out.
+  //      Panels are prefetched TWO ahead through two register sets (the early panels feed only 4-8 MFMAs, far less
+  //      than one L2 round trip), and the first two are requested before the K tile is computed.
+  const double* __restrict__ JT = ws + p.JT;
+  const double* __restrict__ Jm = ws + p.J;
+  const double* __restrict__ Lq = ws + p.Lq;
+  const double* __restrict__ LqT = ws + p.LqT;
+  double* pan = tile;  // 2 x (MP x 16)
+  double stg[2][MT];
+  // panel sequence of one phase: pp < MT -> lower-type panel pp of matrix M1 (rows [0, 16(pp+1)));
+  //                              pp >= MT -> upper-type panel pp-MT of matrix M2 (rows [16 (pp-MT), MP))
+  // (row-block u of a panel exists iff u < nb with nb = i+1 (lower) / MT-i (upper): a compile-time predicate once the
+  //  tile loops are unrolled -- a `row < r1` test would cost an exec-mask branch around every load and store)
+  auto issue = [&](const double* __restrict__ M1, const double* __restrict__ M2, int pp, double (&st)[MT]) {
+    const bool lower = pp < MT;
+    const int i = lower ? pp : pp - MT;
+    const double* __restrict__ Mt = (lower ? M1 : M2) + (size_t)((lower ? 0 : 16 * i) + (tid >> 4)) * MP + 16 * i + (tid & 15);
+    const int nb = lower ? i + 1 : MT - i;
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+      if (u < nb) st[u] = Mt[(size_t)16 * u * MP];
+  };
+  auto commit = [&](int pp, const double (&st)[MT]) {
+    const bool lower = pp < MT;
+    const int i = lower ? pp : pp - MT;
+    const int nb = lower ? i + 1 : MT - i;
+    double* buf = pan + (pp & 1) * (MP * 16) + ((lower ? 0 : 16 * i) + (tid >> 4)) * 16 + (tid & 15);
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+      if (u < nb) buf[16 * u * 16] = st[u];
+  };
+  issue(JT, Lq, 0, stg[0]);
+  if (MT * 2 > 1) issue(JT, Lq, 1, stg[1]);
+
   // ---- K tile in B-operand layout: Kr[ks] = K[m = 4 ks + q][row nl] ----
   double Kr[4 * MT];
 #pragma unroll
@@ -170,75 +235,29 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
       const double t = x[d] - zs[mm * DP + d];
       d2 += t * t;
     }
-    Kr[ks] = mm < M ? s2 * exp(-0.5 * d2) : 0.0;
+    Kr[ks] = mm < M ? s2 * exp_fast(-0.5 * d2) : 0.0;
   }
 
   TGP_STAMP(a.ws, p, 2);
-  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
-  //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
-  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out;
-  //      the global load of panel p+1 is in flight while panel p feeds the matrix pipe.
-  const double* __restrict__ JT = ws + p.JT;
-  const double* __restrict__ Jm = ws + p.J;
-  const double* __restrict__ Lq = ws + p.Lq;
-  const double* __restrict__ LqT = ws + p.LqT;
-  double* pan = tile;  // 2 x (MP x 16)
-  double stg[MT];
-  // lower-type panel i: rows [0, 16(i+1)); upper-type: rows [16 i, MP)
-  auto issue = [&](const double* __restrict__ Mt, int i, bool lower) {
-    const int r0 = lower ? 0 : 16 * i, r1 = lower ? 16 * (i + 1) : MP;
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      const int row = r0 + (tid >> 4) + 16 * u;
-      if (row < r1) stg[u] = Mt[(size_t)row * MP + 16 * i + (tid & 15)];
-    }
-  };
-  auto commit = [&](double* buf, int i, bool lower) {
-    const int r0 = lower ? 0 : 16 * i, r1 = lower ? 16 * (i + 1) : MP;
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      const int row = r0 + (tid >> 4) + 16 * u;
-      if (row < r1) buf[row * 16 + (tid & 15)] = stg[u];
-    }
-  };
-
   d4 Aa[MT], Ba[MT];
   // ---- A = J K : A_i = sum_{kb <= i} J[i,kb] K_kb  (A operand = rows of J^T) ----
-  issue(JT, 0, true);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    double* buf = pan + (i & 1) * (MP * 16);
-    commit(buf, i, true);
+    const double* buf = pan + (i & 1) * (MP * 16);
+    commit(i, stg[i & 1]);
     __syncthreads();
-    if (i + 1 < MT) issue(JT, i + 1, true);
-    else issue(Lq, 0, false);
-    // two independent accumulator chains: a single dependent chain of v_mfma_f64_16x16x4 issues at about half
-    // the rate of the matrix pipe (measured ~140 cycles per MFMA instead of 64)
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 4 * (i + 1); ks += 2) {
-      c = TGP_MFMA(buf[(4 * ks + q) * 16 + nl], Kr[ks], c);
-      c2 = TGP_MFMA(buf[(4 * ks + 4 + q) * 16 + nl], Kr[ks + 1], c2);
-    }
-    Aa[i] = c + c2;
+    if (i + 2 < 2 * MT) issue(JT, Lq, i + 2, stg[i & 1]);
+    Aa[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Kr[st]; });
   }
   TGP_STAMP(a.ws, p, 3);
   // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    double* buf = pan + ((MT + i) & 1) * (MP * 16);
-    commit(buf, i, false);
+    const double* buf = pan + ((MT + i) & 1) * (MP * 16);
+    commit(MT + i, stg[(MT + i) & 1]);
     __syncthreads();
-    if (i + 1 < MT) issue(Lq, i + 1, false);
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int kb = i; kb < MT; ++kb) {
-      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Aa[kb][0], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Aa[kb][1], c2);
-      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Aa[kb][2], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Aa[kb][3], c2);
-    }
-    Ba[i] = c + c2;
+    if (MT + i + 2 < 2 * MT) issue(JT, Lq, MT + i + 2, stg[(MT + i) & 1]);
+    Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Aa[i + st / 4][st % 4]; });
   }
   TGP_STAMP(a.ws, p, 4);
   // ---- mu, v ----
@@ -319,24 +338,16 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) Ba[i] *= vb;
   d4 Ca[MT];
-  __syncthreads();  // every wave is done with the forward panels before they are overwritten
-  issue(LqT, 0, true);
+  __syncthreads();  // every wave is done with the flow stack / forward panels before the region is overwritten
+  issue(LqT, Jm, 0, stg[0]);
+  issue(LqT, Jm, 1, stg[1]);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    double* buf = pan + (i & 1) * (MP * 16);
-    commit(buf, i, true);
+    const double* buf = pan + (i & 1) * (MP * 16);
+    commit(i, stg[i & 1]);
     __syncthreads();
-    if (i + 1 < MT) issue(LqT, i + 1, true);
-    else issue(Jm, 0, false);
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int kb = 0; kb <= i; ++kb) {
-      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Ba[kb][0], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Ba[kb][1], c2);
-      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Ba[kb][2], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Ba[kb][3], c2);
-    }
-    Ca[i] = c + c2;
+    if (i + 2 < 2 * MT) issue(LqT, Jm, i + 2, stg[i & 1]);
+    Ca[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Ba[st / 4][st % 4]; });
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -344,19 +355,11 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     for (int r = 0; r < 4; ++r) Ca[i][r] = mv[16 * i + 4 * r + q] * mub - 2.0 * Aa[i][r] * vb + 2.0 * Ca[i][r];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    double* buf = pan + ((MT + i) & 1) * (MP * 16);
-    commit(buf, i, false);
+    const double* buf = pan + ((MT + i) & 1) * (MP * 16);
+    commit(MT + i, stg[(MT + i) & 1]);
     __syncthreads();
-    if (i + 1 < MT) issue(Jm, i + 1, false);
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int kb = i; kb < MT; ++kb) {
-      c = TGP_MFMA(buf[(16 * kb + q) * 16 + nl], Ca[kb][0], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 4 + q) * 16 + nl], Ca[kb][1], c2);
-      c = TGP_MFMA(buf[(16 * kb + 8 + q) * 16 + nl], Ca[kb][2], c);
-      c2 = TGP_MFMA(buf[(16 * kb + 12 + q) * 16 + nl], Ca[kb][3], c2);
-    }
-    Ba[i] = c + c2;  // Kbar
+    if (MT + i + 2 < 2 * MT) issue(LqT, Jm, MT + i + 2, stg[(MT + i) & 1]);
+    Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Ca[i + st / 4][st % 4]; });  // Kbar
   }
   __syncthreads();  // panels dead: the region becomes the transposition tile
 
@@ -382,13 +385,9 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
   __syncthreads();
   for (int t = wave; t < MT * CT; t += 4) {
     const int ti = t / CT, tc = t % CT;
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int nk = 0; nk < 16; nk += 2) {
-      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], xt[(4 * nk + q) * CT16 + 16 * tc + nl], c);
-      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q], xt[(4 * nk + 4 + q) * CT16 + 16 * tc + nl], c2);
-    }
-    c += c2;
+    d4 c = {0, 0, 0, 0};
+    c = tile_mm_f([&](int k) { return tile[(16 * ti + nl) * LD + k + q]; },
+                  [&](int k) { return xt[(k + q) * CT16 + 16 * tc + nl]; }, 0, TGP_ROWS_PER_BLOCK, c);
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
   }
@@ -402,34 +401,60 @@ __global__ __launch_bounds__(256) void k_rows(RowArgs a) {
     for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
   if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
   __syncthreads();
-  for (int t = wave; t < p.ntri; t += 4) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+  TGP_STAMP(a.ws, p, 17);
+  TGP_STAMP(a.ws, p, 17);
+  // Row-blocks of G are dealt to the waves in balanced groups -- MT odd: {MT-1}, {MT-2, 0}, {MT-3, 1}, ...; MT even:
+  // {MT-1, 0}, {MT-2, 1}, ... (every group holds MT or MT+1 of the MT(MT+1)/2 lower tiles) -- so that the 16 A-operand
+  // fragments of a row-block are read from LDS ONCE, kept in registers (first raw for s = A mubar, then scaled by vbar for
+  // the G tiles of that row) and only the B operand streams from LDS: with all operands re-read per MFMA the four waves
+  // saturated the LDS (61 ns per MFMA measured instead of 27).
+  {
+    const int ngroups = (MT + 1) / 2;
+    if (wave < ngroups) {
+      int rows[2], nrows;
+      if (MT & 1) {
+        if (wave == 0) { rows[0] = MT - 1; nrows = 1; }
+        else { rows[0] = MT - 1 - wave; rows[1] = wave - 1; nrows = 2; }
+      } else {
+        rows[0] = MT - 1 - wave; rows[1] = wave; nrows = 2;
+      }
+      for (int g = 0; g < nrows; ++g) {
+        const int ti = rows[g];
+        double af[16];
 #pragma unroll
-    for (int nk = 0; nk < 16; nk += 2) {
-      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q] * vbs[4 * nk + q], tile[(16 * tj + nl) * LD + 4 * nk + q], c);
-      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q] * vbs[4 * nk + 4 + q],
-                    tile[(16 * tj + nl) * LD + 4 * nk + 4 + q], c2);
+        for (int nk = 0; nk < 16; ++nk) af[nk] = tile[(16 * ti + nl) * LD + 4 * nk + q];
+        {  // s = A mubar (B operand = mubar in column 0)
+          d4 c = {0, 0, 0, 0};
+          double bm[16];
+#pragma unroll
+          for (int nk = 0; nk < 16; ++nk) bm[nk] = nl == 0 ? mbs[4 * nk + q] : 0.0;
+#pragma unroll
+          for (int nk = 0; nk < 16; ++nk) c = TGP_MFMA(af[nk], bm[nk], c);
+          if (nl == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
+          }
+        }
+#pragma unroll
+        for (int nk = 0; nk < 16; ++nk) af[nk] *= vbs[4 * nk + q];
+        for (int tj = 0; tj <= ti; ++tj) {
+          const int t = ti * (ti + 1) / 2 + tj;
+          d4 c = {0, 0, 0, 0};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = tile[(16 * tj + nl) * LD + 4 * (8 * h + u) + q];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) c = TGP_MFMA(af[8 * h + u], bv[u], c);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
+        }
+      }
     }
-    c += c2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
   }
-  for (int ti = wave; ti < MT; ti += 4) {
-    d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
-#pragma unroll
-    for (int nk = 0; nk < 16; nk += 2) {
-      c = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + q], nl == 0 ? mbs[4 * nk + q] : 0.0, c);
-      c2 = TGP_MFMA(tile[(16 * ti + nl) * LD + 4 * nk + 4 + q], nl == 0 ? mbs[4 * nk + 4 + q] : 0.0, c2);
-    }
-    c += c2;
-    if (nl == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
-    }
-  }
+  TGP_STAMP(a.ws, p, 18);
 
   TGP_STAMP(a.ws, p, 9);
   // ---- scalars, flow parameter gradients ----
