@@ -168,18 +168,18 @@ __device__ __forceinline__ d4 tile_mm(const double* __restrict__ A, const double
 // Same product with caller-supplied operand fetchers fa(k), fb(k) (k = first row of the 4-deep k-step; the
 // fetcher adds the lane's own q).  Loads of 8 k-steps are issued before their MFMAs so the (L2/LDS) latency
 // of one batch overlaps the matrix pipe instead of serialising load -> mfma -> load.
-template <class FA, class FB>
+template <int BATCH = 8, class FA, class FB>
 __device__ __forceinline__ d4 tile_mm_f(FA fa, FB fb, int k0, int k1, d4 acc) {
   int k = k0;
-  for (; k + 32 <= k1; k += 32) {
-    double a[8], b[8];
+  for (; k + 4 * BATCH <= k1; k += 4 * BATCH) {
+    double a[BATCH], b[BATCH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { a[u] = fa(k + 4 * u); b[u] = fb(k + 4 * u); }
+    for (int u = 0; u < BATCH; ++u) { a[u] = fa(k + 4 * u); b[u] = fb(k + 4 * u); }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = TGP_MFMA(a[u], b[u], acc);
-    // pin the batch shape: every load (LDS or global) of the batch before its 8 MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100 | 0x020, 24, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    for (int u = 0; u < BATCH; ++u) acc = TGP_MFMA(a[u], b[u], acc);
+    // pin the batch shape: every load (LDS or global) of the batch before its MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100 | 0x020, 3 * BATCH, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, BATCH, 0);
   }
   for (; k + 16 <= k1; k += 16) {
     double a[4], b[4];
@@ -191,6 +191,9 @@ __device__ __forceinline__ d4 tile_mm_f(FA fa, FB fb, int k0, int k1, d4 acc) {
   for (; k < k1; k += 4) acc = TGP_MFMA(fa(k), fb(k), acc);
   return acc;
 }
+
+// Global-memory operands (L2 round trip ~1 us): one big batch so a whole tile costs one or two round trips.
+#define TGP_GBATCH 28
 
 // ---------------------------------------------------------------------------------------------------
 // flows (models/flow.py).  `tp` = shared parameters after their positivity transform, `tg` = d(tp)/d(raw)

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       ws[p.Lq + (size_t)row * MP + col] = lq;
       ws[p.LqT + (size_t)col * MP + row] = lq;
       ws[p.Kmm + (size_t)row * MP + col] = k;
+      if (tj > ti) {  // strictly-upper tile: zero in L and J; its mirror (tj, ti) is zero in J^T
+        ws[p.L + (size_t)row * MP + col] = 0.0;
+        ws[p.J + (size_t)row * MP + col] = 0.0;
+        ws[p.JT + (size_t)col * MP + row] = 0.0;
+      }
     }
     if (wave == 4) {  // S tile on a wave that did no copy work
       const int i = ti * 16 + r, j = tj * 16 + r;
@@ -322,27 +327,29 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   }
   if (has_nan) s_nan = 1;
   __syncthreads();
-  // ---- write L, J, J^T tile by tile (one wave per 16x16 tile, 128-byte row segments) ----
-  for (int t = wave; t < MT * MT; t += PREP_THREADS / 64) {
-    const int ti = t / MT, tj = t % MT;
+  // ---- write L, J (lower tiles) and J^T (upper tiles), one wave per tile, 128-byte row segments.  A single CU
+  //      stores at ~30-50 GB/s, so block 0 writes only what is non-zero; the structurally-zero tiles are written
+  //      by the (otherwise idle) tile blocks of this same launch ----
+  for (int t = wave; t < p.ntri; t += PREP_THREADS / 64) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      double l = 0.0, jv = 0.0;
+      double l, jv;
       if (ti == tj) {
-        if (cc <= rr) l = A[rr * LD + cc];
+        l = cc <= rr ? A[rr * LD + cc] : 0.0;
         jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
-      } else if (tj < ti) {
+      } else {
         l = A[rr * LD + cc];
         jv = A[cc * LD + rr];
       }
       ws[p.L + (size_t)rr * MP + cc] = l;
       ws[p.J + (size_t)rr * MP + cc] = jv;
-      // J^T tile (ti, tj) = transpose of J tile (tj, ti)
-      double jt = 0.0;
-      if (ti == tj) jt = Dt[ti * 256 + (cc & 15) * 16 + (rr & 15)];
-      else if (ti < tj) jt = A[rr * LD + cc];
-      ws[p.JT + (size_t)rr * MP + cc] = jt;
+      // J^T tile (tj, ti), rows = cols of the J tile: element [16 tj + q+4u][16 ti + r] = J[16 ti + r][16 tj + q+4u]
+      const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
+      ws[p.JT + (size_t)rt * MP + ct] = (ti == tj) ? Dt[ti * 256 + (ct & 15) * 16 + (rt & 15)] : A[rt * LD + ct];
     }
   }
   if (tid == 0) {
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
     if (t < MT - c) {
       const int i0 = 16 * (c + t);
       d4 acc = {0, 0, 0, 0};
-      acc = tile_mm_f([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
+      acc = tile_mm_f<TGP_GBATCH>([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
                       [&](int k) { return Gs[(k + q) * 16 + r]; }, 0, MP, acc);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
       const int j = t - (MT - c), j0 = 16 * j;
       d4 acc = {0, 0, 0, 0};
       if (j <= c)
-        acc = tile_mm_f([&](int k) { return Lq[(size_t)(k + q) * MP + j0 + r]; },
+        acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lq[(size_t)(k + q) * MP + j0 + r]; },
                         [&](int k) { return Gs[(k + q) * 16 + r]; }, j0, MP, acc);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
     const int i = c + t, i0 = 16 * i;
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
+    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
                     [&](int k) { return LbL[(k + q) * 16 + r]; }, i0, MP, acc);
     if (i != c) {
 #pragma unroll
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
       }
     } else {
       d4 tr = {0, 0, 0, 0};  // M1^T tile = Lbar^T L
-      tr = tile_mm_f([&](int k) { return LbL[(k + q) * 16 + r]; },
+      tr = tile_mm_f<TGP_GBATCH>([&](int k) { return LbL[(k + q) * 16 + r]; },
                      [&](int k) { return Lm[(size_t)(k + q) * MP + c0 + r]; }, c0, MP, tr);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restric
   const double* __restrict__ Q = ws + p.Q;
   for (int kb = wave; kb < MT; kb += BWD_THREADS / 64) {
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f([&](int k) { return J[(size_t)(k + q) * MP + i0 + r]; },
+    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return J[(size_t)(k + q) * MP + i0 + r]; },
                     [&](int k) { return Q[(size_t)(k + q) * MP + 16 * kb + r]; }, i0, MP, acc);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Yl[kb * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restric
   for (int jb = wave; jb < MT; jb += BWD_THREADS / 64) {
     const int j0 = 16 * jb;
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f([&](int k) { return Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q]; },
+    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q]; },
                     [&](int k) { return J[(size_t)(k + q) * MP + j0 + r]; }, j0, MP, acc);  // J[k,j] = 0 for k < j
     double ep[4];
 #pragma unroll

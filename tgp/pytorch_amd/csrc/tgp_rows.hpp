@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ti = t / MT, tj = t % MT;
     const double* __restrict__ Sg = ws + p.S_;
     d4 hacc = {0, 0, 0, 0};
-    hacc = tile_mm_f([&](int k) { return Jg[(size_t)(k + q) * MP + 16 * ti + nl]; },
+    hacc = tile_mm_f<TGP_GBATCH>([&](int k) { return Jg[(size_t)(k + q) * MP + 16 * ti + nl]; },
                     [&](int k) { return Sg[(size_t)(k + q) * MP + 16 * tj + nl]; }, 16 * ti, MP, hacc);  // (J^T)[i,k]=0, k<i
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
