@@ -33,10 +33,12 @@
 extern "C" {
 #endif
 
-#define TGP_VERSION 100
+#define TGP_VERSION 101
+#define TGP_FUSED_MAX_M 128 /* up to here the whole step is 7 fused kernels (operators resident in LDS/registers) */
+#define TGP_BIG_MAX_M 4096  /* above: chunked path built on a tiled float64 MFMA GEMM                             */
 
 /* error codes (negative return values below -64 are generic) */
-#define TGP_E_UNSUPPORTED (-100) /* shape outside this build's limits (M > 128, D > 16, ...) */
+#define TGP_E_UNSUPPORTED (-100) /* shape outside this build's limits (M > 4096, D > 16, ...) */
 #define TGP_E_WORKSPACE (-101)   /* workspace too small                                        */
 #define TGP_E_LDS (-102)         /* flow program too large for one CU's LDS                    */
 #define TGP_E_LAUNCH (-103)      /* hipLaunchKernel failed; see tgp_last_error()               */
@@ -67,7 +69,7 @@ extern "C" {
 typedef struct tgp_model {
   int32_t N;       /* rows in this call (this rank's shard of the minibatch)            */
   int32_t D;       /* input dimension (<= 16)                                           */
-  int32_t M;       /* inducing points (<= 128 in this build)                            */
+  int32_t M;       /* inducing points: <= 128 fused path, <= TGP_BIG_MAX_M tiled-GEMM path */
   int32_t S;       /* quadrature nodes (TGP_LIK_FLOW)                                   */
   int32_t nblk;    /* flow blocks                                                       */
   int32_t P;       /* shared flow scalars in theta                                      */
@@ -146,6 +148,16 @@ int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const do
  * A (M,M) symmetric, L (M,M) lower (strict upper zeroed); Linv (M,M) = L^-1 or NULL. */
 int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_t* status, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* Dense float64 contraction on the matrix cores, the building block of the M > 128 path (the reference's
+ * torch.bmm / triangular_solve calls at models/sparse_MF_SP.py:354,376-382 on (M,M)x(M,N) operands):
+ *   C = alpha * op(A) op(B) + beta * C, row-major, op = transpose when trans_* != 0.
+ * m, n multiples of 128, k a multiple of 16 (callers pad).  `tri` declares triangular operands so that the k range
+ * is trimmed per output tile: 1 op(A) lower, 2 op(A) upper, 4 op(B) lower, 8 op(B) upper, 16 compute only the
+ * lower block triangle of C (flags OR-ed; 0 = general). */
+int tgp_gemm_f64(int32_t trans_a, int32_t trans_b, int32_t tri, int32_t m, int32_t n, int32_t k, double alpha,
+                 const double* A, int32_t lda, const double* B, int32_t ldb, double beta, double* C, int32_t ldc,
+                 void* stream);
 
 /* Whitened KL and its gradients: sparse_MF_SP.KLD, models/sparse_MF_SP.py:406-431. out[0] = KL. */
 int tgp_kl_whitened_f64(const double* m, const double* Lam, int32_t M, double* out, double* g_m, double* g_Lam,

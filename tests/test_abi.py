@@ -49,7 +49,8 @@ def test_argument_errors_are_codes_not_crashes(lib):
     assert lib.tgp_kmm_f64(None, None, None, 4, 2, ctypes.c_double(0.0), None, None) == -1
     lib.tgp_workspace_bytes.restype = ctypes.c_size_t
     assert lib.tgp_workspace_bytes(8611, 4, 100, 32, 6, 30, 0) > 0
-    assert lib.tgp_workspace_bytes(8611, 4, 129, 32, 6, 30, 0) == 0      # M > 128 unsupported in this build
+    assert lib.tgp_workspace_bytes(8611, 4, 129, 32, 6, 30, 0) > 0       # M > 128: tiled-GEMM path
+    assert lib.tgp_workspace_bytes(8611, 4, 4097, 32, 6, 30, 0) == 0     # M > TGP_BIG_MAX_M unsupported in this build
     assert lib.tgp_workspace_bytes(8611, 17, 100, 32, 6, 30, 0) == 0     # D > 16 unsupported
 
 

@@ -1,0 +1,144 @@
+"""GPU (-m gpu): the general-M path (M > 128: tiled float64 MFMA GEMM, multi-kernel blocked Cholesky, chunked rows)
+through the C ABI against the oracle, plus the GEMM building block against torch.matmul."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import rel_err
+from test_gpu_parity import compare, run_hip
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_matches_torch(ta, tb):
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 256, 384, 208
+    A = torch.randn((k, m) if ta else (m, k), generator=g, dtype=torch.float64).to(dev)
+    B = torch.randn((n, k) if tb else (k, n), generator=g, dtype=torch.float64).to(dev)
+    C0 = torch.randn(m, n, generator=g, dtype=torch.float64).to(dev)
+    ref = 0.7 * (A.T if ta else A) @ (B.T if tb else B) - 1.3 * C0
+    C = ops.gemm(A, B, trans_a=ta, trans_b=tb, alpha=0.7, beta=-1.3, C=C0.clone())
+    torch.cuda.synchronize()
+    assert rel_err(C.cpu(), ref.cpu()) < 1e-13
+
+
+def test_gemm_triangular_trimming():
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    n = 384
+    Lo = torch.tril(torch.randn(n, n, generator=g, dtype=torch.float64)).to(dev)
+    X = torch.randn(n, n, generator=g, dtype=torch.float64).to(dev)
+    cases = [
+        (dict(trans_a=False, trans_b=False, tri=ops.TRI_A_LOWER), Lo, X, Lo @ X),
+        (dict(trans_a=True, trans_b=False, tri=ops.TRI_A_UPPER), Lo, X, Lo.T @ X),
+        (dict(trans_a=False, trans_b=False, tri=ops.TRI_B_LOWER), X, Lo, X @ Lo),
+        (dict(trans_a=False, trans_b=True, tri=ops.TRI_B_UPPER), X, Lo, X @ Lo.T),
+        (dict(trans_a=False, trans_b=True, tri=ops.TRI_A_LOWER | ops.TRI_B_UPPER), Lo, Lo, Lo @ Lo.T),
+        (dict(trans_a=True, trans_b=False, tri=ops.TRI_A_UPPER | ops.TRI_B_LOWER), Lo, Lo, Lo.T @ Lo),
+    ]
+    for kw, A, B, ref in cases:
+        C = ops.gemm(A, B, **kw)
+        torch.cuda.synchronize()
+        assert rel_err(C.cpu(), ref.cpu()) < 1e-13, kw
+    # lower block triangle only: tiles above the diagonal stay untouched
+    C = ops.gemm(X, X, trans_b=True, tri=ops.TRI_C_LOWER, C=torch.full((n, n), 7.0, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    ref = (X @ X.T).cpu()
+    C = C.cpu()
+    for bi in range(3):
+        for bj in range(3):
+            blk = C[128 * bi:128 * bi + 128, 128 * bj:128 * bj + 128]
+            if bj <= bi:
+                assert rel_err(blk, ref[128 * bi:128 * bi + 128, 128 * bj:128 * bj + 128]) < 1e-13
+            else:
+                assert float((blk - 7.0).abs().max()) == 0.0
+
+
+def _oracle_case(N, D, M, flow, S, seed=3):
+    from oracle import tgp_oracle as orc
+    prob = orc.synthetic_problem(N, D, M, seed=seed, flow=flow, S=S)
+    (elbo, ell, kld), og = orc.elbo_and_grads(prob["X"], prob["Y"], prob["params"], prob["N_total"], prob["program"],
+                                              prob["xs"], prob["ws"], prob["rowp"])
+    g = dict(prob)
+    g.update(ELBO=elbo, ELL=ell, KLD=kld, g_Z=og["Z"], g_raw_lengthscale=og["raw_lengthscale"],
+             g_raw_outputscale=og["raw_outputscale"], g_m=og["m"], g_Lam=og["Lam"], g_log_var_noise=og["log_var_noise"])
+    if "theta" in og:
+        g["g_theta"] = og["theta"]
+    if "rowp" in og:
+        g["g_rowp"] = og["rowp"]
+    return g
+
+
+@pytest.mark.parametrize("N,D,M,flow,S", [(300, 8, 200, "tanh5x6", 32), (1000, 4, 129, None, 8), (700, 8, 300, "sal2", 32),
+                                           (400, 5, 150, "idsal3", 16), (2000, 8, 1000, "tanh5x6", 32)])
+def test_big_elbo_step_matches_oracle(N, D, M, flow, S):
+    g = _oracle_case(N, D, M, flow, S)
+    out, grads, status, (mu, v) = run_hip(g)
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    compare(out, grads, g)
+    assert float(torch.triu(grads["Lam"], 1).abs().max()) == 0.0
+
+
+def test_big_qf_moments_matches_oracle():
+    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    prob = orc.synthetic_problem(900, 6, 260, seed=4, flow=None, S=8)
+    p = prob["params"]
+    mu_o, v_o = orc.qf_moments(prob["X"], p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"])
+    mu, v = ops.qf_moments(prob["X"].to(dev), p["Z"].to(dev), p["raw_lengthscale"].to(dev), p["raw_outputscale"].to(dev),
+                           p["m"].to(dev), p["Lam"].to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(mu.cpu(), mu_o.reshape(-1)) < 1e-9
+    assert rel_err(v.cpu(), v_o.reshape(-1)) < 1e-7
+
+
+_CHUNK_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_big import _oracle_case
+from test_gpu_parity import run_hip, compare
+g = _oracle_case(1000, 6, 160, "sal2", 16, seed=5)
+out, grads, status, _ = run_hip(g)
+assert int(status[0]) == 0
+compare(out, grads, g)
+print("CHUNKED_OK")
+"""
+
+
+def test_big_path_several_row_chunks():
+    """TGP_BIG_CHUNK (read once per process) forces 4 row chunks, the last one ragged: accumulation across chunks."""
+    env = dict(os.environ, TGP_BIG_CHUNK="256")
+    r = subprocess.run([sys.executable, "-c", _CHUNK_SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_big_non_psd_reports_pivot():
+    """Duplicate inducing points make K_MM singular: status[0] is the first failing pivot (LAPACK info), as for M <= 128."""
+    from oracle import tgp_oracle as orc
+    prob = orc.synthetic_problem(400, 4, 200, seed=7, flow=None, S=8)
+    prob["params"]["Z"][150] = prob["params"]["Z"][20]
+    g = dict(prob)
+    g.update(program=None)
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    p = {k: t.to(dev) for k, t in prob["params"].items()}
+    out, grads, status, _ = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
+                                           p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], 400.0)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 151

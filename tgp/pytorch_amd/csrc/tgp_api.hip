@@ -19,7 +19,7 @@ static int check_model(const tgp_model* m, bool need_lik) {
   if (m == nullptr) return -1;
   if (m->N < 1 || m->D < 1 || m->D > 16) return -1;
   if (m->M < 1) return -1;
-  if (m->M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
+  if (m->M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
   if (!m->Z || !m->raw_ls || !m->raw_os || !m->m || !m->Lam || !m->log_var_noise) return -1;
   if (need_lik && m->lik == TGP_LIK_FLOW) {
     if (m->S < 1 || m->nblk < 0 || !m->xs || !m->wn) return -1;
@@ -61,6 +61,7 @@ int tgp_version(void) { return TGP_VERSION; }
 const char* tgp_last_error(void) { return g_err; }
 
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP) {
+  if (M > TGP_FUSED_MAX_M) return big_workspace_doubles(N, D, M, S, nblk, P, RP) * sizeof(double);
   Plan p;
   if (make_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
   size_t d = p.total;
@@ -90,12 +91,9 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   if ((mu == nullptr) != (v == nullptr)) return -7;
   if (!status) return -9;
   if (!workspace) return -10;
-  Plan p;
   const int nblk = model->lik == TGP_LIK_FLOW ? model->nblk : 0;
   const int P = model->lik == TGP_LIK_FLOW ? model->P : 0;
   const int RP = model->lik == TGP_LIK_FLOW ? model->RP : 0;
-  if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
-  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
@@ -103,6 +101,11 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   FlowProg fp;
   if (int rc = make_prog(&md, model->lik == TGP_LIK_FLOW, fp)) return rc;
   md.program = nullptr;  // kernels use the by-value copy
+  if (model->M > TGP_FUSED_MAX_M)
+    return launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st);
+  Plan p;
+  if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   p.nslots = fp.nslots;
   if (phases & TGP_PHASE_PREPARE)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
@@ -121,13 +124,14 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   if (!v) return -4;
   if (!status) return -5;
   if (!workspace) return -6;
-  Plan p;
-  if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
-  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
   md.nblk = 0; md.P = 0; md.RP = 0; md.lik = TGP_LIK_GAUSS; md.program = nullptr;
+  if (model->M > TGP_FUSED_MAX_M) return launch_big_moments(md, X, mu, v, status, ws, workspace_bytes / sizeof(double), st);
+  Plan p;
+  if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   FlowProg fp;
   fp.nblk = 0; fp.nslots = 0;
   if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
@@ -167,6 +171,20 @@ int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_
   if (!L) return -3;
   if (!status) return -5;
   return launch_cholesky(A, M, L, Linv, status, static_cast<hipStream_t>(stream));
+}
+
+int tgp_gemm_f64(int32_t trans_a, int32_t trans_b, int32_t tri, int32_t m, int32_t n, int32_t k, double alpha,
+                 const double* A, int32_t lda, const double* B, int32_t ldb, double beta, double* C, int32_t ldc,
+                 void* stream) {
+  if (tri < 0 || tri > 31) return -3;
+  if (m < 1 || m % 128) return -4;
+  if (n < 1 || n % 128) return -5;
+  if (k < 1 || k % 16) return -6;
+  if (!A) return -8;
+  if (!B) return -10;
+  if (!C) return -13;
+  return launch_gemm_plain(trans_a != 0, trans_b != 0, tri, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc,
+                           static_cast<hipStream_t>(stream));
 }
 
 int tgp_kl_whitened_f64(const double* m, const double* Lam, int32_t M, double* out, double* g_m, double* g_Lam,

@@ -1,0 +1,765 @@
+// tgp_big.hip -- the general-M ELBO step (128 < M <= TGP_BIG_MAX_M), same algebra as the fused path.
+//
+// At M = 1000 (SURVEY config C5) neither the M x M operators nor a row block's A = L^-1 K_MN column fit in LDS/registers,
+// and the work is dense contraction proper: 5.25 M^2 N flops per step against 8 (D+1) N compulsory bytes.  So this
+// path is organised around ONE tiled MFMA GEMM (tgp_gemm.hpp) with fused operand/epilogue modifiers:
+//
+//   prepare   : K_MM, blocked right-looking Cholesky (128-wide: in-LDS potrf+trtri of the diagonal block, panel and
+//               trailing update as GEMMs), block-row inverse J = L^-1, S = Lq Lq^T, H' = J^T (S - I), w = J^T m, KL
+//   row chunks: rows are processed NC (<= 16384) at a time, matrices laid out [M][NC] (inducing index major):
+//               Kc -> A = J Kc -> B = Lq^T A -> (mu, v) -> likelihood (k_ell_gauss / k_ell_flow) ->
+//               Abar = vbar o (2 Lq B - 2 A) + m mubar^T (GEMM epilogue) -> Kbar = J^T Abar ->
+//               T += (Kbar o Kc) [xs, xs^2, 1]  (split-K GEMM)   G += A diag(vbar) A^T  (split-K SYRK)   s += A mubar
+//   backward  : Lbar = -tril(w s^T + 2 H' G), Lambar = 2 tril(G Lq) - kl(...), Q = Phi(L^T Lbar) + Phi(.)^T,
+//               Kbar_MM = 1/2 J^T Q J, U = (Kbar_MM o K_MM) [Zs, Zs^2, 1], parameter gradients.
+// Replaces the same reference lines as tgp_mm.hip / tgp_rows.hpp (models/sparse_MF_SP.py:274-431,552-626).
+#include <cstdlib>
+#include "tgp_dev.hpp"
+#include "tgp_gemm.hpp"
+#include "tgp_launch.hpp"
+
+namespace tgp {
+
+#define LAUNCH_CHECK()                                              \
+  do {                                                              \
+    hipError_t e_ = hipGetLastError();                              \
+    if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
+  } while (0)
+
+#define BIG_XW 128    /* width of the augmented coordinate matrices [xs, xs^2, 1, 0...] */
+#define BIG_KSG 8     /* split-K slabs of the G SYRK */
+#define BIG_KST 32    /* split-K slabs of the T statistics GEMM */
+#define BIG_NKL 64    /* KL partial blocks */
+#define BIG_NCMAX 16384
+
+struct BigPlan {
+  int N, D, M, S, nblk, P, RP, lik;
+  int MP, DP, NC, nchunks, NP, LS;
+  size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb;
+  size_t Kmm, Lm, J, Lq, S_, Hp, G, Q, R1, tmp;
+  size_t Zaug, U, T, Xaug;
+  size_t Kc, A, B, Ab;
+  size_t mu, v, mub, vb;
+  size_t Gpart, Tpart, likslot, likws;
+  size_t total;
+};
+
+static int big_chunk_max() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("TGP_BIG_CHUNK");  // test hook: force several chunks at small N
+    int x = e ? atoi(e) : BIG_NCMAX;
+    if (x < 128) x = 128;
+    v = (x + 127) / 128 * 128;
+  }
+  return v;
+}
+
+static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
+  if (D < 1 || D > 16) return -2;
+  if (M <= 16 * TGP_MAX_MT || M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
+  p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
+  p.MP = (M + 127) / 128 * 128;
+  p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
+  const int ncmax = big_chunk_max();
+  p.nchunks = (N + ncmax - 1) / ncmax;
+  if (p.nchunks < 1) p.nchunks = 1;
+  p.NC = (int)rup((size_t)(N + p.nchunks - 1) / p.nchunks, 128);
+  p.NP = p.NC * p.nchunks;
+  p.LS = (int)rup(2 + P, 8);
+  size_t o = 0;
+  const size_t mm = (size_t)p.MP * p.MP, mn = (size_t)p.MP * p.NC;
+  p.hdr = o; o += H_N;
+  p.ils = o; o += 16;
+  p.ls = o; o += 16;
+  p.Zs = o; o += (size_t)p.MP * p.DP;
+  p.mpad = o; o += p.MP;
+  p.w = o; o += p.MP;
+  p.sv = o; o += p.MP;
+  p.klpart = o; o += BIG_NKL;
+  p.svb = o; o += 16;
+  p.Kmm = o; o += mm; p.Lm = o; o += mm; p.J = o; o += mm; p.Lq = o; o += mm; p.S_ = o; o += mm;
+  p.Hp = o; o += mm; p.G = o; o += mm; p.Q = o; o += mm; p.R1 = o; o += mm;
+  p.tmp = o; o += (size_t)128 * p.MP;
+  p.Zaug = o; o += (size_t)p.MP * BIG_XW;
+  p.U = o; o += (size_t)p.MP * BIG_XW;
+  p.T = o; o += (size_t)p.MP * BIG_XW;
+  p.Xaug = o; o += (size_t)p.NC * BIG_XW;
+  p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
+  p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
+  p.Gpart = o; o += BIG_KSG * mm;
+  p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
+  p.likslot = o; o += (size_t)p.nchunks * p.LS;
+  p.likws = o; o += lik_workspace_doubles(p.NC, P, RP);
+  p.total = o;
+  return 0;
+}
+
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP) {
+  BigPlan p;
+  if (make_big_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
+  return p.total;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GEMM launcher
+// ---------------------------------------------------------------------------------------------------
+int launch_gemm(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
+  if (g.m % GT || g.n % GT || g.k % GK || g.m < 1 || g.n < 1 || g.ksplit < 1) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    const void* fs[4] = {reinterpret_cast<const void*>(k_gemm<false, false>), reinterpret_cast<const void*>(k_gemm<false, true>),
+                         reinterpret_cast<const void*>(k_gemm<true, false>), reinterpret_cast<const void*>(k_gemm<true, true>)};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+      if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    }
+    attr_done = true;
+  }
+  dim3 grid(g.n / GT, g.m / GT, g.ksplit), block(256);
+  if (ta && tb) hipLaunchKernelGGL((k_gemm<true, true>), grid, block, GEMM_LDS_BYTES, st, g);
+  else if (ta) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, GEMM_LDS_BYTES, st, g);
+  else if (tb) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, GEMM_LDS_BYTES, st, g);
+  else hipLaunchKernelGGL((k_gemm<false, false>), grid, block, GEMM_LDS_BYTES, st, g);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prepare kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_big_hdr(BigPlan p, tgp_model md, double* __restrict__ ws, int32_t* __restrict__ status) {
+  const int tid = threadIdx.x;
+  if (tid < 16) {
+    const double l = tid < p.D ? softplus_d(md.raw_ls[tid]) : 1.0;
+    ws[p.ls + tid] = l;
+    ws[p.ils + tid] = tid < p.D ? 1.0 / l : 0.0;
+  }
+  if (tid == 0) {
+    double* hdr = ws + p.hdr;
+    hdr[H_S2] = softplus_d(md.raw_os[0]);
+    hdr[H_ETA] = md.log_var_noise[0];
+    hdr[H_EINV] = exp(-md.log_var_noise[0]);
+    hdr[H_SIG_OS] = sigmoid_d(md.raw_os[0]);
+    status[0] = 0;
+    status[1] = 0;
+  }
+  // zero the adjoints of the padding rows of the last chunk
+  for (int i = p.N + tid; i < p.NP; i += 256) { ws[p.mub + i] = 0.0; ws[p.vb + i] = 0.0; }
+}
+
+// Zs, padded m, Zaug = [Zs, Zs^2, 1, 0...]; one thread per Zaug element
+__global__ __launch_bounds__(256) void k_big_zs(BigPlan p, tgp_model md, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int row = (int)(e >> 7), c = (int)(e & 127);
+  if (row >= p.MP) return;
+  const int DP = p.DP;
+  double x = 0.0;
+  if (row < p.M) {
+    const int d = c < DP ? c : c - DP;
+    if (c < 2 * DP) {
+      if (d < p.D) {
+        const double z = md.Z[(size_t)row * p.D + d] * (1.0 / softplus_d(md.raw_ls[d]));
+        x = c < DP ? z : z * z;
+      }
+    } else if (c == 2 * DP) {
+      x = 1.0;
+    }
+  }
+  ws[p.Zaug + e] = x;
+  if (c < DP) ws[p.Zs + (size_t)row * DP + c] = x;
+  if (c == 0) ws[p.mpad + row] = row < p.M ? md.m[row] : 0.0;
+}
+
+// whitened KL partial sums (models/sparse_MF_SP.py:406-431)
+__global__ __launch_bounds__(256) void k_big_kl(BigPlan p, tgp_model md, double* __restrict__ ws) {
+  __shared__ double red[4];
+  const int M = p.M;
+  double part = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)M * M; i += (size_t)BIG_NKL * 256) {
+    const int rr = (int)(i / M), cc = (int)(i % M);
+    if (cc <= rr) {
+      const double x = md.Lam[i];
+      part += x * x;
+      if (cc == rr) part -= log(x * x);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < M; i += 256) part += md.m[i] * md.m[i];
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[p.klpart + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// K_MM (+ jitter, identity on the padding), the to-be-factorised copy (lower block triangle), J = 0, masked L_q
+__global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double* __restrict__ ws, int32_t* __restrict__ status) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int MP = p.MP, M = p.M, DP = p.DP;
+  const int row = (int)(e / MP), col = (int)(e % MP);
+  double k, lq = 0.0;
+  if (row < M && col < M) {
+    const double* zr = ws + p.Zs + (size_t)row * DP;
+    const double* zc = ws + p.Zs + (size_t)col * DP;
+    double d2 = 0.0;
+    for (int d = 0; d < DP; ++d) {
+      const double t = zr[d] - zc[d];
+      d2 += t * t;
+    }
+    k = ws[p.hdr + H_S2] * exp_fast(-0.5 * d2);
+    if (k != k) status[1] = 1;
+    if (row == col) k += md.jitter;
+    if (col <= row) lq = md.Lam[(size_t)row * M + col];
+  } else {
+    k = row == col ? 1.0 : 0.0;
+  }
+  ws[p.Kmm + e] = k;
+  ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
+  ws[p.J + e] = 0.0;
+  ws[p.Lq + e] = lq;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cholesky + inverse of one 128 x 128 diagonal block, in LDS (8 waves; same lookahead schedule as k_prep_a).
+//   in : lower triangle of Lm[o.., o..] (o = 128 kb), already updated by the previous block columns
+//   out: L_kk (zero above the diagonal) in place, J_kk = L_kk^-1 into J's diagonal block
+// ---------------------------------------------------------------------------------------------------
+#define POTRF_THREADS 512
+#define POTRF_LD 129
+#define POTRF_LDS_BYTES ((128 * POTRF_LD + 8 * 256) * sizeof(double))
+
+__global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
+                                                              int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* A = reinterpret_cast<double*>(smem_raw);  // 128 x 129: lower = block -> L ; strict-upper TILES hold J^T tiles
+  double* Dt = A + 128 * POTRF_LD;                  // 8 x 256: inverses of the diagonal 16x16 tiles
+  __shared__ int s_info;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int LD = POTRF_LD, MT = 8;
+  const size_t o = (size_t)kb * 128;
+  double* Lb = Lm + o * ld + o;
+  double* Jb = Jm + o * ld + o;
+  if (tid == 0) s_info = 0;
+  for (int e = tid; e < 128 * 128; e += POTRF_THREADS) {
+    const int rr = e >> 7, cc = e & 127;
+    if (cc <= rr) A[rr * LD + cc] = Lb[(size_t)rr * ld + cc];
+  }
+  __syncthreads();
+  auto ll_sum = [&](int i0, int j0, int kend) {
+    d4 acc = {0, 0, 0, 0};
+    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, 0,
+                     kend, acc);
+  };
+  auto panel_tile = [&](int i, int c) {
+    const int i0 = 16 * i, c0 = 16 * c;
+    const d4 upd = ll_sum(i0, c0, c0);
+    double av[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = av[rr];
+    __builtin_amdgcn_wave_barrier();
+    d4 acc = {0, 0, 0, 0};
+    double a4[4], b4[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(i0 + r) * LD + c0 + 4 * s4 + q]; b4[s4] = Dt[c * 256 + r * 16 + 4 * s4 + q]; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(a4[s4], b4[s4], acc);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = acc[rr];
+  };
+  auto inv_tile = [&](int j, int c) {
+    const int j0 = 16 * j, c0 = 16 * c;
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; }, [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; },
+                    0, 16, acc);
+    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
+                    c0 + 16, j0, acc);
+    double dj[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) dj[s4] = Dt[j * 256 + r * 16 + 4 * s4 + q];
+    d4 out = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) out = TGP_MFMA(dj[s4], acc[s4], out);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
+  };
+  for (int j = 0; j <= MT; ++j) {
+    const int j0 = 16 * j;
+    if (wave == 0) {
+      if (j < MT) {
+        if (j > 0) {
+          panel_tile(j, j - 1);
+          __builtin_amdgcn_wave_barrier();
+          const d4 upd = ll_sum(j0, j0, j0);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
+          __builtin_amdgcn_wave_barrier();
+        }
+        double a[16], x[16];
+        const int li = lane & 15;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
+        const int bad = potrf_trtri16(a, x, li);
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
+            Dt[j * 256 + c * 16 + lane] = x[c];
+          }
+        }
+        if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
+      }
+    } else if (j > 0) {
+      const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
+      for (int t = wave - 1; t < npanel + (j - 1); t += POTRF_THREADS / 64 - 1) {
+        if (t < npanel) panel_tile(j + 1 + t, j - 1);
+        else inv_tile(j - 1, t - npanel);
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 128 * 128; e += POTRF_THREADS) {
+    const int rr = e >> 7, cc = e & 127, ti = rr >> 4, tj = cc >> 4;
+    double l = 0.0, jv = 0.0;
+    if (ti == tj) {
+      l = cc <= rr ? A[rr * LD + cc] : 0.0;
+      jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
+    } else if (ti > tj) {
+      l = A[rr * LD + cc];
+      jv = A[cc * LD + rr];
+    }
+    Lb[(size_t)rr * ld + cc] = l;
+    Jb[(size_t)rr * ld + cc] = jv;
+  }
+  if (tid == 0 && s_info != 0 && status[0] == 0) status[0] = (int)o + s_info;
+}
+
+__global__ __launch_bounds__(256) void k_big_sub_eye(double* __restrict__ S, int MP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < MP) S[(size_t)i * MP + i] -= 1.0;
+}
+
+// w = J^T m (J lower): thread per column
+__global__ __launch_bounds__(256) void k_big_wvec(BigPlan p, double* __restrict__ ws) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.MP) return;
+  const double* __restrict__ J = ws + p.J;
+  const double* __restrict__ m = ws + p.mpad;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const int ib = (j >> 8) << 8;  // J[i][j] = 0 for i < j; start at the block's first column
+  int i = ib;
+  for (; i + 4 <= p.MP; i += 4) {
+    s0 = fma(J[(size_t)i * p.MP + j], m[i], s0);
+    s1 = fma(J[(size_t)(i + 1) * p.MP + j], m[i + 1], s1);
+    s2 = fma(J[(size_t)(i + 2) * p.MP + j], m[i + 2], s2);
+    s3 = fma(J[(size_t)(i + 3) * p.MP + j], m[i + 3], s3);
+  }
+  ws[p.w + j] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// row-chunk kernels (matrices [MP][NC], column n = data row c0 + n)
+// ---------------------------------------------------------------------------------------------------
+// Xaug[n][:] = [xs, xs^2, 1, 0...] (zero rows for the padding)
+__global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n = (int)(e >> 7), c = (int)(e & 127), DP = p.DP;
+  if (n >= p.NC) return;
+  double x = 0.0;
+  if (n < nrows) {
+    const int d = c < DP ? c : c - DP;
+    if (c < 2 * DP) {
+      if (d < p.D) {
+        const double t = X[(size_t)n * p.D + d] * ws[p.ils + d];
+        x = c < DP ? t : t * t;
+      }
+    } else if (c == 2 * DP) {
+      x = 1.0;
+    }
+  }
+  ws[p.Xaug + e] = x;
+}
+
+// Kc[m][n] = s2 exp(-1/2 |xs_n - zs_m|^2); block = 128 columns x 32 inducing rows (2 row groups of 16)
+__global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
+  __shared__ double zl[32 * 16];
+  const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7, DP = p.DP;
+  const int n = blockIdx.x * 128 + c, m0 = blockIdx.y * 32;
+  for (int i = tid; i < 32 * DP; i += 256) zl[i] = ws[p.Zs + (size_t)m0 * DP + i];
+  const int nc = n < nrows ? n : nrows - 1;
+  double xs[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) xs[d] = (d < p.D) ? X[(size_t)nc * p.D + d] * ws[p.ils + d] : 0.0;
+  __syncthreads();
+  const double s2 = ws[p.hdr + H_S2];
+  double* __restrict__ Kc = ws + p.Kc;
+  for (int u = 0; u < 16; ++u) {
+    const int ml = rg * 16 + u, m = m0 + ml;
+    double d2 = 0.0;
+    for (int d = 0; d < DP; ++d) {
+      const double t = xs[d] - zl[ml * DP + d];
+      d2 += t * t;
+    }
+    Kc[(size_t)m * p.NC + n] = m < p.M ? s2 * exp_fast(-0.5 * d2) : 0.0;
+  }
+}
+
+// mu_n = sum_m m_m A_mn ; v_n = s2 - sum_m A_mn^2 + sum_m B_mn^2   (sparse_MF_SP.py:354-355,376-382)
+__global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
+                                                      double* __restrict__ v, int nrows) {
+  __shared__ double red[3][4][64];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const double* __restrict__ A = ws + p.A;
+  const double* __restrict__ B = ws + p.B;
+  const double* __restrict__ mp = ws + p.mpad;
+  double sm = 0.0, sa = 0.0, sb = 0.0;
+  for (int m = g; m < p.MP; m += 4) {
+    const double a = A[(size_t)m * p.NC + n], b = B[(size_t)m * p.NC + n];
+    sm = fma(mp[m], a, sm);
+    sa = fma(a, a, sa);
+    sb = fma(b, b, sb);
+  }
+  red[0][g][c] = sm; red[1][g][c] = sa; red[2][g][c] = sb;
+  __syncthreads();
+  if (g == 0 && n < nrows) {
+    const double m_ = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    const double a_ = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    const double b_ = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
+    mu[n] = m_;
+    v[n] = ws[p.hdr + H_S2] - a_ + b_;
+  }
+}
+
+// s_m (+)= sum_n A[m][n] mubar_n (one wave per inducing row); the extra last block accumulates sum_n vbar_n
+__global__ __launch_bounds__(256) void k_big_rowdot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* __restrict__ mub = ws + p.mub + c0;
+  if ((int)blockIdx.x == p.MP / 4) {
+    __shared__ double red[4];
+    const double* __restrict__ vb = ws + p.vb + c0;
+    double s = 0.0;
+    for (int n = tid; n < p.NC; n += 256) s += vb[n];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
+    return;
+  }
+  const int m = blockIdx.x * 4 + wave;
+  const double* __restrict__ A = ws + p.A + (size_t)m * p.NC;
+  double s0 = 0.0, s1 = 0.0;
+  int n = lane;
+  for (; n + 64 < p.NC; n += 128) {
+    s0 = fma(A[n], mub[n], s0);
+    s1 = fma(A[n + 64], mub[n + 64], s1);
+  }
+  for (; n < p.NC; n += 64) s0 = fma(A[n], mub[n], s0);
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) ws[p.sv + m] = (accumulate ? ws[p.sv + m] : 0.0) + s;
+}
+
+// slab reduction: G (lower -> full symmetric), T; likelihood slots -> hdr[H_ELL], hdr[H_ETAB]
+__global__ __launch_bounds__(256) void k_big_reduce(BigPlan p, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t mm = (size_t)p.MP * p.MP;
+  if (e < mm) {
+    const int i = (int)(e / p.MP), j = (int)(e % p.MP);
+    if (j > i) return;
+    double s = 0.0;
+#pragma unroll
+    for (int z = 0; z < BIG_KSG; ++z) s += ws[p.Gpart + z * mm + e];
+    ws[p.G + e] = s;
+    ws[p.G + (size_t)j * p.MP + i] = s;
+  } else {
+    const size_t t = e - mm;
+    if (t >= (size_t)p.MP * BIG_XW) return;
+    double s = 0.0;
+    for (int z = 0; z < BIG_KST; ++z) s += ws[p.Tpart + (size_t)z * p.MP * BIG_XW + t];
+    ws[p.T + t] = s;
+  }
+}
+
+// dst = sum of `ns` slabs of length len
+__global__ __launch_bounds__(256) void k_big_sum_slabs(const double* __restrict__ src, int ns, size_t len, double* __restrict__ dst) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= len) return;
+  double s = 0.0;
+  for (int z = 0; z < ns; ++z) s += src[(size_t)z * len + e];
+  dst[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward M x M elementwise kernels
+// ---------------------------------------------------------------------------------------------------
+// R1 (= 2 H' G) -> Lbar = -tril(w s^T + R1)
+__global__ __launch_bounds__(256) void k_big_lbar(BigPlan p, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(e / p.MP), j = (int)(e % p.MP);
+  double x = 0.0;
+  if (j <= i) x = -(ws[p.w + i] * ws[p.sv + j] + ws[p.R1 + e]);
+  ws[p.R1 + e] = x;
+}
+
+// dELBO/dLam = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)); R2 = 2 G Lq is in S_
+__global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, double* __restrict__ gLam, const double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = p.M;
+  if (e >= (size_t)M * M) return;
+  const int row = (int)(e / M), col = (int)(e % M);
+  double x = 0.0;
+  if (col <= row) {
+    const double lam = md.Lam[e];
+    x = ws[p.S_ + (size_t)row * p.MP + col] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);
+  }
+  gLam[e] = x;
+}
+
+// Q <- Phi(Q) + Phi(Q)^T in place (Phi: lower triangle, diagonal halved)
+__global__ __launch_bounds__(256) void k_big_phisym(BigPlan p, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(e / p.MP), j = (int)(e % p.MP);
+  if (j >= i) return;  // diagonal: 2 * (1/2) Q_ii = Q_ii, unchanged
+  ws[p.Q + (size_t)j * p.MP + i] = ws[p.Q + e];
+}
+
+// parameter gradients and the scalars (single block)
+__global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_grads g, double* __restrict__ out,
+                                                    double* __restrict__ ws) {
+  __shared__ double red[17][256];
+  const int tid = threadIdx.x, M = p.M, D = p.D, DP = p.DP;
+  const double* hdr = ws + p.hdr;
+  const double s2 = hdr[H_S2];
+  double acc[17];
+#pragma unroll
+  for (int d = 0; d < 17; ++d) acc[d] = 0.0;
+  for (int j = tid; j < M; j += 256) {
+    const double* Tj = ws + p.T + (size_t)j * BIG_XW;
+    const double* Uj = ws + p.U + (size_t)j * BIG_XW;
+    const double t0 = Tj[2 * DP], cs = Uj[2 * DP];
+    acc[16] += cs + t0;
+    for (int d = 0; d < D; ++d) {
+      const double zj = ws[p.Zs + (size_t)j * DP + d];
+      const double t1 = Tj[d], t2 = Tj[DP + d], R = Uj[d];
+      g.Z[(size_t)j * D + d] = (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d];
+      acc[d] += (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
+    }
+    g.m[j] = ws[p.sv + j] - md.kl_scale * md.m[j];
+  }
+#pragma unroll
+  for (int d = 0; d < 17; ++d) red[d][tid] = acc[d];
+  __syncthreads();
+  if (tid < 17 && (tid < D || tid == 16)) {
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += red[tid][i];
+    if (tid < D) {
+      g.raw_ls[tid] = s * ws[p.ils + tid] * sigmoid_d(md.raw_ls[tid]);
+    } else {
+      double ell = 0.0, etab = 0.0, kls = 0.0;
+      for (int c = 0; c < p.nchunks; ++c) { ell += ws[p.likslot + (size_t)c * p.LS]; etab += ws[p.likslot + (size_t)c * p.LS + 1]; }
+      for (int b = 0; b < BIG_NKL; ++b) kls += ws[p.klpart + b];
+      const double kl = 0.5 * (kls - (double)M);
+      g.raw_os[0] = (ws[p.svb] + s / s2) * hdr[H_SIG_OS];
+      g.log_var_noise[0] = etab;
+      out[0] = ell - kl;
+      out[1] = ell;
+      out[2] = kl;
+      out[3] = 0.0;
+    }
+  }
+  if (g.theta != nullptr)
+    for (int i = tid; i < p.P; i += 256) {
+      double s = 0.0;
+      for (int c = 0; c < p.nchunks; ++c) s += ws[p.likslot + (size_t)c * p.LS + 2 + i];
+      g.theta[i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------------
+#define GEMM(ta, tb, args)                                  \
+  do {                                                      \
+    if (int rc_ = launch_gemm((ta), (tb), (args), st)) return rc_; \
+  } while (0)
+
+static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
+  const int MP = p.MP, nb = MP / 128;
+  const size_t mm = (size_t)MP * MP;
+  hipLaunchKernelGGL(k_big_hdr, dim3(1), dim3(256), 0, st, p, md, ws, status);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_big_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
+  LAUNCH_CHECK();
+  static bool potrf_attr = false;
+  if (!potrf_attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_potrf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)POTRF_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    potrf_attr = true;
+  }
+  double* Lm = ws + p.Lm;
+  double* J = ws + p.J;
+  // blocked right-looking Cholesky (torch.cholesky, dsp/utils.py:239)
+  for (int kb = 0; kb < nb; ++kb) {
+    hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
+    LAUNCH_CHECK();
+    const int rem = MP - (kb + 1) * 128;
+    if (rem > 0) {
+      double* panel = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)kb * 128;
+      const double* Jkk = J + (size_t)kb * 128 * MP + (size_t)kb * 128;
+      // L[i,kb] = K[i,kb] J_kk^T   (in place: each workgroup reads exactly the tile it overwrites)
+      GEMM(false, true, gemm_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 128));
+      // trailing update K[i,j] -= L[i,kb] L[j,kb]^T, lower block triangle
+      double* trail = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)(kb + 1) * 128;
+      GEMM(false, true, gemm_args(panel, MP, panel, MP, trail, MP, rem, rem, 128, -1.0, 1.0, TRI_C_LOWER));
+    }
+  }
+  // block-row inverse: J[i, 0:i] = -J_ii (L[i, 0:i] J[0:i, 0:i])
+  for (int i = 1; i < nb; ++i) {
+    const double* Li = Lm + (size_t)i * 128 * MP;
+    double* tmp = ws + p.tmp;
+    GEMM(false, false, gemm_args(Li, MP, J, MP, tmp, MP, 128, 128 * i, 128 * i, 1.0, 0.0, TRI_B_LOWER));
+    const double* Jii = J + (size_t)i * 128 * MP + (size_t)i * 128;
+    GEMM(false, false, gemm_args(Jii, MP, tmp, MP, J + (size_t)i * 128 * MP, MP, 128, 128 * i, 128, -1.0, 0.0));
+  }
+  if (!train) return 0;
+  hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, st, p, md, ws);
+  LAUNCH_CHECK();
+  // S = Lq Lq^T - I ; H' = J^T S
+  const double* Lq = ws + p.Lq;
+  GEMM(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER));
+  hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, st, ws + p.S_, MP);
+  LAUNCH_CHECK();
+  GEMM(true, false, gemm_args(J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
+  hipLaunchKernelGGL(k_big_wvec, dim3((MP + 255) / 256), dim3(256), 0, st, p, ws);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// forward part of one chunk: Kc, A, B, moments
+static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, double* ws, double* mu, double* v, bool train,
+                             hipStream_t st) {
+  const int MP = p.MP, NC = p.NC;
+  if (train) {
+    hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws);
+  LAUNCH_CHECK();
+  GEMM(false, false, gemm_args(ws + p.J, MP, ws + p.Kc, NC, ws + p.A, NC, MP, NC, MP, 1.0, 0.0, TRI_A_LOWER));
+  GEMM(true, false, gemm_args(ws + p.Lq, MP, ws + p.A, NC, ws + p.B, NC, MP, NC, MP, 1.0, 0.0, TRI_A_UPPER));
+  hipLaunchKernelGGL(k_big_moments, dim3(NC / 64), dim3(256), 0, st, p, ws, mu, v, nrows);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
+                       size_t ws_doubles, hipStream_t st) {
+  BigPlan p;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
+  if (ws_doubles < p.total) return TGP_E_WORKSPACE;
+  if (int rc = big_prepare(p, md, ws, status, false, st)) return rc;
+  for (int ci = 0; ci < p.nchunks; ++ci) {
+    const size_t c0 = (size_t)ci * p.NC;
+    const int nrows = (int)((size_t)p.N - c0 < (size_t)p.NC ? (size_t)p.N - c0 : (size_t)p.NC);
+    if (int rc = big_chunk_forward(p, X + c0 * p.D, nrows, ws, mu + c0, v + c0, false, st)) return rc;
+  }
+  return 0;
+}
+
+int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
+                    double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
+                    uint32_t phases, hipStream_t st) {
+  BigPlan p;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik)) return rc;
+  if (ws_doubles < p.total) return TGP_E_WORKSPACE;
+  const int MP = p.MP, NC = p.NC;
+  const size_t mm = (size_t)MP * MP;
+  if (phases & TGP_PHASE_PREPARE)
+    if (int rc = big_prepare(p, md, ws, status, true, st)) return rc;
+  if (phases & TGP_PHASE_ROWS) {
+    for (int ci = 0; ci < p.nchunks; ++ci) {
+      const size_t c0 = (size_t)ci * NC;
+      const int nrows = (int)((size_t)p.N - c0 < (size_t)NC ? (size_t)p.N - c0 : (size_t)NC);
+      if (int rc = big_chunk_forward(p, X + c0 * p.D, nrows, ws, ws + p.mu + c0, ws + p.v + c0, true, st)) return rc;
+      // likelihood of the chunk: partial (scale*ELL, scale*eta_bar, theta_bar) into this chunk's slot
+      double* slot = ws + p.likslot + (size_t)ci * p.LS;
+      if (md.lik == TGP_LIK_FLOW) {
+        tgp_model mc = md;
+        mc.N = nrows;
+        if (int rc = launch_ell_flow(mc, fp, Y + c0, ws + p.mu + c0, ws + p.v + c0, rowp ? rowp + c0 * md.RP : nullptr, slot,
+                                     ws + p.mub + c0, ws + p.vb + c0, slot + 2, g.rowp ? g.rowp + c0 * md.RP : nullptr,
+                                     ws + p.likws, st))
+          return rc;
+      } else {
+        if (int rc = launch_ell_gauss(Y + c0, ws + p.mu + c0, ws + p.v + c0, nrows, md.log_var_noise, md.scale, slot,
+                                      ws + p.mub + c0, ws + p.vb + c0, ws + p.likws, st))
+          return rc;
+      }
+      // Abar = vbar o (2 Lq B - 2 A) + m mubar^T
+      GemmArgs a3 = gemm_args(ws + p.Lq, MP, ws + p.B, NC, ws + p.Ab, NC, MP, NC, MP, 2.0, 0.0, TRI_A_LOWER);
+      a3.add = ws + p.A; a3.ldadd = NC; a3.gamma = -2.0;
+      a3.col_scale = ws + p.vb + c0; a3.rowv = ws + p.mpad; a3.colv = ws + p.mub + c0;
+      GEMM(false, false, a3);
+      // Kbar = J^T Abar  (into the B buffer)
+      GEMM(true, false, gemm_args(ws + p.J, MP, ws + p.Ab, NC, ws + p.B, NC, MP, NC, MP, 1.0, 0.0, TRI_A_UPPER));
+      // T slabs (+)= (Kbar o Kc) Xaug
+      GemmArgs at = gemm_args(ws + p.B, NC, ws + p.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+      at.a_mul = ws + p.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW;
+      GEMM(false, false, at);
+      // G slabs (+)= A diag(vbar) A^T, lower block triangle
+      GemmArgs ag = gemm_args(ws + p.A, NC, ws + p.A, NC, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
+      ag.k_scale = ws + p.vb + c0; ag.ksplit = BIG_KSG; ag.cz = mm;
+      GEMM(false, true, ag);
+      hipLaunchKernelGGL(k_big_rowdot, dim3(MP / 4 + 1), dim3(256), 0, st, p, ws, c0, ci ? 1 : 0);
+      LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_big_reduce, dim3((unsigned)((mm + (size_t)MP * BIG_XW) / 256)), dim3(256), 0, st, p, ws);
+    LAUNCH_CHECK();
+    if (mu != nullptr) {
+      hipError_t e = hipMemcpyAsync(mu, ws + p.mu, (size_t)p.N * sizeof(double), hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(v, ws + p.v, (size_t)p.N * sizeof(double), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    }
+  }
+  if (phases & TGP_PHASE_BACKWARD) {
+    const unsigned gmm = (unsigned)(mm / 256);
+    // Lbar = -tril(w s^T + 2 H' G)
+    GEMM(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0));
+    hipLaunchKernelGGL(k_big_lbar, dim3(gmm), dim3(256), 0, st, p, ws);
+    LAUNCH_CHECK();
+    // dLam
+    GEMM(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, ws + p.S_, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER));
+    hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, st, p, md, g.Lam, ws);
+    LAUNCH_CHECK();
+    // Q = Phi(L^T Lbar) + Phi(.)^T
+    GEMM(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER));
+    hipLaunchKernelGGL(k_big_phisym, dim3(gmm), dim3(256), 0, st, p, ws);
+    LAUNCH_CHECK();
+    // Kbar_MM = 1/2 J^T Q J
+    GEMM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
+    GEMM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
+    // U = (Kbar_MM o K_MM) Zaug
+    GemmArgs au = gemm_args(ws + p.R1, MP, ws + p.Zaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, MP, 1.0, 0.0);
+    au.a_mul = ws + p.Kmm; au.ksplit = 8; au.cz = (size_t)MP * BIG_XW;
+    GEMM(false, false, au);
+    hipLaunchKernelGGL(k_big_sum_slabs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, ws + p.Tpart, 8,
+                       (size_t)MP * BIG_XW, ws + p.U);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_final, dim3(1), dim3(256), 0, st, p, md, g, out, ws);
+    LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// diagnostic / test entry: plain GEMM on padded operands
+int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+                      int ldb, double beta, double* C, int ldc, hipStream_t st) {
+  return launch_gemm(ta, tb, gemm_args(A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri), st);
+}
+
+}  // namespace tgp

@@ -150,6 +150,58 @@ __device__ __forceinline__ double quad_sum(double x) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// one-wave 16x16 Cholesky + triangular inverse (the serial core of both blocked factorisations)
+// ---------------------------------------------------------------------------------------------------
+// uniform broadcast of lane `src`'s double (src compile-time constant after unrolling)
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) from the hardware estimate v_rsq_f64 plus two Newton steps (y <- y (1.5 - 0.5 d y^2)): the diagonal
+// tile factorisation is ONE serial dependency chain, so the ~40-instruction 1.0/sqrt(d) sequence was its main cost.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// Cholesky of one 16x16 diagonal tile + its inverse, executed by ONE wave; lane i (< 16) owns row i.
+//   in : a[c] = A[i][c] (lower part valid)
+//   out: a[c] = L[i][c] ; x[r] = (L^-1)[r][lane] (column `lane` of the inverse) ; returns first bad pivot (0 = ok)
+__device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], int lane) {
+  double dinv[16];
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double d = bcast_lane(a[k], k);
+    if (!(d > 0.0) && bad == 0) bad = k + 1;  // uniform; also catches NaN
+    const double rinv = rsqrt_nr(d);
+    dinv[k] = rinv;
+    a[k] = (lane == k) ? d * rinv : a[k] * rinv;  // column k of L (rows >= k meaningful)
+#pragma unroll
+    for (int j = k + 1; j < 16; ++j) a[j] = fma(-a[k], bcast_lane(a[k], j), a[j]);  // a_ij -= L_ik L_jk (rows i >= j)
+  }
+  // forward substitution for column `lane` of X = L^-1:  x_i = -(sum_{k<i} L_ik x_k) / L_ii,  x_lane = 1/L_lane,lane
+  // (two partial sums halve the dependent-add chain)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < i; k += 2) {
+      s0 = fma(bcast_lane(a[k], i), x[k], s0);
+      if (k + 1 < i) s1 = fma(bcast_lane(a[k + 1], i), x[k + 1], s1);
+    }
+    x[i] = (lane == i) ? dinv[i] : (lane < i ? -(s0 + s1) * dinv[i] : 0.0);
+  }
+  return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 16x16 output tile of opA(A) * opB(B) over k in [k0,k1) (multiples of 4), operands in global memory,
 // leading dimension ld.  TA: opA = A^T, TB: opB = B^T.  One wave.
 // ---------------------------------------------------------------------------------------------------

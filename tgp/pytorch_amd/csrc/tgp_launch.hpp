@@ -32,6 +32,16 @@ int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* st
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
+// tgp_big.hip (general-M path, 128 < M <= TGP_BIG_MAX_M)
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP);
+int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
+                    double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
+                    uint32_t phases, hipStream_t st);
+int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
+                       size_t ws_doubles, hipStream_t st);
+int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
+                      int ldb, double beta, double* C, int ldc, hipStream_t st);
+
 // tgp_lik.hip
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* log_var_noise,
                      double scale, double* out, double* g_mu, double* g_v, double* ws, hipStream_t st);

@@ -53,7 +53,7 @@ def workspace(N, D, M, S, nblk, P, RP, device):
     if buf is None:
         nbytes = L.load().tgp_workspace_bytes(N, D, M, max(S, 1), nblk, P, RP)
         if nbytes == 0:
-            raise L.TgpError("unsupported problem shape N=%d D=%d M=%d (this build: D<=16, M<=128)" % (N, D, M))
+            raise L.TgpError("unsupported problem shape N=%d D=%d M=%d (this build: D<=16, M<=4096)" % (N, D, M))
         buf = torch.empty(nbytes // 8 + 16, dtype=torch.float64, device=device)
         _ws_cache[key] = buf
     return buf
@@ -288,6 +288,27 @@ def psd_safe_cholesky(A, jitter=None):
             warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
             return Lo, Ap
     raise NotPSDError("matrix not positive definite even with jitter %g" % prev)
+
+
+TRI_A_LOWER, TRI_A_UPPER, TRI_B_LOWER, TRI_B_UPPER, TRI_C_LOWER = 1, 2, 4, 8, 16
+
+
+def gemm(A, B, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, C=None, tri=0):
+    """C = alpha op(A) op(B) + beta C on the float64 matrix cores (tgp_gemm_f64); m, n multiples of 128, k of 16.
+
+    The building block of the M > 128 path: stands in for the reference's torch.bmm / triangular_solve on
+    (M,M)x(M,N) operands (models/sparse_MF_SP.py:354,376-382).  `tri` declares triangular operands (TRI_*)."""
+    A, B = _c(A, "A"), _c(B, "B")
+    m, k = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    k2, n = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if k != k2:
+        raise L.TgpError("gemm: inner dimensions differ (%d vs %d)" % (k, k2))
+    if C is None:
+        C = torch.zeros(m, n, dtype=torch.float64, device=A.device)
+    L.check(L.load().tgp_gemm_f64(int(trans_a), int(trans_b), int(tri), m, n, k, float(alpha), L.ptr(A), A.shape[1],
+                                  L.ptr(B), B.shape[1], float(beta), L.ptr(C), C.shape[1], L.stream_ptr()),
+            "tgp_gemm_f64")
+    return C
 
 
 def kl_whitened(m, Lam):
