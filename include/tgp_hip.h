@@ -152,7 +152,7 @@ int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_
 /* Dense float64 contraction on the matrix cores, the building block of the M > 128 path (the reference's
  * torch.bmm / triangular_solve calls at models/sparse_MF_SP.py:354,376-382 on (M,M)x(M,N) operands):
  *   C = alpha * op(A) op(B) + beta * C, row-major, op = transpose when trans_* != 0.
- * m, n multiples of 128, k a multiple of 16 (callers pad).  `tri` declares triangular operands so that the k range
+ * m, n multiples of 128, k a multiple of 16, lda/ldb even, A and B 16-byte aligned (callers pad).  `tri` declares triangular operands so that the k range
  * is trimmed per output tile: 1 op(A) lower, 2 op(A) upper, 4 op(B) lower, 8 op(B) upper, 16 compute only the
  * lower block triangle of C (flags OR-ed; 0 = general). */
 int tgp_gemm_f64(int32_t trans_a, int32_t trans_b, int32_t tri, int32_t m, int32_t n, int32_t k, double alpha,

@@ -6,10 +6,12 @@
 //
 //   prepare   : K_MM, blocked right-looking Cholesky (128-wide: in-LDS potrf+trtri of the diagonal block, panel and
 //               trailing update as GEMMs), block-row inverse J = L^-1, S = Lq Lq^T, H' = J^T (S - I), w = J^T m, KL
-//   row chunks: rows are processed NC (<= 16384) at a time, matrices laid out [M][NC] (inducing index major):
-//               Kc -> A = J Kc -> B = Lq^T A -> (mu, v) -> likelihood (k_ell_gauss / k_ell_flow) ->
-//               Abar = vbar o (2 Lq B - 2 A) + m mubar^T (GEMM epilogue) -> Kbar = J^T Abar ->
-//               T += (Kbar o Kc) [xs, xs^2, 1]  (split-K GEMM)   G += A diag(vbar) A^T  (split-K SYRK)   s += A mubar
+//   row chunks: rows are processed NC (<= 16384) at a time; the chunk matrices are the TRANSPOSES of the DESIGN.md
+//               operands, laid out [NC][MP] (one data row = 8 KB contiguous), so that the triangular GEMMs stream
+//               contiguous 1 MB row blocks and the two reductions over rows (G, T) read k-major, fully coalesced:
+//               K' = K_NM -> A' = K' J^T -> B' = A' Lq -> (mu, v) -> likelihood (k_ell_gauss / k_ell_flow) ->
+//               Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T (GEMM epilogue) -> Kbar' = Abar' J ->
+//               T += (Kbar' o K')^T [xs, xs^2, 1] (split-K)   G += A'^T diag(vbar) A' (split-K SYRK)   s += A'^T mubar
 //   backward  : Lbar = -tril(w s^T + 2 H' G), Lambar = 2 tril(G Lq) - kl(...), Q = Phi(L^T Lbar) + Phi(.)^T,
 //               Kbar_MM = 1/2 J^T Q J, U = (Kbar_MM o K_MM) [Zs, Zs^2, 1], parameter gradients.
 // Replaces the same reference lines as tgp_mm.hip / tgp_rows.hpp (models/sparse_MF_SP.py:274-431,552-626).
@@ -27,15 +29,16 @@ namespace tgp {
   } while (0)
 
 #define BIG_XW 128    /* width of the augmented coordinate matrices [xs, xs^2, 1, 0...] */
-#define BIG_KSG 8     /* split-K slabs of the G SYRK */
 #define BIG_KST 32    /* split-K slabs of the T statistics GEMM */
 #define BIG_NKL 64    /* KL partial blocks */
+#define BIG_SSL 32    /* row slabs of the s = A'^T mubar partial sums */
 #define BIG_NCMAX 16384
 
 struct BigPlan {
   int N, D, M, S, nblk, P, RP, lik;
   int MP, DP, NC, nchunks, NP, LS;
-  size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb;
+  int ksg;  // split-K slabs of the G SYRK: about two workgroups per CU over the lower block triangle
+  size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb, spart;
   size_t Kmm, Lm, J, Lq, S_, Hp, G, Q, R1, tmp;
   size_t Zaug, U, T, Xaug;
   size_t Kc, A, B, Ab;
@@ -67,6 +70,12 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.NC = (int)rup((size_t)(N + p.nchunks - 1) / p.nchunks, 128);
   p.NP = p.NC * p.nchunks;
   p.LS = (int)rup(2 + P, 8);
+  {
+    const int nb = p.MP / 128, ntiles = nb * (nb + 1) / 2;
+    p.ksg = 512 / ntiles;  // one resident round: two workgroups per CU
+    if (p.ksg < 1) p.ksg = 1;
+    if (p.ksg > 32) p.ksg = 32;
+  }
   size_t o = 0;
   const size_t mm = (size_t)p.MP * p.MP, mn = (size_t)p.MP * p.NC;
   p.hdr = o; o += H_N;
@@ -78,6 +87,7 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.sv = o; o += p.MP;
   p.klpart = o; o += BIG_NKL;
   p.svb = o; o += 16;
+  p.spart = o; o += (size_t)BIG_SSL * p.MP;
   p.Kmm = o; o += mm; p.Lm = o; o += mm; p.J = o; o += mm; p.Lq = o; o += mm; p.S_ = o; o += mm;
   p.Hp = o; o += mm; p.G = o; o += mm; p.Q = o; o += mm; p.R1 = o; o += mm;
   p.tmp = o; o += (size_t)128 * p.MP;
@@ -87,7 +97,7 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.Xaug = o; o += (size_t)p.NC * BIG_XW;
   p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
   p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
-  p.Gpart = o; o += BIG_KSG * mm;
+  p.Gpart = o; o += (size_t)p.ksg * mm;
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
   p.likslot = o; o += (size_t)p.nchunks * p.LS;
   p.likws = o; o += lik_workspace_doubles(p.NC, P, RP);
@@ -104,25 +114,48 @@ size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP
 // ---------------------------------------------------------------------------------------------------
 // GEMM launcher
 // ---------------------------------------------------------------------------------------------------
-int launch_gemm(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
-  if (g.m % GT || g.n % GT || g.k % GK || g.m < 1 || g.n < 1 || g.ksplit < 1) return -1;
+template <bool TA, bool TB, bool MOD, bool EPI>
+static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   static bool attr_done = false;
+  const void* f = reinterpret_cast<const void*>(k_gemm<TA, TB, MOD, EPI>);
   if (!attr_done) {
-    const void* fs[4] = {reinterpret_cast<const void*>(k_gemm<false, false>), reinterpret_cast<const void*>(k_gemm<false, true>),
-                         reinterpret_cast<const void*>(k_gemm<true, false>), reinterpret_cast<const void*>(k_gemm<true, true>)};
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipFuncSetAttribute(fs[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-      if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
-    }
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
     attr_done = true;
   }
-  dim3 grid(g.n / GT, g.m / GT, g.ksplit), block(256);
-  if (ta && tb) hipLaunchKernelGGL((k_gemm<true, true>), grid, block, GEMM_LDS_BYTES, st, g);
-  else if (ta) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, GEMM_LDS_BYTES, st, g);
-  else if (tb) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, GEMM_LDS_BYTES, st, g);
-  else hipLaunchKernelGGL((k_gemm<false, false>), grid, block, GEMM_LDS_BYTES, st, g);
+  const int nj = g.n / GT, nb = g.m / GT;
+  dim3 grid(g.pair ? (nj + 1) / 2 : nj, nb, g.ksplit), block(256);
+  if (g.xcd == 3) grid = dim3(nb * (nb + 1) / 2 * g.ksplit, 1, 1);
+  hipLaunchKernelGGL((k_gemm<TA, TB, MOD, EPI>), grid, block, GEMM_LDS_BYTES, st, g);
   LAUNCH_CHECK();
   return 0;
+}
+
+template <bool MOD, bool EPI>
+static int launch_gemm_l(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
+  if (ta && tb) return launch_gemm_t<true, true, MOD, EPI>(g, st);
+  if (ta) return launch_gemm_t<true, false, MOD, EPI>(g, st);
+  if (tb) return launch_gemm_t<false, true, MOD, EPI>(g, st);
+  return launch_gemm_t<false, false, MOD, EPI>(g, st);
+}
+
+int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  if (g.m % GT || g.n % GT || g.k % GK || g.m < 1 || g.n < 1 || g.ksplit < 1) return -1;
+  if ((g.lda | g.ldb) & 1) return -1;  // 16-byte operand loads
+  if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B) | reinterpret_cast<uintptr_t>(g.a_mul) |
+       reinterpret_cast<uintptr_t>(g.k_scale)) & 15)
+    return -1;
+  if (g.add != nullptr && g.beta != 0.0) return -1;  // the epilogue reads one extra matrix, not two
+  // triangular op(B) without split-K: pair column tiles so that all workgroups run the same number of stages
+  g.pair = ((g.tri & (TRI_B_LOWER | TRI_B_UPPER)) && !(g.tri & (TRI_A_LOWER | TRI_A_UPPER | TRI_C_LOWER)) && g.ksplit == 1 &&
+            g.n / GT > 1) ? 1 : 0;
+  if ((g.tri & TRI_C_LOWER) && g.ksplit > 1 && g.m == g.n && !(g.tri & ~TRI_C_LOWER)) g.xcd = 3;
+  else if (g.xcd == 3) g.xcd = 0;
+  const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
+  const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
+  if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
+  return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -382,86 +415,93 @@ __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __res
   ws[p.Xaug + e] = x;
 }
 
-// Kc[m][n] = s2 exp(-1/2 |xs_n - zs_m|^2); block = 128 columns x 32 inducing rows (2 row groups of 16)
+// K'[n][m] = s2 exp(-1/2 |xs_n - zs_m|^2); block = 32 data rows x 128 inducing columns (2 row groups of 16)
 __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
-  __shared__ double zl[32 * 16];
+  __shared__ double xl[32 * 16];
   const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7, DP = p.DP;
-  const int n = blockIdx.x * 128 + c, m0 = blockIdx.y * 32;
-  for (int i = tid; i < 32 * DP; i += 256) zl[i] = ws[p.Zs + (size_t)m0 * DP + i];
-  const int nc = n < nrows ? n : nrows - 1;
-  double xs[16];
+  const int m = blockIdx.x * 128 + c, n0 = blockIdx.y * 32;
+  for (int i = tid; i < 32 * DP; i += 256) {
+    const int nl = i / DP, d = i % DP;
+    int n = n0 + nl;
+    n = n < nrows ? n : nrows - 1;  // padding rows repeat the last row: finite values, zero adjoints
+    xl[i] = d < p.D ? X[(size_t)n * p.D + d] * ws[p.ils + d] : 0.0;
+  }
+  double zs[16];
 #pragma unroll
-  for (int d = 0; d < 16; ++d) xs[d] = (d < p.D) ? X[(size_t)nc * p.D + d] * ws[p.ils + d] : 0.0;
+  for (int d = 0; d < 16; ++d) zs[d] = d < DP ? ws[p.Zs + (size_t)m * DP + d] : 0.0;
   __syncthreads();
   const double s2 = ws[p.hdr + H_S2];
   double* __restrict__ Kc = ws + p.Kc;
   for (int u = 0; u < 16; ++u) {
-    const int ml = rg * 16 + u, m = m0 + ml;
+    const int nl = rg * 16 + u;
     double d2 = 0.0;
     for (int d = 0; d < DP; ++d) {
-      const double t = xs[d] - zl[ml * DP + d];
+      const double t = xl[nl * DP + d] - zs[d];
       d2 += t * t;
     }
-    Kc[(size_t)m * p.NC + n] = m < p.M ? s2 * exp_fast(-0.5 * d2) : 0.0;
+    Kc[(size_t)(n0 + nl) * p.MP + m] = m < p.M ? s2 * exp_fast(-0.5 * d2) : 0.0;
   }
 }
 
-// mu_n = sum_m m_m A_mn ; v_n = s2 - sum_m A_mn^2 + sum_m B_mn^2   (sparse_MF_SP.py:354-355,376-382)
+// mu_n = sum_m m_m A'_nm ; v_n = s2 - sum_m A'_nm^2 + sum_m B'_nm^2   (sparse_MF_SP.py:354-355,376-382); wave per row
 __global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
                                                       double* __restrict__ v, int nrows) {
-  __shared__ double red[3][4][64];
-  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
-  const int n = blockIdx.x * 64 + c;
-  const double* __restrict__ A = ws + p.A;
-  const double* __restrict__ B = ws + p.B;
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= nrows) return;
+  const double* __restrict__ A = ws + p.A + (size_t)n * p.MP;
+  const double* __restrict__ B = ws + p.B + (size_t)n * p.MP;
   const double* __restrict__ mp = ws + p.mpad;
   double sm = 0.0, sa = 0.0, sb = 0.0;
-  for (int m = g; m < p.MP; m += 4) {
-    const double a = A[(size_t)m * p.NC + n], b = B[(size_t)m * p.NC + n];
-    sm = fma(mp[m], a, sm);
-    sa = fma(a, a, sa);
-    sb = fma(b, b, sb);
+  for (int m = 2 * lane; m < p.MP; m += 128) {
+    const d2 a = *reinterpret_cast<const d2*>(A + m), b = *reinterpret_cast<const d2*>(B + m);
+    const d2 mm_ = *reinterpret_cast<const d2*>(mp + m);
+    sm = fma(mm_[0], a[0], sm); sm = fma(mm_[1], a[1], sm);
+    sa = fma(a[0], a[0], sa); sa = fma(a[1], a[1], sa);
+    sb = fma(b[0], b[0], sb); sb = fma(b[1], b[1], sb);
   }
-  red[0][g][c] = sm; red[1][g][c] = sa; red[2][g][c] = sb;
-  __syncthreads();
-  if (g == 0 && n < nrows) {
-    const double m_ = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    const double a_ = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-    const double b_ = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
-    mu[n] = m_;
-    v[n] = ws[p.hdr + H_S2] - a_ + b_;
+  sm = wave_sum(sm); sa = wave_sum(sa); sb = wave_sum(sb);
+  if (lane == 0) {
+    mu[n] = sm;
+    v[n] = ws[p.hdr + H_S2] - sa + sb;
   }
 }
 
-// s_m (+)= sum_n A[m][n] mubar_n (one wave per inducing row); the extra last block accumulates sum_n vbar_n
-__global__ __launch_bounds__(256) void k_big_rowdot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const double* __restrict__ mub = ws + p.mub + c0;
-  if ((int)blockIdx.x == p.MP / 4) {
-    __shared__ double red[4];
+// s_m partial (+)= sum_{n in row slab} A'[n][m] mubar_n : grid (MP/64, BIG_SSL), block = 64 columns x 4 row phases;
+// block (0, BIG_SSL) accumulates sum_n vbar_n
+__global__ __launch_bounds__(256) void k_big_coldot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+  if ((int)blockIdx.y == BIG_SSL) {
+    if (blockIdx.x != 0) return;
     const double* __restrict__ vb = ws + p.vb + c0;
     double s = 0.0;
     for (int n = tid; n < p.NC; n += 256) s += vb[n];
     s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
+    if (c == 0) red[g][0] = s;
     __syncthreads();
-    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
     return;
   }
-  const int m = blockIdx.x * 4 + wave;
-  const double* __restrict__ A = ws + p.A + (size_t)m * p.NC;
+  const int m = blockIdx.x * 64 + c;
+  const int per = (p.NC + BIG_SSL - 1) / BIG_SSL, n0 = blockIdx.y * per, n1 = min(p.NC, n0 + per);
+  const double* __restrict__ A = ws + p.A;
+  const double* __restrict__ mub = ws + p.mub + c0;
   double s0 = 0.0, s1 = 0.0;
-  int n = lane;
-  for (; n + 64 < p.NC; n += 128) {
-    s0 = fma(A[n], mub[n], s0);
-    s1 = fma(A[n + 64], mub[n + 64], s1);
+  int n = n0 + g;
+  for (; n + 4 < n1; n += 8) {
+    s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
+    s1 = fma(A[(size_t)(n + 4) * p.MP + m], mub[n + 4], s1);
   }
-  for (; n < p.NC; n += 64) s0 = fma(A[n], mub[n], s0);
-  const double s = wave_sum(s0 + s1);
-  if (lane == 0) ws[p.sv + m] = (accumulate ? ws[p.sv + m] : 0.0) + s;
+  for (; n < n1; n += 4) s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
+  red[g][c] = s0 + s1;
+  __syncthreads();
+  if (g == 0) {
+    double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
+    *o = (accumulate ? *o : 0.0) + ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  }
 }
 
-// slab reduction: G (lower -> full symmetric), T; likelihood slots -> hdr[H_ELL], hdr[H_ETAB]
+// slab reduction: G (lower -> full symmetric), T, s
 __global__ __launch_bounds__(256) void k_big_reduce(BigPlan p, double* __restrict__ ws) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t mm = (size_t)p.MP * p.MP;
@@ -469,16 +509,21 @@ __global__ __launch_bounds__(256) void k_big_reduce(BigPlan p, double* __restric
     const int i = (int)(e / p.MP), j = (int)(e % p.MP);
     if (j > i) return;
     double s = 0.0;
-#pragma unroll
-    for (int z = 0; z < BIG_KSG; ++z) s += ws[p.Gpart + z * mm + e];
+    for (int z = 0; z < p.ksg; ++z) s += ws[p.Gpart + z * mm + e];
     ws[p.G + e] = s;
     ws[p.G + (size_t)j * p.MP + i] = s;
   } else {
     const size_t t = e - mm;
-    if (t >= (size_t)p.MP * BIG_XW) return;
-    double s = 0.0;
-    for (int z = 0; z < BIG_KST; ++z) s += ws[p.Tpart + (size_t)z * p.MP * BIG_XW + t];
-    ws[p.T + t] = s;
+    if (t < (size_t)p.MP * BIG_XW) {
+      double s = 0.0;
+      for (int z = 0; z < BIG_KST; ++z) s += ws[p.Tpart + (size_t)z * p.MP * BIG_XW + t];
+      ws[p.T + t] = s;
+    } else if (t < (size_t)p.MP * BIG_XW + p.MP) {
+      const size_t m = t - (size_t)p.MP * BIG_XW;
+      double s = 0.0;
+      for (int z = 0; z < BIG_SSL; ++z) s += ws[p.spart + (size_t)z * p.MP + m];
+      ws[p.sv + m] = s;
+    }
   }
 }
 
@@ -648,11 +693,16 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws);
+  hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws);
   LAUNCH_CHECK();
-  GEMM(false, false, gemm_args(ws + p.J, MP, ws + p.Kc, NC, ws + p.A, NC, MP, NC, MP, 1.0, 0.0, TRI_A_LOWER));
-  GEMM(true, false, gemm_args(ws + p.Lq, MP, ws + p.A, NC, ws + p.B, NC, MP, NC, MP, 1.0, 0.0, TRI_A_UPPER));
-  hipLaunchKernelGGL(k_big_moments, dim3(NC / 64), dim3(256), 0, st, p, ws, mu, v, nrows);
+  // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD
+  GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
+  a1.xcd = 1;
+  GEMM(false, true, a1);
+  GemmArgs a2 = gemm_args(ws + p.A, MP, ws + p.Lq, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+  a2.xcd = 1;
+  GEMM(false, false, a2);
+  hipLaunchKernelGGL(k_big_moments, dim3((nrows + 3) / 4), dim3(256), 0, st, p, ws, mu, v, nrows);
   LAUNCH_CHECK();
   return 0;
 }
@@ -700,25 +750,28 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                                       ws + p.mub + c0, ws + p.vb + c0, ws + p.likws, st))
           return rc;
       }
-      // Abar = vbar o (2 Lq B - 2 A) + m mubar^T
-      GemmArgs a3 = gemm_args(ws + p.Lq, MP, ws + p.B, NC, ws + p.Ab, NC, MP, NC, MP, 2.0, 0.0, TRI_A_LOWER);
-      a3.add = ws + p.A; a3.ldadd = NC; a3.gamma = -2.0;
-      a3.col_scale = ws + p.vb + c0; a3.rowv = ws + p.mpad; a3.colv = ws + p.mub + c0;
-      GEMM(false, false, a3);
-      // Kbar = J^T Abar  (into the B buffer)
-      GEMM(true, false, gemm_args(ws + p.J, MP, ws + p.Ab, NC, ws + p.B, NC, MP, NC, MP, 1.0, 0.0, TRI_A_UPPER));
-      // T slabs (+)= (Kbar o Kc) Xaug
-      GemmArgs at = gemm_args(ws + p.B, NC, ws + p.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
-      at.a_mul = ws + p.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW;
-      GEMM(false, false, at);
-      // G slabs (+)= A diag(vbar) A^T, lower block triangle
-      GemmArgs ag = gemm_args(ws + p.A, NC, ws + p.A, NC, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
-      ag.k_scale = ws + p.vb + c0; ag.ksplit = BIG_KSG; ag.cz = mm;
-      GEMM(false, true, ag);
-      hipLaunchKernelGGL(k_big_rowdot, dim3(MP / 4 + 1), dim3(256), 0, st, p, ws, c0, ci ? 1 : 0);
+      // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T
+      GemmArgs a3 = gemm_args(ws + p.B, MP, ws + p.Lq, MP, ws + p.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
+      a3.add = ws + p.A; a3.ldadd = MP; a3.gamma = -2.0;
+      a3.row_scale = ws + p.vb + c0; a3.rowv = ws + p.mub + c0; a3.colv = ws + p.mpad;
+      a3.xcd = 1;
+      GEMM(false, true, a3);
+      // Kbar' = Abar' J  (into the B' buffer)
+      GemmArgs a4 = gemm_args(ws + p.Ab, MP, ws + p.J, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+      a4.xcd = 1;
+      GEMM(false, false, a4);
+      // T slabs (+)= (Kbar' o K')^T Xaug
+      GemmArgs at = gemm_args(ws + p.B, MP, ws + p.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+      at.a_mul = ws + p.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
+      GEMM(true, false, at);
+      // G slabs (+)= A'^T diag(vbar) A', lower block triangle
+      GemmArgs ag = gemm_args(ws + p.A, MP, ws + p.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
+      ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;
+      GEMM(true, false, ag);
+      hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, p, ws, c0, ci ? 1 : 0);
       LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_big_reduce, dim3((unsigned)((mm + (size_t)MP * BIG_XW) / 256)), dim3(256), 0, st, p, ws);
+    hipLaunchKernelGGL(k_big_reduce, dim3((unsigned)((mm + (size_t)MP * BIG_XW + MP + 255) / 256)), dim3(256), 0, st, p, ws);
     LAUNCH_CHECK();
     if (mu != nullptr) {
       hipError_t e = hipMemcpyAsync(mu, ws + p.mu, (size_t)p.N * sizeof(double), hipMemcpyDeviceToDevice, st);

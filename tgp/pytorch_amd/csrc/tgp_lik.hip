@@ -16,7 +16,7 @@ namespace tgp {
   } while (0)
 
 size_t lik_workspace_doubles(int N, int P, int RP) {
-  const size_t nb = (size_t)(N + 255) / 256 + 1;
+  const size_t nb = (size_t)(N + 63) / 64 + 1;  // k_ell_flow: 64 rows per block
   return nb * (size_t)(2 + P) + 2 * (size_t)P + 64;
 }
 
@@ -78,7 +78,7 @@ __device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), one thread per row
+// TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), four lanes per row
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, const double* __restrict__ Y,
                                                    const double* __restrict__ mu, const double* __restrict__ v,
@@ -96,7 +96,11 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   double* tg = tp + (P + 2) / 2 * 2;                                  // P+2
   for (int i = tid; i < P * 64 + RP * 256; i += 256) accq[i] = 0.0;
   flow_params_lds(md, fp, tp, tg);
-  const int n = blockIdx.x * 256 + tid;
+  // 64 rows per block, 4 lanes per row (lanes l, l^16, l^32, l^48 -- the quad flow_backward_store reduces over);
+  // lane group q takes the quadrature nodes s = q, q+4, ...  Every lane runs the same trip count (cross-lane sums
+  // inside the reverse sweep); nodes past S and padding rows carry weight 0.
+  const int qn = lane >> 4;
+  const int n = blockIdx.x * 64 + wave * 16 + (lane & 15);
   const bool valid = n < md.N;
   const int nc = valid ? n : md.N - 1;
   const double eta = md.log_var_noise[0], einv = exp(-eta);
@@ -104,26 +108,29 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   double ellp = 0.0, etap = 0.0, cm = 0.0, cv = 0.0;
   const double m_ = mu[nc], sq = sqrt(2.0 * v[nc]), y = Y[nc];
   const double* rp = rowp ? rowp + (size_t)nc * RP : nullptr;
-  // every lane runs all S nodes (the reverse sweep sums shared-parameter partials across the 4 lanes of a quad;
-  // here those are 4 different rows, which is what the total over rows needs); padding rows carry weight 0
-  for (int s = 0; s < md.S; ++s) {
-    const double xsn = md.xs[s], wsn = valid ? md.wn[s] : 0.0;
+  for (int s0 = 0; s0 < md.S; s0 += 4) {
+    const int s = s0 + qn, sc = s < md.S ? s : md.S - 1;
+    const double xsn = md.xs[sc], wsn = (valid && s < md.S) ? md.wn[sc] : 0.0;
     double f[1] = {m_ + sq * xsn}, c[1];
     flow_forward_store<1>(F, f, rp, stack + tid, 256);
     const double r = y - f[0];
     ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
     etap += wsn * (-0.5 + 0.5 * einv * r * r);
     c[0] = md.scale * einv * wsn * r;
-    flow_backward_store<1>(F, c, rp, stack + tid, 256, fp.nslots, accq + wave * 16 + (lane & 15), 64, (lane >> 4) == 0,
+    flow_backward_store<1>(F, c, rp, stack + tid, 256, fp.nslots, accq + wave * 16 + (lane & 15), 64, qn == 0,
                            accr + tid, 256);
     cm += c[0];
     cv += c[0] * xsn;
   }
-  if (valid) {
+  cm = quad_sum(cm);
+  cv = quad_sum(cv);
+  for (int j = 0; j < RP; ++j) {
+    const double a = quad_sum(accr[(size_t)j * 256 + tid]);
+    if (valid && qn == 0 && g_rowp) g_rowp[(size_t)n * RP + j] = a;
+  }
+  if (valid && qn == 0) {
     if (g_mu) g_mu[n] = cm;
     if (g_v) g_v[n] = cv / sq;
-    if (g_rowp)
-      for (int j = 0; j < RP; ++j) g_rowp[(size_t)n * RP + j] = accr[(size_t)j * 256 + tid];
   }
   ellp = wave_sum(ellp); etap = wave_sum(etap);
   if (lane == 0) { red[wave] = ellp; red[4 + wave] = etap; }
@@ -284,7 +291,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
   if (int rc = flow_lds(md, fp.nslots, &lds)) return rc;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
-  const int nb = (md.N + 255) / 256;
+  const int nb = (md.N + 63) / 64;
   hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);

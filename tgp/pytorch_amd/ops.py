@@ -355,7 +355,7 @@ def ell_flow(Y, mu, v, lvn, flow, theta, S, rowp=None, scale=1.0):
     theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
     dev, N = Y.device, Y.numel()
     md, keep = _flow_model(N, S, flow, theta, lvn, dev, scale)
-    nws = (N // 256 + 2) * (2 + flow.P) + 2 * flow.P + 128
+    nws = (N // 64 + 2) * (2 + flow.P) + 2 * flow.P + 128
     ws = torch.empty(nws, dtype=torch.float64, device=dev)
     out = torch.empty(2, dtype=torch.float64, device=dev)
     gmu, gv = torch.empty_like(mu), torch.empty_like(v)
