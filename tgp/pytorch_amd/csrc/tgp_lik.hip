@@ -48,12 +48,24 @@ __global__ __launch_bounds__(256) void k_ell_gauss(const double* __restrict__ Y,
   }
 }
 
-// sum `nb` partial vectors of length `len` (stride len) into out; single block
+// sum `nb` partial vectors of length `len` (stride len) into out[0..split) / out2; block = 32 columns x 8 row groups
 __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int nb, int len,
                                                     double* __restrict__ out, double* __restrict__ out2, int split) {
-  for (int j = threadIdx.x; j < len; j += 256) {
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[(size_t)b * len + j];
+  __shared__ double red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5, j = blockIdx.x * 32 + c;
+  double s0 = 0.0, s1 = 0.0;
+  if (j < len) {
+    int b = g;
+    for (; b + 8 < nb; b += 16) {
+      s0 += part[(size_t)b * len + j];
+      s1 += part[(size_t)(b + 8) * len + j];
+    }
+    if (b < nb) s0 += part[(size_t)b * len + j];
+  }
+  red[g][c] = s0 + s1;
+  __syncthreads();
+  if (g == 0 && j < len) {
+    const double s = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
     if (j < split) out[j] = s;
     else if (out2) out2[j - split] = s;
   }
@@ -294,7 +306,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
   const int nb = (md.N + 63) / 64;
   hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);
+  hipLaunchKernelGGL(k_sum_parts, dim3((2 + md.P + 31) / 32), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);
   LAUNCH_CHECK();
   return 0;
 }
