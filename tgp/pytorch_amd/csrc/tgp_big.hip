@@ -339,7 +339,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
             if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
-            Dt[j * 256 + c * 16 + lane] = x[c];
+            Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
           }
         }
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;

@@ -174,29 +174,27 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 //   in : a[c] = A[i][c] (lower part valid)
 //   out: a[c] = L[i][c] ; x[r] = (L^-1)[r][lane] (column `lane` of the inverse) ; returns first bad pivot (0 = ok)
 __device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], int lane) {
-  double dinv[16];
   int bad = 0;
+  // Row k of X = L^-1 needs only L[k][0..k-1] (final after pivot k-1), the rows of X above it and 1/L_kk, so it is
+  // formed inside step k: its dot product is independent of the pivot's rsqrt/Newton chain and of the rank-1 update,
+  // and the fully unrolled code lets the scheduler interleave the two dependency chains (the factorisation alone
+  // sets the latency; the inverse rides in its shadow).
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const double d = bcast_lane(a[k], k);
     if (!(d > 0.0) && bad == 0) bad = k + 1;  // uniform; also catches NaN
     const double rinv = rsqrt_nr(d);
-    dinv[k] = rinv;
+    // x_k = -(sum_{m<k} L_km x_m) / L_kk for column `lane` (two partial sums halve the dependent-add chain)
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < k; m += 2) {
+      s0 = fma(bcast_lane(a[m], k), x[m], s0);
+      if (m + 1 < k) s1 = fma(bcast_lane(a[m + 1], k), x[m + 1], s1);
+    }
+    x[k] = (lane == k) ? rinv : (lane < k ? -(s0 + s1) * rinv : 0.0);
     a[k] = (lane == k) ? d * rinv : a[k] * rinv;  // column k of L (rows >= k meaningful)
 #pragma unroll
     for (int j = k + 1; j < 16; ++j) a[j] = fma(-a[k], bcast_lane(a[k], j), a[j]);  // a_ij -= L_ik L_jk (rows i >= j)
-  }
-  // forward substitution for column `lane` of X = L^-1:  x_i = -(sum_{k<i} L_ik x_k) / L_ii,  x_lane = 1/L_lane,lane
-  // (two partial sums halve the dependent-add chain)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int k = 0; k < i; k += 2) {
-      s0 = fma(bcast_lane(a[k], i), x[k], s0);
-      if (k + 1 < i) s1 = fma(bcast_lane(a[k + 1], i), x[k + 1], s1);
-    }
-    x[i] = (lane == i) ? dinv[i] : (lane < i ? -(s0 + s1) * dinv[i] : 0.0);
   }
   return bad;
 }

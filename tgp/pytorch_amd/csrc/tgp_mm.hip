@@ -132,8 +132,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   double tph[4] = {0, 0, 0, 0};
   unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
 #define PSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tph[i] += (double)(tn_ - tlast); tlast = tn_; } while (0)
+  double twv[5] = {0, 0, 0, 0, 0};
+  unsigned long long twl = 0;
+#define WSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) twv[i] += (double)(tn_ - twl); twl = tn_; } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
+#define WSTAMP(i) do { } while (0)
 #endif
   const int LD = MP + 1;
   double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
@@ -241,18 +245,22 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
           }
           __builtin_amdgcn_wave_barrier();
         } else {
+          WSTAMP(0);
           panel_tile(j, j - 1);
           __builtin_amdgcn_wave_barrier();
+          WSTAMP(1);
           const d4 upd = ll_sum(j0, j0, j0);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
           __builtin_amdgcn_wave_barrier();
+          WSTAMP(2);
         }
         double a[16], x[16];
         const int li = lane & 15;
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
         const int bad = potrf_trtri16(a, x, li);
+        WSTAMP(3);
         if (lane < 16) {
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
             Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
           }
         }
+        WSTAMP(4);
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
       }
     } else if (j == 0) {
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < 4; ++i) ws[p.hdr + H_STAMP + 12 + i] = tph[i];
     ws[p.hdr + H_STAMP + 16] = (double)(tn_ - tlast);
+    for (int i = 1; i < 5; ++i) ws[p.hdr + H_STAMP + 18 + i] = twv[i];  // wave-0 chain, shader cycles summed over block columns
   }
 #endif
 }
