@@ -147,16 +147,17 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   __shared__ double s_ils[16];
   if (tid == 0) { s_info = 0; s_nan = 0; }
   if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
-  __syncthreads();
   const double s2 = softplus_d(md.raw_os[0]);
   const bool zl = p.zs_lds != 0;
   if (zl) {
+    // every thread transforms the lengthscale it needs itself: the Z and raw_ls loads go out together and the
+    // set-up pays one memory round trip and one barrier instead of two of each
     for (int i = tid; i < MP * DP; i += PREP_THREADS) {
       const int mrow = i / DP, d = i % DP;
-      zs[i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * s_ils[d] : 0.0;
+      zs[i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * (1.0 / softplus_d(md.raw_ls[d])) : 0.0;
     }
-    __syncthreads();
   }
+  __syncthreads();
   // K_MM element (lower triangle only: the factorisation never reads above the diagonal; the strict-upper TILES later
   // receive J^T); identity on the padding keeps L and L^-1 well defined
   bool has_nan = false;
@@ -229,19 +230,33 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
   };
 
+  // Rows [r0, r1) of K_MM column block c (16 columns) by waves 1..7.  Block c is first read at iteration c (its
+  // diagonal tile, by wave 0) and c+1 (the rest), so each piece is filled one iteration ahead, in the shadow of the
+  // critical chain, instead of all of K_MM before the first pivot.
+  auto fill_block = [&](int c, int r0, int r1) {
+    const int n = (r1 - r0) * 16;
+    for (int e = tid - 64; e < n; e += PREP_THREADS - 64) {
+      const int rr = r0 + (e >> 4), cc = 16 * c + (e & 15);
+      if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
+    }
+  };
   // ---- blocked Cholesky + inverse with LOOKAHEAD, one barrier per block column --------------------------------------
   // iteration j:  wave 0 (the critical chain)  : panel tile (j, j-1) of step j-1, diagonal update, potrf + trtri of tile j
-  //               waves 1..7 (off the chain)   : iteration 0: fill K_MM below tile (0,0);
+  //               waves 1..7 (off the chain)   : iteration 0: fill K_MM column block 0 below tile (0,0) and tile (1,1);
   //                                              iteration j >= 1: the other panel tiles (i > j, j-1) and the inverse
-  //                                              tiles (j-1, c < j-1) of step j-1
+  //                                              tiles (j-1, c < j-1) of step j-1, then K_MM column block j below its diagonal tile and tile (j+1,j+1)
   for (int j = 0; j <= MT; ++j) {
     const int j0 = 16 * j;
     if (wave == 0) {
       if (j < MT) {
         if (j == 0) {
-          for (int e = lane; e < 256; e += 64) {
-            const int rr = e >> 4, cc = e & 15;
-            if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
+          double kv[4];  // four independent exp chains per lane, no branch between them
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kv[u] = kmm_elem((lane + 64 * u) >> 4, lane & 15);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int rr = (lane + 64 * u) >> 4, cc = lane & 15;
+            if (cc <= rr) A[rr * LD + cc] = kv[u];
           }
           __builtin_amdgcn_wave_barrier();
         } else {
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
       }
     } else if (j == 0) {
-      for (int rr = 16 + (wave - 1); rr < MP; rr += PREP_THREADS / 64 - 1)
-        for (int cc = lane; cc <= rr; cc += 64) A[rr * LD + cc] = kmm_elem(rr, cc);
+      fill_block(0, 16, MP);  // tile (0,0) is wave 0's
+      if (MT > 1) fill_block(1, 16, 32);
     } else {
       // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2  (at most MT-2 <= 6 tiles for 7 waves)
       const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
@@ -281,6 +296,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         if (t < npanel) panel_tile(j + 1 + t, j - 1);
         else inv_tile(j - 1, t - npanel);
       }
+      if (j < MT) fill_block(j, 16 * (j + 1), MP);                      // rest of block j: read from iteration j+1 on
+      if (j + 1 < MT) fill_block(j + 1, 16 * (j + 1), 16 * (j + 2));     // diagonal tile (j+1, j+1): wave 0, iteration j+1
     }
     __syncthreads();
     PSTAMP(j < 4 ? j : 3);
