@@ -61,3 +61,16 @@ def test_product_path_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle in oracle/", ""), fn
+
+
+def test_workspace_query_covers_both_paths(lib):
+    """tgp_workspace_bytes is host-only: sizes for the fused (M <= 128) and the general-M plan, monotone in N."""
+    lib.tgp_workspace_bytes.restype = ctypes.c_size_t
+    small = lib.tgp_workspace_bytes(8611, 4, 128, 32, 6, 30, 0)
+    big = lib.tgp_workspace_bytes(8611, 4, 129, 32, 6, 30, 0)
+    assert 0 < small < big
+    assert lib.tgp_workspace_bytes(250000, 8, 1000, 32, 5, 130, 0) < 2 * 1024 ** 3      # C5 shard: < 2 GiB of 288 GB
+    assert lib.tgp_workspace_bytes(20000, 8, 1000, 32, 5, 130, 0) >= lib.tgp_workspace_bytes(10000, 8, 1000, 32, 5, 130, 0)
+    lib.tgp_gemm_f64.restype = ctypes.c_int
+    assert lib.tgp_gemm_f64(0, 0, 0, 100, 128, 16, ctypes.c_double(1.0), None, 128, None, 128, ctypes.c_double(0.0), None,
+                            128, None) == -4      # m not a multiple of 128: refused before touching the device
