@@ -66,6 +66,12 @@ extern "C" {
 #define TGP_LIK_GAUSS 0 /* GaussianLinearMean.expected_log_prob, likelihoods/GaussianLinearMean.py:60-87       */
 #define TGP_LIK_FLOW 1  /* GaussianNonLinearMean.expected_log_prob, likelihoods/GaussianNonLinearMean.py:64-150 */
 
+/* covariance function: instance_kernel(name, ...) of models/utils_models.py:145-204 (gpytorch kernels, ARD, softplus
+ * parameters).  RBF: s2 exp(-r^2/2);  MATERN32: s2 (1 + sqrt3 r) exp(-sqrt3 r), r = sqrt(max(r^2, 1e-30)) as gpytorch's
+ * covar_dist clamps it.  MATERN32 always runs on the general (tiled-GEMM) path. */
+#define TGP_KERNEL_SCALE_RBF 0      /* 'scale_rbf'      utils_models.py:188-193 (what main.py:229 uses) */
+#define TGP_KERNEL_SCALE_MATERN32 1 /* 'scale_matern32' utils_models.py:199-204                          */
+
 typedef struct tgp_model {
   int32_t N;       /* rows in this call (this rank's shard of the minibatch)            */
   int32_t D;       /* input dimension (<= 16)                                           */
@@ -75,6 +81,8 @@ typedef struct tgp_model {
   int32_t P;       /* shared flow scalars in theta                                      */
   int32_t RP;      /* per-row flow parameter columns in rowp                            */
   int32_t lik;     /* TGP_LIK_*                                                         */
+  int32_t kernel;  /* TGP_KERNEL_*                                                      */
+  int32_t reserved0;
   double scale;    /* N_total / MB_global: sparse_MF_SP.ELL, models/sparse_MF_SP.py:623-626 */
   double jitter;   /* added to diag(K_MM) before the Cholesky (0 unless retrying)       */
   double kl_scale; /* weight of the KL gradient in this call: 1/world_size so that an
@@ -108,6 +116,9 @@ const char* tgp_last_error(void);
 
 /* Bytes of workspace the calls below need for a problem of this shape (training is the maximum). */
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP);
+/* Same for a given covariance function (tgp_workspace_bytes == TGP_KERNEL_SCALE_RBF). */
+size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
+                                  int32_t kernel);
 
 /* One fused ELBO evaluation with gradients: replaces sparse_MF_SP.ELBO (models/sparse_MF_SP.py:552-598)
  * + loss.backward() (trainers/trainer_base.py:341) for one minibatch shard.
@@ -138,6 +149,10 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
  * models/utils_models.py:188-193, called at models/sparse_MF_SP.py:316.  K (M,M). */
 int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,
                 double* K, void* stream);
+/* Same with the covariance function selected (TGP_KERNEL_*); X2 == NULL: K(X1, X1) + jitter I (N2 ignored),
+ * else K(X1, X2) of shape (N1, N2). */
+int tgp_kernel_matrix_f64(int32_t kernel, const double* X1, int32_t N1, const double* X2, int32_t N2, int32_t D,
+                          const double* raw_ls, const double* raw_os, double jitter, double* K, void* stream);
 
 /* K_NM assembly (models/sparse_MF_SP.py:319); K (N,M).  Diagnostic/next-row use: the training path
  * never materialises K_NM. */

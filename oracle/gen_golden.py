@@ -46,13 +46,13 @@ IP = {"variational_distribution": {"variance_scale": 1e-5, "mean_scale": 0.0}}
 KINIT = {"length_scale": 2.0, "kernel_scale": 2.0, "noisy_variance": 1e-6}
 
 
-def build_reference_model(prob, flow):
+def build_reference_model(prob, flow, kernel="scale_rbf"):
     """Instantiate the reference's model classes and overwrite their parameters with prob['params']."""
     X, p = prob["X"], prob["params"]
     N, D = X.shape
     M = p["Z"].shape[0]
     S = prob["xs"].shape[0]
-    K = instance_kernel("scale_rbf", ard_num_dim=D, num_multioutput=1, kernel_is_shared=False, init_params=KINIT)
+    K = instance_kernel(kernel, ard_num_dim=D, num_multioutput=1, kernel_is_shared=False, init_params=KINIT)
     if flow is None:
         lik = GaussianLinearMean(out_dim=1, noise_init=0.05, noise_is_shared=False)
         model = sparse_MF_GP(["zero", K], X, p["Z"].clone(), N, lik, 1, True, False, False, False, False, 0.0,
@@ -104,10 +104,10 @@ def load_theta(model, program, theta):
         prm.data = val.clone().reshape(())
 
 
-def reference_step0(prob, flow, name):
+def reference_step0(prob, flow, name, kernel="scale_rbf"):
     """ELBO/ELL/KLD + q(f) moments + every gradient from the reference model."""
     torch.manual_seed(0)
-    model = build_reference_model(prob, flow)
+    model = build_reference_model(prob, flow, kernel)
     model.set_is_training(True)
     X, Y, p = prob["X"], prob["Y"], prob["params"]
     captured = {}
@@ -135,6 +135,8 @@ def reference_step0(prob, flow, name):
     }
     for k, v in p.items():
         out["p_" + k] = v
+    if kernel != "scale_rbf":
+        out["kernel"] = np.array(kernel)
     if flow is not None:
         out["program"] = np.array(prob["program"], dtype=np.int32)
         out["g_theta"] = torch.stack([q.grad.reshape(()) for q in flow_scalar_params(model, prob["program"])])
@@ -202,7 +204,21 @@ def save(name, d):
     print("wrote", name, {k: a.shape for k, a in list(arrs.items())[:4]}, "...")
 
 
+def matern_fixtures():
+    """'scale_matern32' (utils_models.py:199-204; main.py never selects it): the reference's model classes run
+    unmodified on top of the builder-written gpytorch stand-in for MaternKernel (third-party arithmetic: unpinned)."""
+    for name, kw in (("tiny_matern_svgp", dict(N=64, D=3, M=8, S=8, flow=None)),
+                     ("med_matern_sal2", dict(N=512, D=4, M=60, S=16, flow="sal2")),
+                     ("med_matern_tanh2x2", dict(N=300, D=6, M=40, S=12, flow="tanh2x2"))):
+        prob = orc.synthetic_problem(kw["N"], kw["D"], kw["M"], seed=0, flow=kw["flow"], S=kw["S"])
+        reference_step0(prob, kw["flow"], name, kernel="scale_matern32")
+
+
 def main():
+    if "--matern-only" in sys.argv:
+        matern_fixtures()
+        return
+    matern_fixtures()
     cases = [
         ("tiny_svgp", dict(N=64, D=3, M=8, S=8, flow=None)),
         ("tiny_sal2", dict(N=64, D=3, M=8, S=8, flow="sal2")),

@@ -50,9 +50,37 @@ class RBFKernel(Kernel):
 
 
 class MaternKernel(RBFKernel):
+    """gpytorch 1.1.1 MaternKernel.forward (autograd branch): inputs centred on the mean of x1, divided by the
+    lengthscale, distance = sqrt(clamp(sq_dist, 1e-30)), exp(-sqrt(2 nu) d) times the nu-dependent polynomial."""
+
     def __init__(self, nu=1.5, **kwargs):
         super().__init__(**kwargs)
+        if nu not in (0.5, 1.5, 2.5):
+            raise RuntimeError("nu expected to be 0.5, 1.5, or 2.5")
         self.nu = nu
+
+    def forward(self, x1, x2, diag=False, **params):
+        import math
+        mean = x1.reshape(-1, x1.size(-1)).mean(0)[(None,) * (x1.dim() - 1)]
+        a = (x1 - mean) / self.lengthscale
+        b = (x2 - mean) / self.lengthscale
+        if diag:
+            d = (a - b).pow(2).sum(-1).clamp_min(1e-30).sqrt()
+        else:
+            shift = a.mean(-2, keepdim=True)
+            a = a - shift
+            b = b - shift
+            sq = a.pow(2).sum(-1, keepdim=True) - 2.0 * a.matmul(b.transpose(-2, -1)) \
+                + b.pow(2).sum(-1, keepdim=True).transpose(-2, -1)
+            d = sq.clamp_min(1e-30).sqrt()
+        e = torch.exp(-math.sqrt(self.nu * 2) * d)
+        if self.nu == 0.5:
+            c = 1
+        elif self.nu == 1.5:
+            c = (math.sqrt(3) * d).add(1)
+        else:
+            c = (math.sqrt(5) * d).add(1).add(5.0 / 3.0 * d ** 2)
+        return c * e
 
 
 class ScaleKernel(Kernel):

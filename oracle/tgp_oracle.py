@@ -78,6 +78,26 @@ def scale_rbf(X1, X2, raw_lengthscale, raw_outputscale):
     return softplus(raw_outputscale).reshape(()) * torch.exp(-0.5 * sq.clamp_min(0.0))
 
 
+def scale_matern32(X1, X2, raw_lengthscale, raw_outputscale):
+    """sigma^2 (1 + sqrt3 r) exp(-sqrt3 r): gpytorch 1.1.1 ScaleKernel(MaternKernel(nu=1.5, ard)) as built by
+    instance_kernel('scale_matern32'), utils_models.py:199-204 (third party: mean-centred inputs, the distance is
+    sqrt(clamp(sq_dist, 1e-30)) with the same centred expansion as the RBF)."""
+    ls = softplus(raw_lengthscale).reshape(1, -1)
+    mean = X1.reshape(-1, X1.shape[-1]).mean(0, keepdim=True)
+    a = (X1 - mean) / ls
+    b = (X2 - mean) / ls
+    shift = a.mean(-2, keepdim=True)
+    a = a - shift
+    b = b - shift
+    sq = a.pow(2).sum(-1, keepdim=True) - 2.0 * a.matmul(b.transpose(-2, -1)) \
+        + b.pow(2).sum(-1, keepdim=True).transpose(-2, -1)
+    r = sq.clamp_min(1e-30).sqrt()
+    return softplus(raw_outputscale).reshape(()) * (1.0 + math.sqrt(3.0) * r) * torch.exp(-math.sqrt(3.0) * r)
+
+
+KERNELS = {"scale_rbf": scale_rbf, "scale_matern32": scale_matern32}
+
+
 def scale_rbf_diag(X, raw_outputscale):
     """kernel(X, diag=True) == outputscale for a stationary kernel (sparse_MF_SP.py:313)."""
     return softplus(raw_outputscale).reshape(()) * torch.ones(X.shape[:-1], dtype=X.dtype)
@@ -114,13 +134,14 @@ def psd_safe_cholesky(A, jitter=None, constant_jitter=None):
 
 
 # ---- q(f) marginals -- sparse_MF_SP.py:274-396 (whitened, diagonal) -------------------------------
-def qf_moments(X, Z, raw_lengthscale, raw_outputscale, m, Lam, jitter=None):
+def qf_moments(X, Z, raw_lengthscale, raw_outputscale, m, Lam, jitter=None, kernel="scale_rbf"):
     """mu_n, v_n of q(f_n).  X (N,D), Z (M,D), m (M,), Lam (M,M) dense (tril applied at use).
     Keeps the reference's sequence: K_xx diag, K_zz, K_xz, chol, tril mask, S = Lq Lq^T,
     triangular_solve(m, L^T), cholesky_solve(K_zx, L), triangular_solve(K_zx, L)."""
-    K_xx = scale_rbf_diag(X, raw_outputscale)                                   # :313
-    K_zz = scale_rbf(Z, Z, raw_lengthscale, raw_outputscale)                    # :316
-    K_xz = scale_rbf(X, Z, raw_lengthscale, raw_outputscale)                    # :319
+    kfun = KERNELS[kernel]
+    K_xx = scale_rbf_diag(X, raw_outputscale)                                   # :313 (k(x,x) = sigma^2 for both kernels)
+    K_zz = kfun(Z, Z, raw_lengthscale, raw_outputscale)                         # :316
+    K_xz = kfun(X, Z, raw_lengthscale, raw_outputscale)                         # :319
     K_zx = K_xz.transpose(-2, -1)                                               # :327
     L, _, _ = psd_safe_cholesky(K_zz, jitter=jitter)                            # :330
     mask = torch.ones(Lam.shape[-2:], dtype=Lam.dtype).tril(0)                  # :344
@@ -226,11 +247,11 @@ def ell_flow(Y, mu, v, log_var_noise, program, theta, xs, ws, rowp=None):
 
 # ---- ELBO -- sparse_MF_SP.py:552-626 --------------------------------------------------------------
 def elbo(X, Y, Z, raw_lengthscale, raw_outputscale, m, Lam, log_var_noise, N_total,
-         program=None, theta=None, xs=None, ws=None, rowp=None, jitter=None):
+         program=None, theta=None, xs=None, ws=None, rowp=None, jitter=None, kernel="scale_rbf"):
     """Returns (ELBO, ELL, KLD) as 0-d tensors.  program=None -> SVGP closed form (sparse_MF_GP)."""
     Xr = X.repeat(1, 1, 1)[0]                                                       # :565 (Dy = 1)
     kl = kld_whitened(m, Lam)                                                       # :571
-    mu, v = qf_moments(Xr, Z, raw_lengthscale, raw_outputscale, m, Lam, jitter)     # :580
+    mu, v = qf_moments(Xr, Z, raw_lengthscale, raw_outputscale, m, Lam, jitter, kernel)   # :580
     y = Y.reshape(-1)
     if program is None:
         ell = ell_gauss(y, mu, v, log_var_noise)
@@ -240,7 +261,7 @@ def elbo(X, Y, Z, raw_lengthscale, raw_outputscale, m, Lam, log_var_noise, N_tot
     return ell - kl, ell, kl                                                        # :590-598
 
 
-def elbo_and_grads(X, Y, params, N_total, program=None, xs=None, ws=None, rowp=None):
+def elbo_and_grads(X, Y, params, N_total, program=None, xs=None, ws=None, rowp=None, kernel="scale_rbf"):
     """params: dict with Z, raw_lengthscale, raw_outputscale, m, Lam, log_var_noise[, theta].
     Returns ((ELBO, ELL, KLD), grads dict) -- autograd, like the reference (trainer_base.py:341)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
@@ -248,7 +269,7 @@ def elbo_and_grads(X, Y, params, N_total, program=None, xs=None, ws=None, rowp=N
     if rowp is not None:
         rp = rowp.detach().clone().requires_grad_(True)
     out = elbo(X, Y, leaves["Z"], leaves["raw_lengthscale"], leaves["raw_outputscale"], leaves["m"],
-               leaves["Lam"], leaves["log_var_noise"], N_total, program, leaves.get("theta"), xs, ws, rp)
+               leaves["Lam"], leaves["log_var_noise"], N_total, program, leaves.get("theta"), xs, ws, rp, kernel=kernel)
     out[0].backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     if rp is not None:

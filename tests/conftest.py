@@ -24,12 +24,15 @@ def load_golden(name):
         a = z[k]
         if k == "program":
             out[k] = [tuple(int(t) for t in row) for row in a]
+        elif k == "kernel":
+            out[k] = str(a)
         elif a.dtype.kind == "f":
             out[k] = torch.from_numpy(np.array(a, dtype=np.float64))
         else:
             out[k] = torch.from_numpy(np.array(a))
     out["params"] = {k[2:]: out[k] for k in out if k.startswith("p_")}
     out.setdefault("program", None)
+    out.setdefault("kernel", "scale_rbf")
     return out
 
 

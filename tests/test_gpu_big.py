@@ -68,12 +68,13 @@ def test_gemm_triangular_trimming():
                 assert float((blk - 7.0).abs().max()) == 0.0
 
 
-def _oracle_case(N, D, M, flow, S, seed=3):
+def _oracle_case(N, D, M, flow, S, seed=3, kernel="scale_rbf"):
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(N, D, M, seed=seed, flow=flow, S=S)
     (elbo, ell, kld), og = orc.elbo_and_grads(prob["X"], prob["Y"], prob["params"], prob["N_total"], prob["program"],
-                                              prob["xs"], prob["ws"], prob["rowp"])
+                                              prob["xs"], prob["ws"], prob["rowp"], kernel=kernel)
     g = dict(prob)
+    g["kernel"] = kernel
     g.update(ELBO=elbo, ELL=ell, KLD=kld, g_Z=og["Z"], g_raw_lengthscale=og["raw_lengthscale"],
              g_raw_outputscale=og["raw_outputscale"], g_m=og["m"], g_Lam=og["Lam"], g_log_var_noise=og["log_var_noise"])
     if "theta" in og:
@@ -91,6 +92,64 @@ def test_big_elbo_step_matches_oracle(N, D, M, flow, S):
     assert int(status[0]) == 0 and int(status[1]) == 0
     compare(out, grads, g)
     assert float(torch.triu(grads["Lam"], 1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["tiny_matern_svgp", "med_matern_sal2", "med_matern_tanh2x2"])
+def test_matern32_matches_reference_fixture(name):
+    """'scale_matern32' runs on the general path whatever M is; fixtures from the reference's model classes."""
+    from conftest import load_golden
+    g = load_golden(name)
+    out, grads, status, (mu, v) = run_hip(g)
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    compare(out, grads, g)
+    assert rel_err(mu, g["mu"]) < 1e-9
+    assert float(((v - g["v"]).abs() / g["v"].abs()).max()) < 1e-6
+
+
+@pytest.mark.parametrize("N,D,M,flow,S", [(400, 5, 150, "sal2", 16), (300, 8, 20, "tanh3x2", 8), (500, 3, 260, None, 8)])
+def test_matern32_matches_oracle(N, D, M, flow, S):
+    g = _oracle_case(N, D, M, flow, S, seed=6, kernel="scale_matern32")
+    out, grads, status, _ = run_hip(g)
+    assert int(status[0]) == 0
+    compare(out, grads, g)
+
+
+def test_matern32_kernel_matrix_and_model_class():
+    """instance_kernel('scale_matern32') -> ScaleKernel(MaternKernel): dense K through tgp_kernel_matrix_f64 and one
+    ELBO + backward through the model class, against the oracle."""
+    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd import config as cg
+    from tgp.pytorch_amd.kernels import instance_kernel
+    from tgp.pytorch_amd.likelihoods import GaussianLinearMean
+    from tgp.pytorch_amd.models import sparse_MF_GP
+    dev = _dev()
+    cg.set_maximum_precission()
+    prob = orc.synthetic_problem(200, 4, 30, seed=8, flow=None, S=8)
+    p = prob["params"]
+    K = instance_kernel("scale_matern32", ard_num_dim=4, num_multioutput=1, kernel_is_shared=False,
+                        init_params={"length_scale": 2.0, "kernel_scale": 2.0}).to(dev)
+    with torch.no_grad():
+        K.raw_outputscale.data = p["raw_outputscale"].reshape(1).to(dev)
+        K.base_kernel.raw_lengthscale.data = p["raw_lengthscale"].reshape(1, 1, 4).to(dev)
+    Kd = K(prob["X"].to(dev), p["Z"].to(dev)).evaluate()
+    ref = orc.scale_matern32(prob["X"], p["Z"], p["raw_lengthscale"], p["raw_outputscale"])
+    assert rel_err(Kd.cpu(), ref) < 1e-12
+    lik = GaussianLinearMean(out_dim=1, noise_init=0.05, noise_is_shared=False)
+    model = sparse_MF_GP(["zero", K], prob["X"].to(dev), p["Z"].clone().to(dev), 200, lik, 1, True, False, False, False,
+                         False, 0.0, init_params={"variational_distribution": {"variance_scale": 1e-5, "mean_scale": 0.0}})
+    model = model.to(dev)
+    with torch.no_grad():
+        model.q_U.variational_mean.data = p["m"].reshape(1, -1).to(dev)
+        model.q_U.chol_variational_covar.data = p["Lam"].reshape(1, 30, 30).to(dev)
+        model.likelihood.log_var_noise.data = p["log_var_noise"].reshape(1, 1).to(dev)
+    elbo, ell, kld = model.ELBO(prob["X"].to(dev), prob["Y"].to(dev))
+    elbo.backward()
+    (e_o, l_o, k_o), og = orc.elbo_and_grads(prob["X"], prob["Y"], p, prob["N_total"], None, prob["xs"], prob["ws"], None,
+                                             kernel="scale_matern32")
+    assert rel_err(elbo.detach().cpu(), e_o) < 1e-9
+    assert rel_err(model.Z.grad[0].cpu(), og["Z"]) < 1e-7
+    assert rel_err(K.base_kernel.raw_lengthscale.grad.reshape(-1).cpu(), og["raw_lengthscale"]) < 1e-7
+    assert rel_err(K.raw_outputscale.grad.reshape(-1).cpu(), og["raw_outputscale"]) < 1e-7
 
 
 def test_big_qf_moments_matches_oracle():

@@ -36,7 +36,7 @@ def run_hip(g, want_moments=True, **kw):
     out, grads, status, (mu, v) = ops.elbo_step(g["X"].to(dev), g["Y"].to(dev), p["Z"], p["raw_lengthscale"],
                                                  p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"],
                                                  float(g["N_total"]), flow=flow, theta=theta, rowp=rowp, S=S,
-                                                 want_moments=want_moments, **kw)
+                                                 want_moments=want_moments, kernel=g.get("kernel", "scale_rbf"), **kw)
     torch.cuda.synchronize()
     return out.cpu(), {k: t.cpu() for k, t in grads.items()}, status.cpu(), (mu.cpu(), v.cpu())
 

@@ -48,6 +48,24 @@ def test_evaluation_path_matches_reference(name):
     assert rel_err(orc.test_log_lik_sum_ref(lp), g["test_logp_sum"]) < TOL
 
 
+@pytest.mark.parametrize("name", ["tiny_matern_svgp", "med_matern_sal2", "med_matern_tanh2x2"])
+def test_matern32_step0_matches_reference(name):
+    """'scale_matern32' (utils_models.py:199-204): the oracle's restatement against the reference's model classes
+    executed on the gpytorch stand-in (third-party kernel arithmetic: unpinned, see oracle/gen_golden.py)."""
+    g = load_golden(name)
+    assert g["kernel"] == "scale_matern32"
+    (elbo, ell, kld), grads = orc.elbo_and_grads(g["X"], g["Y"], g["params"], float(g["N_total"]), g["program"],
+                                                 g["xs"], g["ws"], None, kernel=g["kernel"])
+    assert rel_err(elbo, g["ELBO"]) < TOL and rel_err(ell, g["ELL"]) < TOL and rel_err(kld, g["KLD"]) < TOL
+    p = g["params"]
+    mu, v = orc.qf_moments(g["X"], p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"], kernel=g["kernel"])
+    assert rel_err(mu, g["mu"]) < 1e-9 and rel_err(v, g["v"]) < 1e-8
+    for key in ("Z", "m", "Lam", "raw_outputscale", "raw_lengthscale", "log_var_noise"):
+        assert rel_err(grads[key], g["g_" + key]) < 1e-8, key
+    if g["program"] is not None:
+        assert rel_err(grads["theta"], g["g_theta"]) < 1e-8
+
+
 def test_known_answers_at_init():
     """identity-initialised SAL TGP == SVGP ELBO; KL at init = 0.5(-M ln 1e-5 + M 1e-5 - M)."""
     a, b = load_golden("init_sal2_identity"), load_golden("init_svgp")

@@ -20,6 +20,7 @@ static int check_model(const tgp_model* m, bool need_lik) {
   if (m->N < 1 || m->D < 1 || m->D > 16) return -1;
   if (m->M < 1) return -1;
   if (m->M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
+  if (m->kernel != TGP_KERNEL_SCALE_RBF && m->kernel != TGP_KERNEL_SCALE_MATERN32) return -1;
   if (!m->Z || !m->raw_ls || !m->raw_os || !m->m || !m->Lam || !m->log_var_noise) return -1;
   if (need_lik && m->lik == TGP_LIK_FLOW) {
     if (m->S < 1 || m->nblk < 0 || !m->xs || !m->wn) return -1;
@@ -61,7 +62,13 @@ int tgp_version(void) { return TGP_VERSION; }
 const char* tgp_last_error(void) { return g_err; }
 
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP) {
-  if (M > TGP_FUSED_MAX_M) return big_workspace_doubles(N, D, M, S, nblk, P, RP) * sizeof(double);
+  return tgp_workspace_bytes_kernel(N, D, M, S, nblk, P, RP, TGP_KERNEL_SCALE_RBF);
+}
+
+size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
+                                  int32_t kernel) {
+  if (M > TGP_FUSED_MAX_M || kernel != TGP_KERNEL_SCALE_RBF)
+    return big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel) * sizeof(double);
   Plan p;
   if (make_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
   size_t d = p.total;
@@ -101,7 +108,7 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   FlowProg fp;
   if (int rc = make_prog(&md, model->lik == TGP_LIK_FLOW, fp)) return rc;
   md.program = nullptr;  // kernels use the by-value copy
-  if (model->M > TGP_FUSED_MAX_M)
+  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF)
     return launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st);
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
@@ -128,7 +135,7 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   double* ws = static_cast<double*>(workspace);
   tgp_model md = *model;
   md.nblk = 0; md.P = 0; md.RP = 0; md.lik = TGP_LIK_GAUSS; md.program = nullptr;
-  if (model->M > TGP_FUSED_MAX_M) return launch_big_moments(md, X, mu, v, status, ws, workspace_bytes / sizeof(double), st);
+  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) return launch_big_moments(md, X, mu, v, status, ws, workspace_bytes / sizeof(double), st);
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
@@ -147,6 +154,19 @@ int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int
   if (D < 1) return -5;
   if (!K) return -7;
   return launch_kmm(Z, raw_ls, raw_os, M, D, jitter, K, static_cast<hipStream_t>(stream));
+}
+
+int tgp_kernel_matrix_f64(int32_t kernel, const double* X1, int32_t N1, const double* X2, int32_t N2, int32_t D,
+                          const double* raw_ls, const double* raw_os, double jitter, double* K, void* stream) {
+  if (kernel != TGP_KERNEL_SCALE_RBF && kernel != TGP_KERNEL_SCALE_MATERN32) return -1;
+  if (!X1) return -2;
+  if (N1 < 1) return -3;
+  if (X2 && N2 < 1) return -5;
+  if (D < 1) return -6;
+  if (!raw_ls) return -7;
+  if (!raw_os) return -8;
+  if (!K) return -10;
+  return launch_kernel_matrix(kernel, X1, N1, X2, N2, D, raw_ls, raw_os, jitter, K, static_cast<hipStream_t>(stream));
 }
 
 int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int32_t N, int32_t M,

@@ -35,7 +35,7 @@ namespace tgp {
 #define BIG_NCMAX 16384
 
 struct BigPlan {
-  int N, D, M, S, nblk, P, RP, lik;
+  int N, D, M, S, nblk, P, RP, lik, kernel;
   int MP, DP, NC, nchunks, NP, LS;
   int ksg;  // split-K slabs of the G SYRK: about two workgroups per CU over the lower block triangle
   size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb, spart;
@@ -44,6 +44,7 @@ struct BigPlan {
   size_t Kc, A, B, Ab;
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
+  size_t Kmmg, TpartK, TK, UK;  // MATERN32 only: derivative-weight K_MM, statistics of (Kbar o K) next to those of (Kbar o K_g)
   size_t total;
 };
 
@@ -58,9 +59,11 @@ static int big_chunk_max() {
   return v;
 }
 
-static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
+static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int kernel) {
   if (D < 1 || D > 16) return -2;
-  if (M <= 16 * TGP_MAX_MT || M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
+  if (M < 1 || M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
+  if (M <= 16 * TGP_MAX_MT && kernel == TGP_KERNEL_SCALE_RBF) return TGP_E_UNSUPPORTED;  // the fused path owns these
+  p.kernel = kernel;
   p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
   p.MP = (M + 127) / 128 * 128;
   p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
@@ -100,14 +103,21 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.Gpart = o; o += (size_t)p.ksg * mm;
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
   p.likslot = o; o += (size_t)p.nchunks * p.LS;
-  p.likws = o; o += lik_workspace_doubles(p.NC, P, RP);
+  p.likws = o; o += rup(lik_workspace_doubles(p.NC, P, RP), 16);
+  p.Kmmg = p.TpartK = p.TK = p.UK = 0;
+  if (kernel != TGP_KERNEL_SCALE_RBF) {
+    p.Kmmg = o; o += mm;
+    p.TpartK = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
+    p.TK = o; o += (size_t)p.MP * BIG_XW;
+    p.UK = o; o += (size_t)p.MP * BIG_XW;
+  }
   p.total = o;
   return 0;
 }
 
-size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP) {
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel) {
   BigPlan p;
-  if (make_big_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
+  if (make_big_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW, kernel) != 0) return 0;
   return p.total;
 }
 
@@ -239,12 +249,14 @@ __global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double
       const double t = zr[d] - zc[d];
       d2 += t * t;
     }
-    k = ws[p.hdr + H_S2] * exp_fast(-0.5 * d2);
+    k = cov_value(p.kernel, ws[p.hdr + H_S2], d2);
+    if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = cov_gweight(p.kernel, ws[p.hdr + H_S2], d2);
     if (k != k) status[1] = 1;
     if (row == col) k += md.jitter;
     if (col <= row) lq = md.Lam[(size_t)row * M + col];
   } else {
     k = row == col ? 1.0 : 0.0;
+    if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = 0.0;
   }
   ws[p.Kmm + e] = k;
   ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
@@ -415,8 +427,9 @@ __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __res
   ws[p.Xaug + e] = x;
 }
 
-// K'[n][m] = s2 exp(-1/2 |xs_n - zs_m|^2); block = 32 data rows x 128 inducing columns (2 row groups of 16)
-__global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
+// K'[n][m] = k(xs_n, zs_m) (gweight: its derivative weight k_g instead); block = 32 data rows x 128 inducing columns
+__global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws,
+                                                  int gweight) {
   __shared__ double xl[32 * 16];
   const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7, DP = p.DP;
   const int m = blockIdx.x * 128 + c, n0 = blockIdx.y * 32;
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __rest
       const double t = xl[nl * DP + d] - zs[d];
       d2 += t * t;
     }
-    Kc[(size_t)(n0 + nl) * p.MP + m] = m < p.M ? s2 * exp_fast(-0.5 * d2) : 0.0;
+    Kc[(size_t)(n0 + nl) * p.MP + m] = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
   }
 }
 
@@ -518,6 +531,11 @@ __global__ __launch_bounds__(256) void k_big_reduce(BigPlan p, double* __restric
       double s = 0.0;
       for (int z = 0; z < BIG_KST; ++z) s += ws[p.Tpart + (size_t)z * p.MP * BIG_XW + t];
       ws[p.T + t] = s;
+      if (p.kernel != TGP_KERNEL_SCALE_RBF) {
+        double sk = 0.0;
+        for (int z = 0; z < BIG_KST; ++z) sk += ws[p.TpartK + (size_t)z * p.MP * BIG_XW + t];
+        ws[p.TK + t] = sk;
+      }
     } else if (t < (size_t)p.MP * BIG_XW + p.MP) {
       const size_t m = t - (size_t)p.MP * BIG_XW;
       double s = 0.0;
@@ -584,7 +602,9 @@ __global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_
     const double* Tj = ws + p.T + (size_t)j * BIG_XW;
     const double* Uj = ws + p.U + (size_t)j * BIG_XW;
     const double t0 = Tj[2 * DP], cs = Uj[2 * DP];
-    acc[16] += cs + t0;
+    // d/d outputscale needs sum (Kbar o K); for the RBF K_g = K and it is the same ones-column
+    acc[16] += p.kernel != TGP_KERNEL_SCALE_RBF ? ws[p.TK + (size_t)j * BIG_XW + 2 * DP] + ws[p.UK + (size_t)j * BIG_XW + 2 * DP]
+                                                : cs + t0;
     for (int d = 0; d < D; ++d) {
       const double zj = ws[p.Zs + (size_t)j * DP + d];
       const double t1 = Tj[d], t2 = Tj[DP + d], R = Uj[d];
@@ -693,7 +713,7 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws);
+  hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
   LAUNCH_CHECK();
   // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD
   GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
@@ -710,7 +730,7 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
 int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
                        size_t ws_doubles, hipStream_t st) {
   BigPlan p;
-  if (int rc = make_big_plan(p, md.N, md.D, md.M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, 1, 0, 0, 0, TGP_LIK_GAUSS, md.kernel)) return rc;
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
   if (int rc = big_prepare(p, md, ws, status, false, st)) return rc;
   for (int ci = 0; ci < p.nchunks; ++ci) {
@@ -725,7 +745,7 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
                     uint32_t phases, hipStream_t st) {
   BigPlan p;
-  if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik)) return rc;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik, md.kernel)) return rc;
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
   const int MP = p.MP, NC = p.NC;
   const size_t mm = (size_t)MP * MP;
@@ -760,9 +780,17 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       GemmArgs a4 = gemm_args(ws + p.Ab, MP, ws + p.J, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
       a4.xcd = 1;
       GEMM(false, false, a4);
-      // T slabs (+)= (Kbar' o K')^T Xaug
+      // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
+      // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
       GemmArgs at = gemm_args(ws + p.B, MP, ws + p.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
       at.a_mul = ws + p.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
+      if (p.kernel != TGP_KERNEL_SCALE_RBF) {
+        GemmArgs atk = at;
+        atk.C = ws + p.TpartK;
+        GEMM(true, false, atk);
+        hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, X + c0 * p.D, nrows, ws, 1);
+        LAUNCH_CHECK();
+      }
       GEMM(true, false, at);
       // G slabs (+)= A'^T diag(vbar) A', lower block triangle
       GemmArgs ag = gemm_args(ws + p.A, MP, ws + p.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
@@ -796,9 +824,19 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
     // Kbar_MM = 1/2 J^T Q J
     GEMM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
     GEMM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
-    // U = (Kbar_MM o K_MM) Zaug
+    // U = (Kbar_MM o K_MM,g) Zaug  (MATERN32: also with K_MM itself, for d/d outputscale)
     GemmArgs au = gemm_args(ws + p.R1, MP, ws + p.Zaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, MP, 1.0, 0.0);
-    au.a_mul = ws + p.Kmm; au.ksplit = 8; au.cz = (size_t)MP * BIG_XW;
+    au.ksplit = 8; au.cz = (size_t)MP * BIG_XW;
+    if (p.kernel != TGP_KERNEL_SCALE_RBF) {
+      au.a_mul = ws + p.Kmm;
+      GEMM(false, false, au);
+      hipLaunchKernelGGL(k_big_sum_slabs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, ws + p.Tpart, 8,
+                         (size_t)MP * BIG_XW, ws + p.UK);
+      LAUNCH_CHECK();
+      au.a_mul = ws + p.Kmmg;
+    } else {
+      au.a_mul = ws + p.Kmm;
+    }
     GEMM(false, false, au);
     hipLaunchKernelGGL(k_big_sum_slabs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, ws + p.Tpart, 8,
                        (size_t)MP * BIG_XW, ws + p.U);

@@ -129,6 +129,23 @@ __device__ __forceinline__ double exp_fast(double x) {
   return ldexp(fma(s1, r8, s0), (int)k);
 }
 
+// Covariance value from the squared scaled distance d2 = |(x - z)/l|^2, and the weight of -1/2 d(d2) in its
+// derivative (k_g = -2 dk/d(d2)):   RBF      k = s2 exp(-d2/2)                       k_g = k
+//                                   MATERN32 k = s2 (1 + a r) exp(-a r), a = sqrt 3    k_g = 3 s2 exp(-a r)
+// with r = sqrt(max(d2, 1e-30)) as gpytorch's covar_dist clamps it (third-party formula, gpytorch 1.1.1 MaternKernel).
+#define TGP_SQRT3 1.7320508075688772
+__device__ __forceinline__ double cov_value(int kernel, double s2, double d2) {
+  if (kernel == TGP_KERNEL_SCALE_MATERN32) {
+    const double ar = TGP_SQRT3 * sqrt(fmax(d2, 1e-30));
+    return s2 * (1.0 + ar) * exp_fast(-ar);
+  }
+  return s2 * exp_fast(-0.5 * d2);
+}
+__device__ __forceinline__ double cov_gweight(int kernel, double s2, double d2) {
+  if (kernel == TGP_KERNEL_SCALE_MATERN32) return 3.0 * s2 * exp_fast(-TGP_SQRT3 * sqrt(fmax(d2, 1e-30)));
+  return s2 * exp_fast(-0.5 * d2);
+}
+
 // 1/x from v_rcp_f64 + two Newton steps (no v_div_scale / v_div_fixup: operands here are finite, normal, non-zero)
 __device__ __forceinline__ double rcp_fast(double x) {
   double y = __builtin_amdgcn_rcp(x);

@@ -25,6 +25,8 @@ int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int 
                hipStream_t st);
 int launch_knm(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int N, int M, int D,
                double* K, hipStream_t st);
+int launch_kernel_matrix(int kernel, const double* X1, int N1, const double* X2, int N2, int D, const double* raw_ls,
+                         const double* raw_os, double jitter, double* K, hipStream_t st);
 int launch_kl(const double* m, const double* Lam, int M, double* out, double* g_m, double* g_Lam, hipStream_t st);
 int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* status, hipStream_t st);
 
@@ -33,7 +35,7 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
 // tgp_big.hip (general-M path, 128 < M <= TGP_BIG_MAX_M)
-size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP);
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel);
 int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
                     uint32_t phases, hipStream_t st);

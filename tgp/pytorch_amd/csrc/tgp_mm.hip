@@ -617,6 +617,26 @@ __global__ void k_knm(const double* __restrict__ X, const double* __restrict__ Z
   K[i] = softplus_d(raw_os[0]) * exp(-0.5 * d2);
 }
 
+// K(X1, X2) for either covariance function (tgp_kernel_matrix_f64); X2 == nullptr: K(X1, X1) + jitter I
+__global__ void k_kernel_matrix(int kernel, const double* __restrict__ X1, int N1, const double* __restrict__ X2, int N2,
+                                int D, const double* __restrict__ raw_ls, const double* __restrict__ raw_os, double jitter,
+                                double* __restrict__ K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool self = X2 == nullptr;
+  const int n2 = self ? N1 : N2;
+  if (i >= (size_t)N1 * n2) return;
+  const size_t r = i / n2;
+  const size_t c = i % n2;
+  const double* B = self ? X1 : X2;
+  double d2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double il = 1.0 / softplus_d(raw_ls[d]);
+    const double t = X1[r * D + d] * il - B[c * D + d] * il;
+    d2 += t * t;
+  }
+  K[i] = cov_value(kernel, softplus_d(raw_os[0]), d2) + ((self && r == c) ? jitter : 0.0);
+}
+
 // whitened KL + gradients (models/sparse_MF_SP.py:406-431), single block
 __global__ __launch_bounds__(256) void k_kl(const double* __restrict__ m, const double* __restrict__ Lam, int M,
                                              double* __restrict__ out, double* __restrict__ g_m,
@@ -756,6 +776,15 @@ int launch_knm(const double* X, const double* Z, const double* raw_ls, const dou
                double* K, hipStream_t st) {
   const size_t tot = (size_t)N * M;
   hipLaunchKernelGGL(k_knm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, Z, raw_ls, raw_os, N, M, D, K);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_kernel_matrix(int kernel, const double* X1, int N1, const double* X2, int N2, int D, const double* raw_ls,
+                         const double* raw_os, double jitter, double* K, hipStream_t st) {
+  const size_t tot = (size_t)N1 * (X2 ? N2 : N1);
+  hipLaunchKernelGGL(k_kernel_matrix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, kernel, X1, N1, X2, N2, D, raw_ls,
+                     raw_os, jitter, K);
   LAUNCH_CHECK();
   return 0;
 }

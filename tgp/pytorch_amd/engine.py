@@ -75,7 +75,8 @@ class FlatParams:
 
 class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
-                 eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None):
+                 eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
+                 kernel="scale_rbf"):
         self.lib = L.load()
         self.device = torch.device(device)
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
@@ -106,7 +107,7 @@ class ElboEngine:
         fp = self.fp
         self.md, self._keep = ops._model_struct(self.X, fp.view("Z"), fp.view("raw_ls"), fp.view("raw_os"), fp.view("m"),
                                                 fp.view("Lam"), fp.view("lvn"), scale, 0.0, 1.0 / self.world_size,
-                                                self.flow, fp.view("theta") if P else None, self.S)
+                                                self.flow, fp.view("theta") if P else None, self.S, kernel)
         self.gs = L.TgpGrads()
         self.gs.Z, self.gs.raw_ls, self.gs.raw_os = (L.ptr(fp.gview(k)) for k in ("Z", "raw_ls", "raw_os"))
         self.gs.m, self.gs.Lam, self.gs.log_var_noise = (L.ptr(fp.gview(k)) for k in ("m", "Lam", "lvn"))
@@ -114,7 +115,8 @@ class ElboEngine:
             self.gs.theta = L.ptr(fp.gview("theta"))
         if RP:
             self.gs.rowp = L.ptr(self.g_rowp)
-        self.ws = ops.workspace(self.N, self.D, self.M, self.md.S, self.md.nblk, self.md.P, self.md.RP, self.device)
+        self.ws = ops.workspace(self.N, self.D, self.M, self.md.S, self.md.nblk, self.md.P, self.md.RP, self.device,
+                                self.md.kernel)
         self.graph = None
         self._warm = False
 

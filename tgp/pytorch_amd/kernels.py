@@ -23,8 +23,20 @@ class RBFKernel(nn.Module):
         return softplus(self.raw_lengthscale)
 
 
+class MaternKernel(RBFKernel):
+    """gpytorch MaternKernel parameter holder; nu = 1.5 is the only smoothness with a HIP implementation
+    ('scale_matern32', models/utils_models.py:199-204)."""
+
+    def __init__(self, nu=1.5, ard_num_dims=None, batch_shape=torch.Size([])):
+        super().__init__(ard_num_dims, batch_shape)
+        if nu != 1.5:
+            raise NotImplementedError("MaternKernel: only nu=1.5 has a HIP implementation in this build")
+        self.nu = nu
+
+
 class ScaleKernel(nn.Module):
-    """sigma^2 * exp(-1/2 |(x - z)/l|^2) with sigma^2 = softplus(raw_outputscale), l = softplus(raw_lengthscale)."""
+    """sigma^2 * k(|(x - z)/l|) with sigma^2 = softplus(raw_outputscale), l = softplus(raw_lengthscale);
+    k = exp(-r^2/2) (RBFKernel) or (1 + sqrt3 r) exp(-sqrt3 r) (MaternKernel, nu = 1.5)."""
 
     def __init__(self, base_kernel, batch_shape=torch.Size([])):
         super().__init__()
@@ -35,6 +47,11 @@ class ScaleKernel(nn.Module):
     @property
     def outputscale(self):
         return softplus(self.raw_outputscale)
+
+    @property
+    def hip_kernel(self):
+        """The instance_kernel name the HIP library knows this covariance function by."""
+        return "scale_matern32" if isinstance(self.base_kernel, MaternKernel) else "scale_rbf"
 
     def _params(self, idx=0):
         D = self.base_kernel.raw_lengthscale.shape[-1]
@@ -48,11 +65,8 @@ class ScaleKernel(nn.Module):
         if diag:
             return self.outputscale.reshape(-1, 1).detach() * torch.ones(x1.shape[:-1], dtype=x1.dtype, device=x1.device)
         raw_ls, raw_os = self._params()
-        if x2 is None:
-            K = ops.kmm(x1_.contiguous(), raw_ls, raw_os)
-        else:
-            x2_ = x2[0] if x2.dim() == 3 else x2
-            K = ops.knm(x1_.contiguous(), x2_.contiguous(), raw_ls, raw_os)
+        x2_ = None if x2 is None else (x2[0] if x2.dim() == 3 else x2).contiguous()
+        K = ops.kernel_matrix(x1_.contiguous(), x2_, raw_ls, raw_os, kernel=self.hip_kernel)
         return _Dense(K.unsqueeze(0) if x1.dim() == 3 else K)
 
 
@@ -71,10 +85,13 @@ def instance_kernel(name, ard_num_dim, num_multioutput, kernel_is_shared, init_p
     ks = init_params.get("kernel_scale", 1.0)
     if kernel_is_shared:
         num_multioutput = 1
-    if name != "scale_rbf":
-        raise NotImplementedError("kernel '%s': only 'scale_rbf' (the kernel main.py builds, code/main.py:229) has a "
-                                  "HIP implementation in this build" % name)
-    rbf = RBFKernel(ard_num_dims=ard_num_dim, batch_shape=torch.Size([num_multioutput]))
+    if name not in ("scale_rbf", "scale_matern32"):
+        raise NotImplementedError("kernel '%s': 'scale_rbf' (the kernel main.py builds, code/main.py:229) and "
+                                  "'scale_matern32' have a HIP implementation in this build" % name)
+    if name == "scale_matern32":
+        rbf = MaternKernel(nu=1.5, ard_num_dims=ard_num_dim, batch_shape=torch.Size([num_multioutput]))
+    else:
+        rbf = RBFKernel(ard_num_dims=ard_num_dim, batch_shape=torch.Size([num_multioutput]))
     rbf.raw_lengthscale.data = inv_softplus(torch.ones(num_multioutput, 1, rbf.raw_lengthscale.size(-1), dtype=cg.dtype) * ls)
     K = ScaleKernel(rbf, batch_shape=torch.Size([num_multioutput]))
     K.raw_outputscale.data = inv_softplus(torch.ones(num_multioutput, dtype=cg.dtype) * ks)

@@ -18,9 +18,14 @@ LIK_GAUSS, LIK_FLOW = 0, 1
 _dp = C.c_void_p
 
 
+KERNEL_SCALE_RBF, KERNEL_SCALE_MATERN32 = 0, 1
+KERNELS = {"scale_rbf": KERNEL_SCALE_RBF, "scale_matern32": KERNEL_SCALE_MATERN32}
+
+
 class TgpModel(C.Structure):
     _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("S", C.c_int32), ("nblk", C.c_int32),
-                ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("scale", C.c_double),
+                ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("kernel", C.c_int32), ("reserved0", C.c_int32),
+                ("scale", C.c_double),
                 ("jitter", C.c_double), ("kl_scale", C.c_double), ("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp),
                 ("m", _dp), ("Lam", _dp), ("log_var_noise", _dp), ("theta", _dp), ("program", _dp), ("xs", _dp),
                 ("wn", _dp)]
@@ -41,6 +46,8 @@ _SIGS = {
     "tgp_version": (C.c_int, []),
     "tgp_last_error": (C.c_char_p, []),
     "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
+    "tgp_workspace_bytes_kernel": (C.c_size_t, [C.c_int32] * 8),
+    "tgp_kernel_matrix_f64": (C.c_int, [C.c_int32, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp]),
     "tgp_elbo_step_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
                                     C.c_size_t, _dp]),
     "tgp_elbo_step_phases_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp,

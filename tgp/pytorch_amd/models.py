@@ -148,7 +148,7 @@ class sparse_MF_SP(nn.Module):
         X2 = X[0] if X.dim() == 3 else X
         self._require_gpu(X2)
         Z, rl, ro, m, Lam, _ = (t.detach() for t in self._gp_params())
-        mu, v = ops.qf_moments(X2, Z, rl, ro, m, Lam)
+        mu, v = ops.qf_moments(X2, Z, rl, ro, m, Lam, kernel=self.covariance_function.hip_kernel)
         return mu.reshape(1, -1, 1), v.reshape(1, -1, 1)
 
     def KLD(self):
@@ -165,7 +165,7 @@ class sparse_MF_SP(nn.Module):
         spec, theta, rowp = self._flow_inputs(X2, with_grad=True)
         cfg = self._cfg
         cfg.update(N_total=self.N, flow=spec, S=self.quad_points, check_status=(cg.status_check == "always"),
-                   global_jitter=cg.global_jitter)
+                   global_jitter=cg.global_jitter, kernel=self.covariance_function.hip_kernel)
         elbo, ell, kld = ops.ElboFunction.apply(X2, Y, Z, rl, ro, m, Lam, lvn, theta, rowp, cfg)
         return elbo, ell, kld
 

@@ -47,11 +47,20 @@ def gauss_hermite(S, device):
 _ws_cache = {}
 
 
-def workspace(N, D, M, S, nblk, P, RP, device):
-    key = (N, D, M, S, nblk, P, RP, str(device), torch.cuda.current_stream().cuda_stream)
+def kernel_id(kernel):
+    """'scale_rbf' / 'scale_matern32' (instance_kernel names, models/utils_models.py:188-204) or a TGP_KERNEL_* id."""
+    if isinstance(kernel, str):
+        if kernel not in L.KERNELS:
+            raise L.TgpError("kernel '%s' has no HIP implementation (have: %s)" % (kernel, ", ".join(L.KERNELS)))
+        return L.KERNELS[kernel]
+    return int(kernel)
+
+
+def workspace(N, D, M, S, nblk, P, RP, device, kernel=0):
+    key = (N, D, M, S, nblk, P, RP, str(device), torch.cuda.current_stream().cuda_stream, kernel)
     buf = _ws_cache.get(key)
     if buf is None:
-        nbytes = L.load().tgp_workspace_bytes(N, D, M, max(S, 1), nblk, P, RP)
+        nbytes = L.load().tgp_workspace_bytes_kernel(N, D, M, max(S, 1), nblk, P, RP, kernel)
         if nbytes == 0:
             raise L.TgpError("unsupported problem shape N=%d D=%d M=%d (this build: D<=16, M<=4096)" % (N, D, M))
         buf = torch.empty(nbytes // 8 + 16, dtype=torch.float64, device=device)
@@ -86,8 +95,9 @@ class FlowSpec:
         return FlowSpec(self.blocks, self.P, self.RP, device)
 
 
-def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S):
+def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel=0):
     md = L.TgpModel()
+    md.kernel = kernel_id(kernel)
     md.N, md.D = X.shape[0], X.shape[1]
     md.M = m.numel()
     md.scale, md.jitter, md.kl_scale = float(scale), float(jitter), float(kl_scale)
@@ -106,7 +116,7 @@ def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, fl
 
 
 def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=None, rowp=None, S=None, jitter=0.0,
-              kl_scale=1.0, mb_global=None, want_moments=False):
+              kl_scale=1.0, mb_global=None, want_moments=False, kernel="scale_rbf"):
     """One fused ELBO evaluation + all gradients on the GPU.  Returns (out[4], grads dict, status[4], (mu, v)).
 
     out = [ELL_shard - KL, ELL_shard, KL, 0]; grads are d(ELL_shard - kl_scale*KL)/d(param).
@@ -120,8 +130,8 @@ def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=No
     N, D = X.shape
     M = m.numel()
     scale = float(N_total) / float(mb_global if mb_global is not None else N)
-    md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S)
-    ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev)
+    md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel)
+    ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev, md.kernel)
     out = torch.empty(4, dtype=torch.float64, device=dev)
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
@@ -185,10 +195,11 @@ class ElboFunction(torch.autograd.Function):
         out, g, status, _ = elbo_step_safe(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, cfg["N_total"], flow=cfg.get("flow"),
                                            theta=theta, rowp=rowp, S=cfg.get("S"),
                                            kl_scale=cfg.get("kl_scale", 1.0), mb_global=cfg.get("mb_global"),
-                                           global_jitter=cfg.get("global_jitter")) \
+                                           global_jitter=cfg.get("global_jitter"), kernel=cfg.get("kernel", "scale_rbf")) \
             if cfg.get("check_status", True) else \
             elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, cfg["N_total"], flow=cfg.get("flow"), theta=theta,
-                      rowp=rowp, S=cfg.get("S"), kl_scale=cfg.get("kl_scale", 1.0), mb_global=cfg.get("mb_global"))
+                      rowp=rowp, S=cfg.get("S"), kl_scale=cfg.get("kl_scale", 1.0), mb_global=cfg.get("mb_global"),
+                      kernel=cfg.get("kernel", "scale_rbf"))
         ctx.grads = g
         ctx.shapes = tuple(None if t is None else t.shape for t in (Z, raw_ls, raw_os, m, Lam, lvn, theta, rowp))
         cfg["last_status"] = status
@@ -212,15 +223,15 @@ class ElboFunction(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------
 # stand-alone operators
 # ---------------------------------------------------------------------------------------------------
-def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True):
+def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="scale_rbf"):
     """q(f) marginals (models/sparse_MF_SP.py:274-396): returns mu, v of shape (N,)."""
     lib = L.load()
     X = _c(X, "X")
     Z, raw_ls, raw_os, m, Lam = (_c(t, "param") for t in (Z, raw_ls, raw_os, m, Lam))
     dev = X.device
     lvn = torch.zeros(1, dtype=torch.float64, device=dev)
-    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 1.0, None, None, None)
-    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev)
+    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 1.0, None, None, None, kernel)
+    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel)
     mu = torch.empty(X.shape[0], dtype=torch.float64, device=dev)
     v = torch.empty_like(mu)
     status = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -237,6 +248,19 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True):
                 return mu, v
         raise NotPSDError("K_MM not positive definite")
     return mu, v
+
+
+def kernel_matrix(X1, X2, raw_ls, raw_os, kernel="scale_rbf", jitter=0.0):
+    """K(X1, X2) (X2 None: K(X1, X1) + jitter I) for 'scale_rbf' / 'scale_matern32' (tgp_kernel_matrix_f64)."""
+    lib = L.load()
+    X1, raw_ls, raw_os = _c(X1, "X1"), _c(raw_ls, "raw_ls"), _c(raw_os, "raw_os")
+    X2 = _c(X2, "X2")
+    N1, D = X1.shape
+    N2 = X2.shape[0] if X2 is not None else N1
+    K = torch.empty(N1, N2, dtype=torch.float64, device=X1.device)
+    L.check(lib.tgp_kernel_matrix_f64(kernel_id(kernel), L.ptr(X1), N1, L.ptr(X2), N2, D, L.ptr(raw_ls), L.ptr(raw_os),
+                                      float(jitter), L.ptr(K), L.stream_ptr()), "tgp_kernel_matrix_f64")
+    return K
 
 
 def kmm(Z, raw_ls, raw_os, jitter=0.0):
