@@ -203,6 +203,19 @@ int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_
 int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, const double* rowp, const double* Y,
                     double Y_std, double* m1, double* m2, double* logp, void* stream);
 
+/* Inducing-point initialisation: the numerical kernels behind utils.KMEANS, which replaces
+ * sklearn.cluster.KMeans(init='k-means++', n_init, random_state) of dsp/utils.py:143-159.  Random draws, the stopping
+ * rule and the restarts stay on the host (tgp/pytorch_amd/utils.py); D <= 16.
+ *   assign : labels[n] = argmin_k |x_n - c_k|^2 (first minimum), mind2[n] = that distance (mind2 may be NULL)
+ *   segsum : sums[k,:] = sum of the rows X[order[i]], offs[k] <= i < offs[k+1] (rows sorted by label; fixed order)
+ *   pp     : out[t,n] = min(closest[n], |x_n - x_cand[t]|^2) for T <= 16 k-means++ trial candidates (closest NULL: +inf) */
+int tgp_kmeans_assign_f64(const double* X, int32_t N, int32_t D, const double* C, int32_t K, int32_t* labels, double* mind2,
+                          void* stream);
+int tgp_kmeans_segsum_f64(const double* X, int32_t D, const int64_t* order, const int64_t* offs, int32_t K, double* sums,
+                          void* stream);
+int tgp_kmeans_pp_f64(const double* X, int32_t N, int32_t D, const int64_t* cand, int32_t T, const double* closest,
+                      double* out, void* stream);
+
 /* Adam on a flat parameter buffer (torch.optim.Adam semantics, dsp/trainers/optimizers.py:12; L2 weight decay
  * added to the gradient as torch does).  `maximize` != 0 ascends (gradients here are of +ELBO). */
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,

@@ -356,3 +356,20 @@ def test_flow_initialiser_runs_on_the_hip_kernels():
         warnings.simplefilter("ignore")
         fitted, curve = find_forward_params(x.numpy(), x.numpy().copy(), fn, num_restarts=1, num_epochs=300)
     assert curve[-1] < 0.05 * curve[0]
+
+
+@pytest.mark.parametrize("N,D,K,n_init", [(3000, 4, 40, 3), (8611, 4, 100, 1), (1200, 8, 17, 2)])
+def test_kmeans_hip_matches_sklearn(N, D, K, n_init):
+    """utils.KMEANS(backend='hip') (k-means++ seeding and Lloyd iterations on the GPU, sklearn's draws and stopping
+    rule restated) against the reference's own call, sklearn.cluster.KMeans(..., random_state=seed) on the host."""
+    from tgp.pytorch_amd import config as cg
+    from tgp.pytorch_amd.utils import KMEANS
+    cg.set_maximum_precission()
+    g = torch.Generator().manual_seed(12)
+    X = torch.randn(N, D, generator=g, dtype=torch.float64)
+    X[:, 0] += 2.0 * (torch.arange(N) % 3)            # some structure
+    Zs = KMEANS(X, K, n_init=n_init, seed=0, backend="sklearn").cpu()
+    Zh, info = KMEANS(X.to(DEV), K, n_init=n_init, seed=0, backend="hip", return_info=True)
+    Zh = Zh.cpu()
+    assert Zh.shape == (K, D)
+    assert rel_err(Zh, Zs) < 1e-8, (rel_err(Zh, Zs), info["n_iter"])

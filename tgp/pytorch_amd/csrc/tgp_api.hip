@@ -282,6 +282,39 @@ int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, c
   return launch_predict(md, fp, mu, v, rowp, Y, Y_std, m1, m2, logp, static_cast<hipStream_t>(stream));
 }
 
+int tgp_kmeans_assign_f64(const double* X, int32_t N, int32_t D, const double* C, int32_t K, int32_t* labels, double* mind2,
+                          void* stream) {
+  if (!X) return -1;
+  if (N < 1) return -2;
+  if (D < 1 || D > 16) return -3;
+  if (!C) return -4;
+  if (K < 1) return -5;
+  if (!labels) return -6;
+  return launch_kmeans_assign(X, N, D, C, K, labels, mind2, static_cast<hipStream_t>(stream));
+}
+
+int tgp_kmeans_segsum_f64(const double* X, int32_t D, const int64_t* order, const int64_t* offs, int32_t K, double* sums,
+                          void* stream) {
+  if (!X) return -1;
+  if (D < 1 || D > 16) return -2;
+  if (!order) return -3;
+  if (!offs) return -4;
+  if (K < 1) return -5;
+  if (!sums) return -6;
+  return launch_kmeans_segsum(X, D, order, offs, K, sums, static_cast<hipStream_t>(stream));
+}
+
+int tgp_kmeans_pp_f64(const double* X, int32_t N, int32_t D, const int64_t* cand, int32_t T, const double* closest,
+                      double* out, void* stream) {
+  if (!X) return -1;
+  if (N < 1) return -2;
+  if (D < 1 || D > 16) return -3;
+  if (!cand) return -4;
+  if (T < 1 || T > 16) return -5;
+  if (!out) return -7;
+  return launch_kmeans_pp(X, N, D, cand, T, closest, out, static_cast<hipStream_t>(stream));
+}
+
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                  double beta1, double beta2, double eps, double weight_decay, int32_t step, int32_t maximize,
                  void* stream) {

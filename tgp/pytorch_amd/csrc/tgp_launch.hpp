@@ -44,6 +44,12 @@ int launch_big_moments(const tgp_model& md, const double* X, double* mu, double*
 int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                       int ldb, double beta, double* C, int ldc, hipStream_t st);
 
+// tgp_kmeans.hip
+int launch_kmeans_assign(const double* X, int N, int D, const double* C, int K, int32_t* labels, double* mind2, hipStream_t st);
+int launch_kmeans_segsum(const double* X, int D, const int64_t* order, const int64_t* offs, int K, double* sums, hipStream_t st);
+int launch_kmeans_pp(const double* X, int N, int D, const int64_t* cand, int T, const double* closest, double* out,
+                     hipStream_t st);
+
 // tgp_lik.hip
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* log_var_noise,
                      double scale, double* out, double* g_mu, double* g_v, double* ws, hipStream_t st);

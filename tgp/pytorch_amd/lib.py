@@ -64,6 +64,9 @@ _SIGS = {
                                    _dp]),
     "tgp_flow_eval_f64": (C.c_int, [C.POINTER(TgpModel), _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp]),
     "tgp_predict_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
+    "tgp_kmeans_assign_f64": (C.c_int, [_dp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp]),
+    "tgp_kmeans_segsum_f64": (C.c_int, [_dp, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]),
+    "tgp_kmeans_pp_f64": (C.c_int, [_dp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp]),
     "tgp_adam_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int32, C.c_int32, _dp]),
     "tgp_adam_dev_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
