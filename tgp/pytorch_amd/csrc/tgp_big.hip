@@ -44,6 +44,7 @@ struct BigPlan {
   size_t Kc, A, B, Ab;
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
+  size_t Sk;  // split-K slabs of the M x M products
   size_t Kmmg, TpartK, TK, UK;  // MATERN32 only: derivative-weight K_MM, statistics of (Kbar o K) next to those of (Kbar o K_g)
   size_t total;
 };
@@ -104,6 +105,12 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
   p.likslot = o; o += (size_t)p.nchunks * p.LS;
   p.likws = o; o += rup(lik_workspace_doubles(p.NC, P, RP), 16);
+  {
+    const int nb = p.MP / 128;
+    int ks = 256 / (nb * nb);
+    ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    p.Sk = o; o += (size_t)(ks > 1 ? 8 : 0) * (nb <= 4 ? mm : mm / 2);
+  }
   p.Kmmg = p.TpartK = p.TK = p.UK = 0;
   if (kernel != TGP_KERNEL_SCALE_RBF) {
     p.Kmmg = o; o += mm;
@@ -554,6 +561,17 @@ __global__ __launch_bounds__(256) void k_big_sum_slabs(const double* __restrict_
   dst[e] = s;
 }
 
+// C = beta C + sum of `ns` compact slabs [m][n]  (split-K reduction of an M x M product, fixed order)
+__global__ __launch_bounds__(256) void k_big_sum_slabs2d(const double* __restrict__ src, int ns, int m, int n, double* __restrict__ C,
+                                                          int ldc, double beta) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, len = (size_t)m * n;
+  if (e >= len) return;
+  double s = 0.0;
+  for (int z = 0; z < ns; ++z) s += src[(size_t)z * len + e];
+  double* c = C + (size_t)(e / n) * ldc + e % n;
+  *c = beta == 0.0 ? s : s + beta * *c;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward M x M elementwise kernels
 // ---------------------------------------------------------------------------------------------------
@@ -650,6 +668,32 @@ __global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_
     if (int rc_ = launch_gemm((ta), (tb), (args), st)) return rc_; \
   } while (0)
 
+// An M x M product has at most (MP/128)^2 <= 64 output tiles at M = 1000 -- a quarter of the CUs, each running the
+// whole k loop.  Split k so that about 256 workgroups run, partial sums into compact slabs, then one fixed-order
+// reduction into C (150 us -> ~50 us per product at MP = 1024).
+static int gemm_mm(bool ta, bool tb, GemmArgs g, const BigPlan& p, double* ws, hipStream_t st) {
+  const int tiles = (g.m / 128) * (g.n / 128);
+  int ks = 256 / (tiles > 0 ? tiles : 1);
+  if (ks > 8) ks = 8;
+  if (ks > g.k / 64) ks = g.k / 64;  // at least four k stages per slab
+  const size_t slab = (size_t)g.m * g.n;
+  const size_t cap = (size_t)8 * ((p.MP / 128) <= 4 ? (size_t)p.MP * p.MP : (size_t)p.MP * p.MP / 2);
+  if (ks <= 1 || (size_t)ks * slab > cap || g.add || g.row_scale || g.col_scale || g.rowv) return launch_gemm(ta, tb, g, st);
+  double* C = g.C;
+  const int ldc = g.ldc;
+  const double beta = g.beta;
+  g.C = ws + p.Sk; g.ldc = g.n; g.beta = 0.0; g.ksplit = ks; g.cz = slab;
+  if (int rc = launch_gemm(ta, tb, g, st)) return rc;
+  hipLaunchKernelGGL(k_big_sum_slabs2d, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, ws + p.Sk, ks, g.m, g.n, C, ldc,
+                     beta);
+  LAUNCH_CHECK();
+  return 0;
+}
+#define GEMM_MM(ta, tb, args)                                          \
+  do {                                                                 \
+    if (int rc_ = gemm_mm((ta), (tb), (args), p, ws, st)) return rc_;  \
+  } while (0)
+
 static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
   const int MP = p.MP, nb = MP / 128;
   const size_t mm = (size_t)MP * MP;
@@ -687,7 +731,7 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   for (int i = 1; i < nb; ++i) {
     const double* Li = Lm + (size_t)i * 128 * MP;
     double* tmp = ws + p.tmp;
-    GEMM(false, false, gemm_args(Li, MP, J, MP, tmp, MP, 128, 128 * i, 128 * i, 1.0, 0.0, TRI_B_LOWER));
+    GEMM_MM(false, false, gemm_args(Li, MP, J, MP, tmp, MP, 128, 128 * i, 128 * i, 1.0, 0.0, TRI_B_LOWER));
     const double* Jii = J + (size_t)i * 128 * MP + (size_t)i * 128;
     GEMM(false, false, gemm_args(Jii, MP, tmp, MP, J + (size_t)i * 128 * MP, MP, 128, 128 * i, 128, -1.0, 0.0));
   }
@@ -696,10 +740,10 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   LAUNCH_CHECK();
   // S = Lq Lq^T - I ; H' = J^T S
   const double* Lq = ws + p.Lq;
-  GEMM(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER));
+  GEMM_MM(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER));
   hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, st, ws + p.S_, MP);
   LAUNCH_CHECK();
-  GEMM(true, false, gemm_args(J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
+  GEMM_MM(true, false, gemm_args(J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
   hipLaunchKernelGGL(k_big_wvec, dim3((MP + 255) / 256), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   return 0;
@@ -810,20 +854,20 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
   if (phases & TGP_PHASE_BACKWARD) {
     const unsigned gmm = (unsigned)(mm / 256);
     // Lbar = -tril(w s^T + 2 H' G)
-    GEMM(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0));
+    GEMM_MM(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0));
     hipLaunchKernelGGL(k_big_lbar, dim3(gmm), dim3(256), 0, st, p, ws);
     LAUNCH_CHECK();
     // dLam
-    GEMM(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, ws + p.S_, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER));
+    GEMM_MM(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, ws + p.S_, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER));
     hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, st, p, md, g.Lam, ws);
     LAUNCH_CHECK();
     // Q = Phi(L^T Lbar) + Phi(.)^T
-    GEMM(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER));
+    GEMM_MM(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER));
     hipLaunchKernelGGL(k_big_phisym, dim3(gmm), dim3(256), 0, st, p, ws);
     LAUNCH_CHECK();
     // Kbar_MM = 1/2 J^T Q J
-    GEMM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
-    GEMM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
+    GEMM_MM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
+    GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
     // U = (Kbar_MM o K_MM,g) Zaug  (MATERN32: also with K_MM itself, for d/d outputscale)
     GemmArgs au = gemm_args(ws + p.R1, MP, ws + p.Zaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, MP, 1.0, 0.0);
     au.ksplit = 8; au.cz = (size_t)MP * BIG_XW;
