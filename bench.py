@@ -123,12 +123,20 @@ def main():
         log("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TGP_BENCH_BACKEND=gloo is a rehearsal hook: it lets the multi-rank control flow (shards, split graphs, the
+    # all-reduce of the flat buffer, max-over-ranks timing) run with several ranks on ONE GPU, where RCCL refuses
+    # duplicate devices.  The measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("TGP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world,
-                                             device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
 
     from tgp.pytorch_amd.engine import ElboEngine
 
