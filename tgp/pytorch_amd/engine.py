@@ -27,11 +27,20 @@ def allreduce_flat(grad, n, world_size, group=None):
     identical on all ranks, so it is pre-divided and the sum restores it; ELBO is rebuilt from the reduced parts.
     Works on any backend (RCCL on the GPUs, gloo in the CPU tests)."""
     if world_size > 1:
-        out = grad[n:n + 4]
-        out[2].div_(world_size)
+        pre_reduce(grad, n, world_size)
         torch.distributed.all_reduce(grad, op=torch.distributed.ReduceOp.SUM, group=group)
-        out[0] = out[1] - out[2]
+        post_reduce(grad, n)
     return grad
+
+
+def pre_reduce(grad, n, world_size):
+    """KL is identical on every rank: pre-divide so that the sum restores it."""
+    grad[n + 2].div_(world_size)
+
+
+def post_reduce(grad, n):
+    """ELBO from the reduced parts."""
+    grad[n] = grad[n + 1] - grad[n + 2]
 
 
 def shard_rows(N, world_size, rank):
@@ -150,10 +159,13 @@ class ElboEngine:
             self.elbo()                      # first launch sets kernel attributes; must happen outside capture
         torch.cuda.synchronize()
         if self.world_size > 1 and not with_allreduce:
+            # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1):
                 self.elbo()
+                pre_reduce(self.fp.grad, self.fp.n, self.world_size)
             with torch.cuda.graph(self.g2):
+                post_reduce(self.fp.grad, self.fp.n)
                 self.adam()
             self.graph = "split"
         else:
@@ -169,7 +181,7 @@ class ElboEngine:
             self.g1.replay()
         else:
             self.g1.replay()
-            self.allreduce()
+            torch.distributed.all_reduce(self.fp.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             self.g2.replay()
 
     # ---- bookkeeping ---------------------------------------------------------------------------------
