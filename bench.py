@@ -21,6 +21,7 @@ Extra objects on the JSON line (rank 0):
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -38,6 +39,8 @@ WORKLOADS = {
     "tgp_power_sal2": dict(N=8611, D=4, M=100, S=32, flow="sal2", B=2, c=20),          # reference default for Power TGP
     "svgp_power": dict(N=8611, D=4, M=100, S=32, flow=None, B=0, c=0),                 # BASELINE.json configs[1]
     "svgp_boston": dict(N=455, D=13, M=5, S=32, flow=None, B=0, c=0),                  # BASELINE.json configs[0]
+    # BASELINE.json configs[3]: input-dependent SAL x 3, a_n, b_n from 6 MLPs 4 -> 50 -> 50 -> 1 (relu, dropout 0.25)
+    "idtgp_power_sal3": dict(N=8611, D=4, M=100, S=32, flow="idsal3", B=3, c=20, mlp=dict(H=50, L=2, p=0.25)),
     # BASELINE.json configs[4], one GPU's shard of the 2M-row full batch (8 x 250k), reference's airline flow 5x6
     "tgp_airline_tanh5x6": dict(N=250000, D=8, M=1000, S=32, flow="tanh5x6", B=5, c=52),
     "tgp_airline_mb10k": dict(N=10000, D=8, M=1000, S=32, flow="tanh5x6", B=5, c=52),    # C5b: minibatch 10k rows
@@ -60,22 +63,62 @@ def make_problem(w, seed):
     return orc.synthetic_problem(w["N"], w["D"], w["M"], seed=seed, flow=w["flow"], S=w["S"])
 
 
-def cpu_baseline(prob, budget_s=15.0, max_steps=400):
+def make_mlp(w, seed):
+    """ops.MlpSpec + packed weights for the workload's per-row parameter networks: torch.nn.Linear-style uniform
+    init, last layer scaled down and biased so that the flow starts near the identity (a = 0, b = 1)."""
+    from tgp.pytorch_amd import ops
+    nn_ = 2 * w["B"]
+    spec = ops.MlpSpec(w["D"], w["mlp"]["H"], w["mlp"]["L"], nn_, act="relu", drop_p=w["mlp"]["p"], seed=seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    W = torch.empty(nn_, spec.weights_per_net, dtype=torch.float64)
+    for k in range(nn_):
+        o, nin = 0, spec.D
+        for _ in range(spec.L):
+            n = spec.H * nin + spec.H
+            W[k, o:o + n] = (2 * torch.rand(n, generator=g, dtype=torch.float64) - 1) / math.sqrt(nin)
+            o += n
+            nin = spec.H
+        W[k, o:o + spec.H] = 0.1 * (2 * torch.rand(spec.H, generator=g, dtype=torch.float64) - 1) / math.sqrt(spec.H)
+        W[k, o + spec.H] = float(k % 2)        # a nets -> 0, b nets -> 1
+    return spec, W.reshape(-1)
+
+
+def torch_mlps(X, W, spec):
+    """The same nets as plain torch ops (eval mode) -- the CPU baseline's version of the per-row parameters."""
+    outs, pw = [], spec.weights_per_net
+    for k in range(spec.nnets):
+        wk = W[k * pw:(k + 1) * pw]
+        o, h, nin = 0, X, spec.D
+        for _ in range(spec.L):
+            h = torch.relu(h @ wk[o:o + spec.H * nin].reshape(spec.H, nin).T + wk[o + spec.H * nin:o + spec.H * nin + spec.H])
+            o += spec.H * nin + spec.H
+            nin = spec.H
+        outs.append(h @ wk[o:o + spec.H] + wk[o + spec.H])
+    return torch.stack(outs, 1)
+
+
+def cpu_baseline(prob, budget_s=15.0, max_steps=400, mlp=None):
     """Oracle step (reference-shaped eager PyTorch-CPU float64 + autograd + torch Adam) on the host cores.
     The thread count is calibrated first (a 256-thread pool is pathological for these small ops: one step took
     38 s); `cores` reports the count actually used."""
     from oracle import tgp_oracle as orc
     leaves = {k: v.clone().requires_grad_(True) for k, v in prob["params"].items()}
-    opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
+    groups = [{"params": list(leaves.values())}]
+    Wn = None
+    if mlp is not None:
+        Wn = mlp[1].clone().requires_grad_(True)
+        groups.append({"params": [Wn], "weight_decay": 1e-5})
+    opt = torch.optim.Adam(groups, lr=0.01)
     N = prob["X"].shape[0]
     big = leaves["m"].numel() > 128
     ns = min(N, 16384) if big else N      # bounded sample: the reference materialises (N,M) matrices many times over
     X_s, Y_s = prob["X"][:ns], prob["Y"][:ns]
 
     def one():
+        rowp = torch_mlps(X_s, Wn, mlp[0]) if mlp is not None else None
         elbo, _, _ = orc.elbo(X_s, Y_s, leaves["Z"], leaves["raw_lengthscale"], leaves["raw_outputscale"],
                               leaves["m"], leaves["Lam"], leaves["log_var_noise"], prob["N_total"], prob["program"],
-                              leaves.get("theta"), prob["xs"], prob["ws"])
+                              leaves.get("theta"), prob["xs"], prob["ws"], rowp)
         opt.zero_grad()
         (-elbo).backward()
         opt.step()
@@ -143,8 +186,10 @@ def main():
     w = WORKLOADS[args.workload]
     prob = make_problem(w, seed=rank)              # every rank: its own Power-sized shard, same parameters (seed 0)
     params = make_problem(w, seed=0)["params"] if rank else prob["params"]
+    mlp = make_mlp(w, seed=0) if "mlp" in w else None       # same networks on every rank
     eng = ElboEngine(prob["X"], prob["Y"], params, N_total=float(w["N"] * world), flow_blocks=prob["program"],
-                     S=w["S"], device=dev, world_size=world, rank=rank, mb_global=w["N"] * world)
+                     S=w["S"], device=dev, world_size=world, rank=rank, mb_global=w["N"] * world,
+                     mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None)
 
     def barrier():
         if world > 1:
@@ -217,7 +262,7 @@ def main():
                          "kernel_ms": k_ms, "kernel_ms_min": ks[0], "flop_per_launch": flop},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds, mlp=mlp)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -216,6 +216,29 @@ int tgp_kmeans_segsum_f64(const double* X, int32_t D, const int64_t* order, cons
 int tgp_kmeans_pp_f64(const double* X, int32_t N, int32_t D, const int64_t* cand, int32_t T, const double* closest,
                       double* out, void* stream);
 
+/* The per-row parameter networks of the input-dependent flows: Sinh_ArcsinhFlow's NNets_a / NNets_b,
+ * models/flow.py:836-897,949-965 -- `nnets` MLPs of one architecture D -> H (x L hidden layers) -> 1, each layer
+ * Linear -> activation -> Dropout(p) (pytorchlib apply_linear, flow.py:853-871; layer order unpinned).
+ * Packed weights per net, torch parameter order: [W1 (H,D) | b1 (H) | W2 (H,H) | b2 (H) | ... | Wout (1,H) | bout (1)].
+ * Dropout masks are a counter-based hash of (seed, step, net, layer, row, unit); `step_dev` (int32 on the device,
+ * e.g. the Adam step counter of tgp_adam_dev_f64; NULL = 0) makes the mask change every step and stay valid under
+ * hipGraph replay; forward and backward of one step must see the same value.  H <= 64, L <= 3. */
+typedef struct tgp_mlp {
+  int32_t N, D, H, L, nnets;
+  int32_t act;      /* 0 relu, 1 tanh */
+  int32_t training; /* != 0: dropout active (set_is_training, models/sparse_MF_SP.py:133-134) */
+  int32_t reserved0;
+  double drop_p;
+  uint64_t seed;
+} tgp_mlp;
+size_t tgp_mlp_workspace_bytes(const tgp_mlp* mlp);
+/* out (N, nnets): column k = output of net k (feeds `rowp` of tgp_elbo_step_f64). */
+int tgp_mlp_forward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev, double* out,
+                        void* stream);
+/* g_W (nnets * weights_per_net) = d(objective)/dW given g_out (N, nnets) (= g_rowp of tgp_elbo_step_f64). */
+int tgp_mlp_backward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev,
+                         const double* g_out, double* g_W, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Adam on a flat parameter buffer (torch.optim.Adam semantics, dsp/trainers/optimizers.py:12; L2 weight decay
  * added to the gradient as torch does).  `maximize` != 0 ascends (gradients here are of +ELBO). */
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
@@ -228,6 +251,13 @@ int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* e
 int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int32_t maximize,
                      void* stream);
+
+/* tgp_adam_dev_f64 with two parameter groups in one buffer: elements [0, n_plain) without weight decay, elements
+ * [n_plain, n) with `weight_decay_tail` -- the reference's optimiser groups (main.py:276-288: weight decay 1e-5 on
+ * the parameters whose name contains 'NNets'). */
+int tgp_adam_dev_groups_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n,
+                            double lr, double beta1, double beta2, double eps, int64_t n_plain, double weight_decay_tail,
+                            int32_t* step_dev, int32_t maximize, void* stream);
 
 #ifdef __cplusplus
 }

@@ -373,3 +373,89 @@ def test_kmeans_hip_matches_sklearn(N, D, K, n_init):
     Zh = Zh.cpu()
     assert Zh.shape == (K, D)
     assert rel_err(Zh, Zs) < 1e-8, (rel_err(Zh, Zs), info["n_iter"])
+
+
+def _torch_mlps(X, W, spec, masks=None):
+    """Reference: the nets as plain torch ops on the packed weights (Linear -> act -> dropout mask / (1-p))."""
+    outs = []
+    pw = spec.weights_per_net
+    actf = torch.relu if spec.act == 0 else torch.tanh
+    for k in range(spec.nnets):
+        w = W[k * pw:(k + 1) * pw]
+        o, h, nin = 0, X, spec.D
+        for l in range(spec.L):
+            Wl = w[o:o + spec.H * nin].reshape(spec.H, nin); o += spec.H * nin
+            bl = w[o:o + spec.H]; o += spec.H
+            h = actf(h @ Wl.T + bl)
+            if masks is not None:
+                h = h * masks[k][l] / (1.0 - spec.drop_p)
+            nin = spec.H
+        outs.append(h @ w[o:o + spec.H] + w[o + spec.H])
+    return torch.stack(outs, 1)
+
+
+@pytest.mark.parametrize("N,D,H,Lh,nnets,act,p", [(1000, 4, 50, 2, 6, "relu", 0.25), (333, 7, 17, 1, 2, "tanh", 0.1),
+                                                   (129, 3, 32, 3, 3, "relu", 0.0)])
+def test_mlp_kernels_match_torch(N, D, H, Lh, nnets, act, p):
+    """tgp_mlp_forward/backward_f64 (the NNets of the input-dependent flows, flow.py:836-897) against torch autograd:
+    eval mode, and training mode with the dropout mask restated on the host (ops.mlp_keep_mask)."""
+    from tgp.pytorch_amd import ops
+    g = torch.Generator().manual_seed(3)
+    spec = ops.MlpSpec(D, H, Lh, nnets, act=act, drop_p=p, seed=1234)
+    X = torch.randn(N, D, generator=g, dtype=torch.float64)
+    W = (0.4 * torch.randn(nnets * spec.weights_per_net, generator=g, dtype=torch.float64)).requires_grad_(True)
+    G = torch.randn(N, nnets, generator=g, dtype=torch.float64)
+    step = torch.tensor([7, 0], dtype=torch.int32, device=DEV)
+    for training in (False, True):
+        masks = None
+        if training and p > 0:
+            masks = [[torch.from_numpy(ops.mlp_keep_mask(1234, 7, k, l, N, H, p)).to(torch.float64) for l in range(Lh)]
+                     for k in range(nnets)]
+        ref = _torch_mlps(X, W, spec, masks)
+        gW_ref, = torch.autograd.grad((ref * G).sum(), W)
+        out = ops.mlp_forward(spec, X.to(DEV), W.detach().to(DEV), training, step)
+        gW = ops.mlp_backward(spec, X.to(DEV), W.detach().to(DEV), G.to(DEV), training, step)
+        torch.cuda.synchronize()
+        assert rel_err(out.cpu(), ref.detach()) < 1e-12, (training, rel_err(out.cpu(), ref.detach()))
+        assert rel_err(gW.cpu(), gW_ref) < 1e-11, (training, rel_err(gW.cpu(), gW_ref))
+    if p > 0:
+        keep = ops.mlp_keep_mask(1234, 7, 0, 0, 4000, H, p)
+        assert abs(keep.mean() - (1 - p)) < 0.01          # the mask keeps 1 - p of the units
+        assert (ops.mlp_keep_mask(1234, 8, 0, 0, 4000, H, p) != keep).mean() > 0.05   # and changes with the step
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_engine_id_tgp_hip_mlps_match_oracle_adam_history(graph):
+    """ID_TGP with everything resident: MLPs (tgp_mlp_*_f64) -> fused ELBO step -> MLP backward -> grouped Adam
+    (weight decay 1e-5 on the network weights, main.py:276-288), 4 steps, against the oracle + the same nets as torch
+    ops + torch.optim.Adam with two parameter groups.  Dropout off (deterministic comparison)."""
+    import bench
+    from tgp.pytorch_amd.engine import ElboEngine
+    w = dict(N=300, D=4, M=20, S=12, flow="idsal3", B=3, c=20, mlp=dict(H=50, L=2, p=0.25))
+    prob = orc.synthetic_problem(w["N"], w["D"], w["M"], seed=4, flow="idsal3", S=w["S"])
+    spec, W0 = bench.make_mlp(w, seed=0)
+    leaves = {k: t.clone().requires_grad_(True) for k, t in prob["params"].items()}
+    Wn = W0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": list(leaves.values())}, {"params": [Wn], "weight_decay": 1e-5}], lr=0.01)
+    ref = []
+    for _ in range(4):
+        rowp = bench.torch_mlps(prob["X"], Wn, spec)
+        elbo, ell, kl = orc.elbo(prob["X"], prob["Y"], leaves["Z"], leaves["raw_lengthscale"], leaves["raw_outputscale"],
+                                 leaves["m"], leaves["Lam"], leaves["log_var_noise"], prob["N_total"], prob["program"],
+                                 leaves.get("theta"), prob["xs"], prob["ws"], rowp)
+        ref.append([float(elbo.detach()), float(ell.detach()), float(kl.detach())])
+        opt.zero_grad()
+        (-elbo).backward()
+        opt.step()
+    eng = ElboEngine(prob["X"], prob["Y"], prob["params"], float(prob["N_total"]), flow_blocks=prob["program"], S=w["S"],
+                     device=DEV, mlp=spec, mlp_weights=W0, mlp_training=False)
+    hist = []
+    if graph:
+        eng.capture()
+    for _ in range(4):
+        (eng.replay if graph else eng.step)()
+        hist.append(list(eng.scalars()))
+    eng.check_status()
+    assert rel_err(torch.tensor(hist, dtype=torch.float64), torch.tensor(ref, dtype=torch.float64)) < 1e-8
+    assert rel_err(eng.fp.view("nn").cpu(), Wn.detach()) < 1e-7
+    assert rel_err(eng.fp.view("Z").cpu(), leaves["Z"].detach()) < 1e-7

@@ -341,4 +341,44 @@ int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, doubl
                          static_cast<hipStream_t>(stream));
 }
 
+int tgp_adam_dev_groups_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n,
+                            double lr, double beta1, double beta2, double eps, int64_t n_plain, double weight_decay_tail,
+                            int32_t* step_dev, int32_t maximize, void* stream) {
+  if (!params) return -1;
+  if (!grads) return -2;
+  if (!exp_avg) return -3;
+  if (!exp_avg_sq) return -4;
+  if (n < 1) return -5;
+  if (n_plain < 0 || n_plain > n) return -10;
+  if (!step_dev) return -12;
+  return launch_adam_dev(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay_tail, step_dev, maximize,
+                         static_cast<hipStream_t>(stream), n_plain);
+}
+
+size_t tgp_mlp_workspace_bytes(const tgp_mlp* mlp) {
+  if (!mlp) return 0;
+  return mlp_workspace_doubles(mlp->N, mlp->D, mlp->H, mlp->L, mlp->nnets) * sizeof(double);
+}
+
+int tgp_mlp_forward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev, double* out,
+                        void* stream) {
+  if (!mlp) return -1;
+  if (!X) return -2;
+  if (!W) return -3;
+  if (!out) return -5;
+  return launch_mlp_forward(*mlp, X, W, step_dev, out, static_cast<hipStream_t>(stream));
+}
+
+int tgp_mlp_backward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev,
+                         const double* g_out, double* g_W, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!mlp) return -1;
+  if (!X) return -2;
+  if (!W) return -3;
+  if (!g_out) return -5;
+  if (!g_W) return -6;
+  if (!workspace) return -7;
+  return launch_mlp_backward(*mlp, X, W, step_dev, g_out, g_W, static_cast<double*>(workspace),
+                             workspace_bytes / sizeof(double), static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -50,6 +50,12 @@ int launch_kmeans_segsum(const double* X, int D, const int64_t* order, const int
 int launch_kmeans_pp(const double* X, int N, int D, const int64_t* cand, int T, const double* closest, double* out,
                      hipStream_t st);
 
+// tgp_mlp.hip
+size_t mlp_workspace_doubles(int N, int D, int H, int L, int nnets);
+int launch_mlp_forward(const tgp_mlp& d, const double* X, const double* W, const int32_t* step_dev, double* out, hipStream_t st);
+int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, const int32_t* step_dev, const double* g_out,
+                        double* g_W, double* ws, size_t ws_doubles, hipStream_t st);
+
 // tgp_lik.hip
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* log_var_noise,
                      double scale, double* out, double* g_mu, double* g_v, double* ws, hipStream_t st);
@@ -64,7 +70,7 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
                 double beta1, double beta2, double eps, double weight_decay, int step, int maximize, hipStream_t st);
 int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
-                    hipStream_t st);
+                    hipStream_t st, int64_t n_plain = 0);
 size_t lik_workspace_doubles(int N, int P, int RP);
 
 }  // namespace tgp

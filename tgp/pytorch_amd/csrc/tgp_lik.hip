@@ -251,13 +251,13 @@ __global__ __launch_bounds__(256) void k_adam(double* __restrict__ p, const doub
 __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const double* __restrict__ g,
                                                    double* __restrict__ m, double* __restrict__ v, int64_t n, double lr,
                                                    double b1, double b2, double eps, double wd,
-                                                   int32_t* __restrict__ step_dev, double sign) {
+                                                   int32_t* __restrict__ step_dev, double sign, int64_t n_plain) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const double step = (double)(step_dev[0] + 1);
   if (i < n) {
     const double bc1 = 1.0 - pow(b1, step), bc2s = sqrt(1.0 - pow(b2, step));
     double gi = sign * g[i];
-    if (wd != 0.0) gi += wd * p[i];
+    if (wd != 0.0 && i >= n_plain) gi += wd * p[i];  // weight decay only on the tail group
     const double mi = b1 * m[i] + (1.0 - b1) * gi;
     const double vi = b2 * v[i] + (1.0 - b2) * gi * gi;
     m[i] = mi;
@@ -341,9 +341,9 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
 
 int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
-                    hipStream_t st) {
+                    hipStream_t st, int64_t n_plain) {
   hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
-                     n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0);
+                     n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0, n_plain);
   LAUNCH_CHECK();
   return 0;
 }

@@ -18,7 +18,7 @@ import torch
 from . import lib as L
 from . import ops
 
-ORDER = ("Z", "raw_ls", "raw_os", "m", "Lam", "lvn", "theta")
+ORDER = ("Z", "raw_ls", "raw_os", "m", "Lam", "lvn", "theta", "nn")   # "nn" (packed MLP weights) last: the weight-decay group
 
 
 def allreduce_flat(grad, n, world_size, group=None):
@@ -85,7 +85,10 @@ class FlatParams:
 class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
                  eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
-                 kernel="scale_rbf"):
+                 kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True):
+        """`mlp` (ops.MlpSpec) + `mlp_weights` (packed, nnets * weights_per_net): input-dependent flow (ID_TGP) whose
+        per-row parameters come from the HIP MLP kernels inside the step; `nn_weight_decay` is the reference's Adam
+        group for the 'NNets' parameters (main.py:276-288)."""
         self.lib = L.load()
         self.device = torch.device(device)
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
@@ -95,6 +98,12 @@ class ElboEngine:
         names = {"Z": "Z", "raw_ls": "raw_lengthscale", "raw_os": "raw_outputscale", "m": "m", "Lam": "Lam",
                  "lvn": "log_var_noise", "theta": "theta"}
         tensors = {k: params.get(v, params.get(k)) for k, v in names.items()}
+        self.mlp, self.mlp_training, self.nn_wd = mlp, bool(mlp_training), float(nn_weight_decay)
+        if mlp is not None:
+            tensors["nn"] = mlp_weights.reshape(-1)
+            assert tensors["nn"].numel() == mlp.nnets * mlp.weights_per_net
+            assert rowp is None, "per-row parameters come from the MLPs"
+            rowp = torch.zeros(self.N, mlp.nnets, dtype=torch.float64)
         tensors["raw_ls"] = tensors["raw_ls"].reshape(-1)
         tensors["raw_os"] = tensors["raw_os"].reshape(-1)
         tensors["lvn"] = tensors["lvn"].reshape(-1)
@@ -126,6 +135,10 @@ class ElboEngine:
             self.gs.rowp = L.ptr(self.g_rowp)
         self.ws = ops.workspace(self.N, self.D, self.M, self.md.S, self.md.nblk, self.md.P, self.md.RP, self.device,
                                 self.md.kernel)
+        self.mlp_ws = None
+        if self.mlp is not None:
+            d = self.mlp.struct(self.N, True)
+            self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
         self.graph = None
         self._warm = False
 
@@ -141,13 +154,34 @@ class ElboEngine:
         allreduce_flat(self.fp.grad, self.fp.n, self.world_size, self.pg)
 
     def adam(self):
-        rc = self.lib.tgp_adam_dev_f64(L.ptr(self.fp.data), L.ptr(self.fp.grad), L.ptr(self.fp.exp_avg),
-                                       L.ptr(self.fp.exp_avg_sq), self.fp.n, self.lr, self.betas[0], self.betas[1],
-                                       self.eps, 0.0, L.ptr(self.step_dev), 1, L.stream_ptr())
-        L.check(rc, "tgp_adam_dev_f64")
+        n_plain = self.fp.offsets["nn"] if self.mlp is not None else self.fp.n
+        rc = self.lib.tgp_adam_dev_groups_f64(L.ptr(self.fp.data), L.ptr(self.fp.grad), L.ptr(self.fp.exp_avg),
+                                              L.ptr(self.fp.exp_avg_sq), self.fp.n, self.lr, self.betas[0], self.betas[1],
+                                              self.eps, n_plain, self.nn_wd if self.mlp is not None else 0.0,
+                                              L.ptr(self.step_dev), 1, L.stream_ptr())
+        L.check(rc, "tgp_adam_dev_groups_f64")
+
+    def mlp_forward(self):
+        if self.mlp is not None:
+            d = self.mlp.struct(self.N, self.mlp_training)
+            L.check(self.lib.tgp_mlp_forward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")), L.ptr(self.step_dev),
+                                                 L.ptr(self.rowp), L.stream_ptr()), "tgp_mlp_forward_f64")
+
+    def mlp_backward(self):
+        if self.mlp is not None:
+            d = self.mlp.struct(self.N, self.mlp_training)
+            L.check(self.lib.tgp_mlp_backward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")), L.ptr(self.step_dev),
+                                                  L.ptr(self.g_rowp), L.ptr(self.fp.gview("nn")), L.ptr(self.mlp_ws),
+                                                  self.mlp_ws.numel() * 8, L.stream_ptr()), "tgp_mlp_backward_f64")
+
+    def forward_backward(self):
+        """MLPs -> fused ELBO step -> MLP backward: every gradient of the flat buffer is written."""
+        self.mlp_forward()
+        self.elbo()
+        self.mlp_backward()
 
     def step(self):
-        self.elbo()
+        self.forward_backward()
         self.allreduce()
         self.adam()
 
@@ -156,13 +190,13 @@ class ElboEngine:
         """Capture one full step.  With world_size > 1 the all-reduce stays outside (two graphs) unless
         with_allreduce=True."""
         if not self._warm:
-            self.elbo()                      # first launch sets kernel attributes; must happen outside capture
+            self.forward_backward()          # first launch sets kernel attributes; must happen outside capture
         torch.cuda.synchronize()
         if self.world_size > 1 and not with_allreduce:
             # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1):
-                self.elbo()
+                self.forward_backward()
                 pre_reduce(self.fp.grad, self.fp.n, self.world_size)
             with torch.cuda.graph(self.g2):
                 post_reduce(self.fp.grad, self.fp.n)
@@ -171,7 +205,7 @@ class ElboEngine:
         else:
             self.g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1):
-                self.elbo()
+                self.forward_backward()
                 self.allreduce()
                 self.adam()
             self.graph = "full"

@@ -224,6 +224,39 @@ class CompositeFlow(Flow):
             flow.turn_off_initializer_parameters()
 
 
+def mlp_spec(nets, seed=0):
+    """ops.MlpSpec of a list of per-row parameter networks if they share one architecture the HIP kernels cover
+    (Sequential of apply_linear: D -> H x L -> 1, relu/tanh, dropout), else None (the caller evaluates them in PyTorch)."""
+    try:
+        first = nets[0]
+        layers = list(first)
+        D, H, Lh = layers[0].linear.in_features, layers[0].linear.out_features, len(layers) - 1
+        act = {nn.ReLU: "relu", nn.Tanh: "tanh"}[type(layers[0].act)]
+        p = layers[0].drop.p if layers[0].drop is not None else 0.0
+        if not (1 <= Lh <= 3 and H <= 64):
+            return None
+        for net in nets:
+            ls = list(net)
+            if len(ls) != Lh + 1 or ls[-1].linear.out_features != 1 or not isinstance(ls[-1].act, nn.Identity):
+                return None
+            nin = D
+            for l in ls[:-1]:
+                if (l.linear.in_features, l.linear.out_features) != (nin, H) or type(l.act) is not type(layers[0].act):
+                    return None
+                if (l.drop.p if l.drop is not None else 0.0) != p:
+                    return None
+                nin = H
+            if ls[-1].linear.in_features != H:
+                return None
+        spec = ops.MlpSpec(D, H, Lh, len(nets), act=act, drop_p=p, seed=seed)
+        # weights + activation strips must fit one CU's LDS (tgp_mlp.hip)
+        if (spec.weights_per_net + (D + Lh * H) * 129 + 128) * 8 > 158 * 1024:
+            return None
+        return spec
+    except (KeyError, AttributeError, IndexError, TypeError):
+        return None
+
+
 def compile_flow(flow):
     """CompositeFlow -> (ops.FlowSpec, [shared scalar nn.Parameters in theta order], [per-row MLPs in column order])."""
     blocks, theta, nets = [], [], []

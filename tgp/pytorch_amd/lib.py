@@ -36,6 +36,12 @@ class TgpGrads(C.Structure):
                 ("theta", _dp), ("rowp", _dp)]
 
 
+class TgpMlp(C.Structure):
+    _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("nnets", C.c_int32),
+                ("act", C.c_int32), ("training", C.c_int32), ("reserved0", C.c_int32), ("drop_p", C.c_double),
+                ("seed", C.c_uint64)]
+
+
 class TgpError(RuntimeError):
     pass
 
@@ -67,6 +73,11 @@ _SIGS = {
     "tgp_kmeans_assign_f64": (C.c_int, [_dp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp]),
     "tgp_kmeans_segsum_f64": (C.c_int, [_dp, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]),
     "tgp_kmeans_pp_f64": (C.c_int, [_dp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp]),
+    "tgp_mlp_workspace_bytes": (C.c_size_t, [C.POINTER(TgpMlp)]),
+    "tgp_mlp_forward_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp]),
+    "tgp_mlp_backward_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_adam_dev_groups_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_int64, C.c_double, _dp, C.c_int32, _dp]),
     "tgp_adam_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, C.c_int32, C.c_int32, _dp]),
     "tgp_adam_dev_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,

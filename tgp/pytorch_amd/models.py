@@ -138,7 +138,21 @@ class sparse_MF_SP(nn.Module):
         ctx = torch.enable_grad() if with_grad else torch.no_grad()
         with ctx:
             theta = torch.stack([p.reshape(()) for p in theta_list]) if theta_list else None
-            rowp = torch.cat([net(X2d) for net in nets], dim=-1) if nets else None
+            rowp = None
+            if nets:
+                if "mlp" not in self._cfg:
+                    from .flow import mlp_spec
+                    self._cfg["mlp"] = mlp_spec(nets, seed=cg.config_seed)
+                    self._cfg["mlp_step"] = torch.zeros(2, dtype=torch.int32, device=X2d.device)
+                mspec = self._cfg["mlp"]
+                if mspec is not None:
+                    # all nets in one HIP launch (tgp_mlp_forward/backward_f64); a fresh dropout mask per call, the same
+                    # one for this call's backward (the counter moves before the forward, not after it)
+                    self._cfg["mlp_step"][0] += 1
+                    W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
+                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(nets[0].training), self._cfg["mlp_step"])
+                else:
+                    rowp = torch.cat([net(X2d) for net in nets], dim=-1)
         return spec, theta, rowp
 
     # ---- model computations ------------------------------------------------------------------------

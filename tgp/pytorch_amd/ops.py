@@ -427,6 +427,92 @@ def predict(mu, v, lvn, flow=None, theta=None, S=None, rowp=None, Y=None, Y_std=
     return m1, m2, logp
 
 
+# ---------------------------------------------------------------------------------------------------
+# per-row parameter networks of the input-dependent flows (models/flow.py:836-897)
+# ---------------------------------------------------------------------------------------------------
+class MlpSpec:
+    """nnets MLPs of one architecture D -> H x L -> 1 (Linear -> act -> Dropout per hidden layer)."""
+
+    def __init__(self, D, H, L, nnets, act="relu", drop_p=0.0, seed=0):
+        self.D, self.H, self.L, self.nnets = int(D), int(H), int(L), int(nnets)
+        self.act = {"relu": 0, "tanh": 1}[act]
+        self.drop_p, self.seed = float(drop_p), int(seed)
+
+    @property
+    def weights_per_net(self):
+        return self.D * self.H + self.H + (self.L - 1) * (self.H * self.H + self.H) + self.H + 1
+
+    def struct(self, N, training):
+        d = L.TgpMlp()
+        d.N, d.D, d.H, d.L, d.nnets, d.act = int(N), self.D, self.H, self.L, self.nnets, self.act
+        d.training, d.drop_p, d.seed = int(bool(training)), self.drop_p, self.seed
+        return d
+
+
+def mlp_forward(spec, X, W, training=False, step_dev=None):
+    """out (N, nnets) = the nets' outputs for every row (tgp_mlp_forward_f64)."""
+    X, W = _c(X, "X"), _c(W, "W")
+    d = spec.struct(X.shape[0], training)
+    out = torch.empty(X.shape[0], spec.nnets, dtype=torch.float64, device=X.device)
+    L.check(L.load().tgp_mlp_forward_f64(d, L.ptr(X), L.ptr(W), L.ptr(step_dev), L.ptr(out), L.stream_ptr()),
+            "tgp_mlp_forward_f64")
+    return out
+
+
+_mlp_ws = {}
+
+
+def mlp_backward(spec, X, W, g_out, training=False, step_dev=None, g_W=None):
+    """d(objective)/dW (packed like W) from g_out (N, nnets) (tgp_mlp_backward_f64; recomputes the forward)."""
+    X, W, g_out = _c(X, "X"), _c(W, "W"), _c(g_out, "g_out")
+    lib = L.load()
+    d = spec.struct(X.shape[0], training)
+    key = (X.shape[0], spec.D, spec.H, spec.L, spec.nnets, str(X.device), torch.cuda.current_stream().cuda_stream)
+    ws = _mlp_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=X.device)
+        _mlp_ws[key] = ws
+    if g_W is None:
+        g_W = torch.empty_like(W)
+    L.check(lib.tgp_mlp_backward_f64(d, L.ptr(X), L.ptr(W), L.ptr(step_dev), L.ptr(g_out), L.ptr(g_W), L.ptr(ws),
+                                     ws.numel() * 8, L.stream_ptr()), "tgp_mlp_backward_f64")
+    return g_W
+
+
+class MlpFunction(torch.autograd.Function):
+    """rowp = MLPs(X; W) with the HIP forward/backward; W is the packed weight vector (torch.cat of the nets'
+    parameters, so autograd scatters g_W back onto the individual nn.Parameters)."""
+
+    @staticmethod
+    def forward(ctx, X, W, spec, training, step_dev):
+        ctx.spec, ctx.training, ctx.step_dev = spec, training, step_dev
+        ctx.save_for_backward(X, W)
+        return mlp_forward(spec, X, W.detach(), training, step_dev)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        X, W = ctx.saved_tensors
+        return None, mlp_backward(ctx.spec, X, W.detach(), g_out.contiguous(), ctx.training, ctx.step_dev), None, None, None
+
+
+def mlp_keep_mask(seed, step, net, layer, rows, units, p):
+    """The dropout keep mask of tgp_mlp.hip (rows x units, bool) restated in numpy: test infrastructure and the
+    reference for anyone who needs to reproduce a training-mode forward elsewhere."""
+    import numpy as np
+    M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+    r = np.arange(rows, dtype=np.uint64).reshape(-1, 1)
+    ug = (np.arange(units, dtype=np.uint64) >> np.uint64(2)).reshape(1, -1)
+    lane = (np.arange(units, dtype=np.uint64) & np.uint64(3)).reshape(1, -1)
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(step)) & M64
+        z = z ^ (np.uint64(net) << np.uint64(56)) ^ (np.uint64(layer) << np.uint64(48)) ^ (ug << np.uint64(32)) ^ r
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M64
+        z = z ^ (z >> np.uint64(31))
+    bits = (z >> (np.uint64(16) * lane)) & np.uint64(0xFFFF)
+    return bits >= np.uint64(int(p * 65536.0 + 0.5))
+
+
 def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
               maximize=False):
     """In-place Adam on flat float64 buffers (torch.optim.Adam semantics)."""
