@@ -4,13 +4,13 @@
 // at BASELINE config C4, with dropout active in training (MC dropout, sparse_MF_SP.py:133-134).
 //
 // All nets of a flow have one architecture, so they run as ONE launch: grid = (row blocks, nets), 128 rows per
-// block, one thread per row.  A net's weights (2 851 doubles at C4) and the block's activations ([H][128] per
-// layer: a thread's column is its private, conflict-free strip) live in LDS; weights are read as wave-uniform
-// broadcasts, four output units per activation read.
+// block = 2 waves x 64 rows.  A net's weights (zero-padded to 64 units x pad4(inputs)) and the block's activation
+// strips [unit][row] live in LDS; every layer product runs on v_mfma_f64_16x16x4_f64 with the weight tile as the A
+// operand and four 16-row groups of the strip as B operands (the strip layout is k-major, conflict-free).
 //   forward : out[n][net]
-//   backward: recomputes the forward (cheaper than storing N x H x L activations in HBM), back-propagates
-//             d out, and forms the weight gradients block-cooperatively as [units x 128 rows] x [128 rows x units]
-//             contractions from LDS; per-block partials are summed in a second kernel in a fixed order.
+//   backward: recomputes the forward (cheaper than storing N x H x L activations in HBM), back-propagates d out with
+//             W^T tiles as A operands, and forms the weight gradients as [units x 128 rows] x [128 rows x units]
+//             MFMA contractions from the strips; per-block partials are summed in a second kernel in a fixed order.
 // Dropout is a counter-based hash of (seed, step, net, layer, row, unit): the same mask in the forward, in the
 // backward recomputation and under hipGraph replay (step is read from device memory), different every step.
 #include "tgp_dev.hpp"
@@ -24,102 +24,48 @@ namespace tgp {
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-#define MLP_T 128      /* rows per block */
-#define MLP_ST 129     /* LDS stride of an activation strip [unit][row]: a thread's own column is conflict-free and the
-                          block-cooperative (lanes across units) reads of the weight-gradient pass are 2-way at worst */
+#define MLP_T 128      /* rows per block = 2 waves x 64 rows */
+#define MLP_ST 129     /* LDS stride of an activation strip [unit][row] (k-major for the layer products) */
+#define MLP_HP 64      /* units padded to four 16-wide MFMA tiles */
 #define MLP_MAXH 64
 #define MLP_MAXL 3
 
 __host__ __device__ inline int mlp_weights_per_net(int D, int H, int L) {
   return D * H + H + (L - 1) * (H * H + H) + H + 1;
 }
+__host__ __device__ inline int mlp_pad4(int x) { return (x + 3) & ~3; }
 
-// Dropout keep test.  One splitmix64 finaliser per (seed, step, net, layer, row, unit / 4) yields four 16-bit lanes,
-// one per unit of the group: keep iff lane >= round(p * 65536)  (p is quantised to 1/65536; 0.25 is exact).
-__device__ __forceinline__ uint64_t mlp_hash4(uint64_t seed, int step, int net, int layer, int row, int ugroup) {
+// Dropout keep test.  One splitmix64 finaliser per (seed, step, net, layer, row, group) yields four 16-bit lanes, one
+// per unit of the group; unit j belongs to group (j >> 4) * 4 + (j & 3), lane (j >> 2) & 3 -- the four accumulator
+// registers of one MFMA lane.  keep iff lane >= round(p * 65536)  (p quantised to 1/65536; 0.25 is exact).
+__device__ __forceinline__ uint64_t mlp_hash4(uint64_t seed, int step, int net, int layer, int row, int group) {
   uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(unsigned)step;
-  z ^= ((uint64_t)(unsigned)net << 56) ^ ((uint64_t)(unsigned)layer << 48) ^ ((uint64_t)(unsigned)ugroup << 32) ^ (uint64_t)(unsigned)row;
+  z ^= ((uint64_t)(unsigned)net << 56) ^ ((uint64_t)(unsigned)layer << 48) ^ ((uint64_t)(unsigned)group << 32) ^ (uint64_t)(unsigned)row;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
 __device__ __forceinline__ unsigned mlp_thresh(double p) { return (unsigned)(p * 65536.0 + 0.5); }
-__device__ __forceinline__ bool mlp_keep(uint64_t seed, int step, int net, int layer, int row, int unit, double p) {
-  const uint64_t h = mlp_hash4(seed, step, net, layer, row, unit >> 2);
-  return (unsigned)((h >> (16 * (unit & 3))) & 0xFFFFu) >= mlp_thresh(p);
-}
 
 __device__ __forceinline__ double mlp_act(int act, double z) { return act == 0 ? fmax(z, 0.0) : tanh(z); }
 
-// one hidden layer for this thread's row: ain [nin][ST] -> aout [nout][ST]  (post-activation, post-dropout)
-__device__ __forceinline__ void mlp_layer(const double* __restrict__ W, const double* __restrict__ b, int nin, int nout,
-                                          const double* ain, double* aout, int tid, int act, bool drop, double p, double scale,
-                                          uint64_t seed, int step, int net, int layer, int row) {
-  int j = 0;
-  for (; j + 4 <= nout; j += 4) {
-    double s0 = b[j], s1 = b[j + 1], s2 = b[j + 2], s3 = b[j + 3];
-    const double* w0 = W + (size_t)j * nin;
-    int i = 0;
-    // 4 x 4 register block: 4 activation reads + 16 broadcast weight reads in flight per 16 FMAs (the loop is LDS-latency
-    // bound at two waves per CU unless several reads are outstanding)
-    for (; i + 4 <= nin; i += 4) {
-      double a[4], wv[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = ain[(i + u) * MLP_ST + tid];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wv[r][u] = w0[r * nin + i + u];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s0 = fma(wv[0][u], a[u], s0);
-        s1 = fma(wv[1][u], a[u], s1);
-        s2 = fma(wv[2][u], a[u], s2);
-        s3 = fma(wv[3][u], a[u], s3);
-      }
-    }
-    for (; i < nin; ++i) {
-      const double a = ain[i * MLP_ST + tid];
-      s0 = fma(w0[i], a, s0);
-      s1 = fma(w0[nin + i], a, s1);
-      s2 = fma(w0[2 * nin + i], a, s2);
-      s3 = fma(w0[3 * nin + i], a, s3);
-    }
-    double o[4] = {s0, s1, s2, s3};
-    const uint64_t h4 = drop ? mlp_hash4(seed, step, net, layer, row, j >> 2) : 0;
-    const unsigned th = mlp_thresh(p);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      double a = mlp_act(act, o[u]);
-      if (drop) a = ((unsigned)((h4 >> (16 * u)) & 0xFFFFu) >= th) ? a * scale : 0.0;
-      aout[(j + u) * MLP_ST + tid] = a;
-    }
-  }
-  for (; j < nout; ++j) {
-    double s = b[j];
-    for (int i = 0; i < nin; ++i) s = fma(W[(size_t)j * nin + i], ain[i * MLP_ST + tid], s);
-    double a = mlp_act(act, s);
-    if (drop) a = mlp_keep(seed, step, net, layer, row, j, p) ? a * scale : 0.0;
-    aout[j * MLP_ST + tid] = a;
-  }
-}
-
-// global -> LDS copy of one net's weights with 8 loads in flight per thread (a plain loop pays one memory round
-// trip per element: 22 of them at C4)
-__device__ __forceinline__ void mlp_stage_weights(const double* __restrict__ src, int n, double* dst, int tid) {
-  for (int base = 0; base < n; base += 8 * MLP_T) {
+// global -> LDS copy of one hidden layer's weights into the zero-padded [HP][KP] image (+ bias [HP])
+__device__ __forceinline__ void mlp_stage_layer(const double* __restrict__ src, int H, int nin, int KP, double* Wp, double* bp,
+                                                int tid) {
+  for (int base = 0; base < MLP_HP * KP; base += 8 * MLP_T) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = base + u * MLP_T + tid;
-      v[u] = i < n ? src[i] : 0.0;
+      const int e = base + u * MLP_T + tid, j = e / KP, i = e % KP;
+      v[u] = (e < MLP_HP * KP && j < H && i < nin) ? src[j * nin + i] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = base + u * MLP_T + tid;
-      if (i < n) dst[i] = v[u];
+      const int e = base + u * MLP_T + tid;
+      if (e < MLP_HP * KP) Wp[e] = v[u];
     }
   }
+  if (tid < MLP_HP) bp[tid] = tid < H ? src[H * nin + tid] : 0.0;
 }
 
 struct MlpArgs {
@@ -131,173 +77,268 @@ struct MlpArgs {
   const int32_t* step_dev;  // may be nullptr (step 0)
 };
 
-// LDS: weights (PW) | a0 [D][T] | a1 [H][T] | ... | aL [H][T]
-__global__ __launch_bounds__(MLP_T) void k_mlp_fwd(MlpArgs m, double* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* sm = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x, net = blockIdx.y, D = m.D, H = m.H, L = m.L;
-  const int PW = mlp_weights_per_net(D, H, L);
-  double* Wl = sm;
-  double* a0 = Wl + ((PW + 1) & ~1);
-  double* a1 = a0 + D * MLP_ST;
-  double* a2 = a1 + H * MLP_ST;
-  mlp_stage_weights(m.W + (size_t)net * PW, PW, Wl, tid);
-  const int row = blockIdx.x * MLP_T + tid, rc = row < m.N ? row : m.N - 1;
-  for (int d = 0; d < D; ++d) a0[d * MLP_ST + tid] = m.X[(size_t)rc * D + d];
-  __syncthreads();
-  const int step = m.step_dev ? m.step_dev[0] : 0;
-  const bool drop = m.training && m.p > 0.0;
-  const double scale = drop ? 1.0 / (1.0 - m.p) : 1.0;
-  const double* w = Wl;
-  const double* ain = a0;
-  int nin = D;
-  for (int l = 0; l < L; ++l) {
-    double* aout = (l & 1) ? a2 : a1;
-    mlp_layer(w, w + (size_t)H * nin, nin, H, ain, aout, tid, m.act, drop, m.p, scale, m.seed, step, net, l, row);
-    w += (size_t)H * nin + H;
-    ain = aout;
-    nin = H;
+// LDS image shared by both kernels:
+//   per hidden layer l: Wp_l [64][KP_l] (zero padded), b_l [64] ; output layer wo [64], bo [2]
+//   a0 [KP_0][ST] ; a_1 .. a_L [KPH][ST]  (KP_0 = pad4(D), KPH = pad4(H); padded units are exact zeros)
+// (offsets are closed-form: an array indexed by the layer would live in scratch memory)
+struct MlpLds {
+  int KP0, KPH, L, wo, act0, actl, gos, total;
+  __host__ __device__ int wp(int l) const { return l == 0 ? 0 : MLP_HP * KP0 + MLP_HP + (l - 1) * (MLP_HP * KPH + MLP_HP); }
+  __host__ __device__ int bp(int l) const { return wp(l) + MLP_HP * (l == 0 ? KP0 : KPH); }
+};
+__host__ __device__ inline MlpLds mlp_lds(int D, int H, int L, bool bwd) {
+  MlpLds o;
+  o.KP0 = mlp_pad4(D); o.KPH = mlp_pad4(H); o.L = L;
+  int p = o.bp(L - 1) + MLP_HP;
+  o.wo = p; p += MLP_HP + 2;
+  o.act0 = p; p += o.KP0 * MLP_ST;
+  o.actl = p; p += (bwd ? L : (L > 1 ? 2 : 1)) * o.KPH * MLP_ST;
+  p = (p + 1) & ~1;
+  o.gos = p; p += bwd ? MLP_T : 0;
+  o.total = p;
+  return o;
+}
+// offset of layer l inside the packed weight vector of a net (l == L: the output layer)
+__host__ __device__ inline int mlp_woff(int D, int H, int l) { return l == 0 ? 0 : D * H + H + (l - 1) * (H * H + H); }
+
+// (Both kernels declare two waves per SIMD: with the default 512-register budget hipcc splits the file into VGPRs and
+// AGPRs and shuttles all 32 accumulator registers through v_accvgpr_write/read around every k step.)
+//
+// One hidden layer on the matrix cores, this wave's 64 rows:  out[j][r] = act(b_j + sum_i W[j][i] in[i][r]) (+ dropout).
+//   A operand = W tile (lane: unit j = l&15, k = i = l>>4), B operand = activation strip rows (k-major), C/D: lane holds
+//   units q, q+4, q+8, q+12 of row r = l&15 -- exactly one dropout hash group.
+__device__ __forceinline__ void mlp_layer_mfma(const double* Wp, const double* bp, int KP, const double* ain, double* aout,
+                                               int KPout, int lane, int wave, int act, bool drop, double p, double scale,
+                                               uint64_t seed, int step, int net, int layer, int row0) {
+  const int n = lane & 15, q = lane >> 4;
+  const unsigned th = mlp_thresh(p);
+  for (int jt = 0; jt * 16 < KPout; ++jt) {
+    d4 acc[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rt][rr] = bp[16 * jt + q + 4 * rr];
+    // operands of k-step k0+4 are requested before the four MFMAs of k-step k0 issue (one wave per SIMD: nothing else
+    // would hide the LDS latency)
+    const double* wrow = Wp + (16 * jt + n) * KP + q;
+    const double* brow = ain + q * MLP_ST + 64 * wave + n;
+    double a = wrow[0], b[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) b[rt] = brow[16 * rt];
+    for (int k0 = 0; k0 < KP; k0 += 4) {
+      const int kn = k0 + 4 < KP ? k0 + 4 : k0;
+      const double an = wrow[kn];
+      double bn[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
+      a = an;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) b[rt] = bn[rt];
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int rl = 64 * wave + 16 * rt + n;
+      const uint64_t h4 = drop ? mlp_hash4(seed, step, net, layer, row0 + rl, 4 * jt + q) : 0;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int j = 16 * jt + q + 4 * rr;
+        double v = mlp_act(act, acc[rt][rr]);
+        if (drop) v = ((unsigned)((h4 >> (16 * rr)) & 0xFFFFu) >= th) ? v * scale : 0.0;
+        if (j < KPout) aout[j * MLP_ST + rl] = v;
+      }
+    }
   }
-  double s = w[H];
-  for (int i = 0; i < H; ++i) s = fma(w[i], ain[i * MLP_ST + tid], s);
-  if (row < m.N) out[(size_t)row * m.nnets + net] = s;
 }
 
-// backward; partial weight gradients of this (row block, net) into part[(blockIdx.x * nnets + net) * PW ...]
-// LDS: weights | a0 [D][ST] | a1 .. aL [H][ST] each.  The delta of a layer overwrites that layer's activations in place
-// (it depends on the thread's own element only, once the weight gradients that read the activations are done).
-__global__ __launch_bounds__(MLP_T) void k_mlp_bwd(MlpArgs m, const double* __restrict__ g_out, double* __restrict__ part) {
+__device__ __forceinline__ void mlp_stage_all(const MlpArgs& m, const MlpLds& Lo, double* sm, int net, int tid) {
+  const int PW = mlp_weights_per_net(m.D, m.H, m.L);
+  const double* src = m.W + (size_t)net * PW;
+  int nin = m.D;
+  for (int l = 0; l < m.L; ++l) {
+    mlp_stage_layer(src, m.H, nin, l == 0 ? Lo.KP0 : Lo.KPH, sm + Lo.wp(l), sm + Lo.bp(l), tid);
+    src += m.H * nin + m.H;
+    nin = m.H;
+  }
+  if (tid < MLP_HP) sm[Lo.wo + tid] = tid < m.H ? src[tid] : 0.0;
+  if (tid == 0) sm[Lo.wo + MLP_HP] = src[m.H];
+  // inputs: a0 [KP0][ST], this block's rows (padding rows repeat the last row; their d out is zero)
+  const int row = blockIdx.x * MLP_T + tid, rc = row < m.N ? row : m.N - 1;
+  for (int d = 0; d < Lo.KP0; ++d) sm[Lo.act0 + d * MLP_ST + tid] = d < m.D ? m.X[(size_t)rc * m.D + d] : 0.0;
+}
+
+__global__ __launch_bounds__(MLP_T, 2) void k_mlp_fwd(MlpArgs m, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x, net = blockIdx.y, D = m.D, H = m.H, L = m.L;
-  const int PW = mlp_weights_per_net(D, H, L);
-  double* Wl = sm;
-  double* act0 = Wl + ((PW + 1) & ~1);
-  double* actl = act0 + D * MLP_ST;
-  double* gos = actl + (size_t)L * H * MLP_ST;  // d out of the block's rows [T]
-  mlp_stage_weights(m.W + (size_t)net * PW, PW, Wl, tid);
-  const int row = blockIdx.x * MLP_T + tid;
-  const bool valid = row < m.N;
-  const int rc = valid ? row : m.N - 1;
-  for (int d = 0; d < D; ++d) act0[d * MLP_ST + tid] = m.X[(size_t)rc * D + d];
-  const double go = valid ? g_out[(size_t)row * m.nnets + net] : 0.0;
-  gos[tid] = go;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.y, H = m.H, L = m.L;
+  const MlpLds Lo = mlp_lds(m.D, H, L, false);
+  mlp_stage_all(m, Lo, sm, net, tid);
   __syncthreads();
   const int step = m.step_dev ? m.step_dev[0] : 0;
   const bool drop = m.training && m.p > 0.0;
   const double scale = drop ? 1.0 / (1.0 - m.p) : 1.0;
-  int woff[MLP_MAXL + 1];
-  {
-    int o = 0, nin = D;
-    for (int l = 0; l < L; ++l) { woff[l] = o; o += H * nin + H; nin = H; }
-    woff[L] = o;
+  const double* ain = sm + Lo.act0;
+  for (int l = 0; l < L; ++l) {
+    double* aout = sm + Lo.actl + (l & 1) * Lo.KPH * MLP_ST;
+    mlp_layer_mfma(sm + Lo.wp(l), sm + Lo.bp(l), l == 0 ? Lo.KP0 : Lo.KPH, ain, aout, Lo.KPH, lane, wave, m.act, drop, m.p, scale,
+                   m.seed, step, net, l, blockIdx.x * MLP_T);
+    ain = aout;
+    __builtin_amdgcn_wave_barrier();  // a wave reads back only its own 64 columns
   }
+  const int row = blockIdx.x * MLP_T + tid;
+  const double* wo = sm + Lo.wo;
+  double s0 = wo[MLP_HP], s1 = 0.0;
+  for (int i = 0; i + 2 <= Lo.KPH; i += 2) {
+    s0 = fma(wo[i], ain[i * MLP_ST + tid], s0);
+    s1 = fma(wo[i + 1], ain[(i + 1) * MLP_ST + tid], s1);
+  }
+  if (row < m.N) out[(size_t)row * m.nnets + net] = s0 + s1;
+}
+
+// backward; partial weight gradients of this (row block, net) into part[(blockIdx.x * nnets + net) * PW ...].
+// The delta of a layer overwrites that layer's activation strip in place (own element only).
+__global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* __restrict__ g_out, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+  const int net = blockIdx.y, D = m.D, H = m.H, L = m.L;
+  const int PW = mlp_weights_per_net(D, H, L);
+  const MlpLds Lo = mlp_lds(D, H, L, true);
+  const int KPH = Lo.KPH;
+  mlp_stage_all(m, Lo, sm, net, tid);
+  const int row = blockIdx.x * MLP_T + tid;
+  double* gos = sm + Lo.gos;
+  gos[tid] = row < m.N ? g_out[(size_t)row * m.nnets + net] : 0.0;
+  __syncthreads();
+  const int step = m.step_dev ? m.step_dev[0] : 0;
+  const bool drop = m.training && m.p > 0.0;
+  const double scale = drop ? 1.0 / (1.0 - m.p) : 1.0;
+  const unsigned th = mlp_thresh(m.p);
   // ---- forward recomputation, every layer's output kept ----
   {
-    const double* ain = act0;
-    int nin = D;
+    const double* ain = sm + Lo.act0;
     for (int l = 0; l < L; ++l) {
-      double* aout = actl + (size_t)l * H * MLP_ST;
-      const double* w = Wl + woff[l];
-      mlp_layer(w, w + (size_t)H * nin, nin, H, ain, aout, tid, m.act, drop, m.p, scale, m.seed, step, net, l, row);
+      double* aout = sm + Lo.actl + (size_t)l * KPH * MLP_ST;
+      mlp_layer_mfma(sm + Lo.wp(l), sm + Lo.bp(l), l == 0 ? Lo.KP0 : KPH, ain, aout, KPH, lane, wave, m.act, drop, m.p, scale,
+                     m.seed, step, net, l, blockIdx.x * MLP_T);
       ain = aout;
-      nin = H;
+      __builtin_amdgcn_wave_barrier();
     }
   }
   __syncthreads();
   double* gp = part + ((size_t)blockIdx.x * m.nnets + net) * PW;
-  // derivative of (activation -> dropout) through the stored value: relu' from its sign; tanh' needs the kept flag
-  auto dfac = [&](double a, int layer, int unit) {
+  // ---- output layer: out = wo . aL + bo :  dwo[i] = sum_rows go * aL[i][row], dbo = sum_rows go ----
+  double* aL = sm + Lo.actl + (size_t)(L - 1) * KPH * MLP_ST;
+  for (int i = tid; i <= H; i += MLP_T) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 2
+    for (int r = 0; r < MLP_T; r += 4) {
+      s0 = fma(gos[r], i < H ? aL[i * MLP_ST + r] : 1.0, s0);
+      s1 = fma(gos[r + 1], i < H ? aL[i * MLP_ST + r + 1] : 1.0, s1);
+      s2 = fma(gos[r + 2], i < H ? aL[i * MLP_ST + r + 2] : 1.0, s2);
+      s3 = fma(gos[r + 3], i < H ? aL[i * MLP_ST + r + 3] : 1.0, s3);
+    }
+    gp[mlp_woff(D, H, L) + i] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  // derivative of (activation -> dropout) through the stored value a; `kept` only matters for tanh
+  auto dfac = [&](double a, bool kept) {
     if (m.act == 0) return a > 0.0 ? scale : 0.0;
-    const bool kept = !drop || mlp_keep(m.seed, step, net, layer, row, unit, m.p);
     const double t = a / scale;
     return kept ? scale * (1.0 - t * t) : 0.0;
   };
-  // ---- output layer: out = Wo . aL + bo :  dWo[i] = sum_rows go * aL[i][row], dbo = sum_rows go ----
-  double* aL = actl + (size_t)(L - 1) * H * MLP_ST;
-  for (int i = tid; i <= H; i += MLP_T) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r < MLP_T; r += 2) {
-      s0 = fma(gos[r], i < H ? aL[i * MLP_ST + r] : 1.0, s0);
-      s1 = fma(gos[r + 1], i < H ? aL[i * MLP_ST + r + 1] : 1.0, s1);
-    }
-    gp[woff[L] + i] = s0 + s1;
-  }
-  __syncthreads();
+  auto kept_flag = [&](int layer, int rl, int j) {
+    if (!drop || m.act == 0) return true;
+    const uint64_t h4 = mlp_hash4(m.seed, step, net, layer, blockIdx.x * MLP_T + rl, (j >> 4) * 4 + (j & 3));
+    return (unsigned)((h4 >> (16 * ((j >> 2) & 3))) & 0xFFFFu) >= th;
+  };
   {
-    const double* wo = Wl + woff[L];
-    for (int i = 0; i < H; ++i) {
+    const double* wo = sm + Lo.wo;
+    const double go = gos[tid];
+    for (int i = 0; i < KPH; ++i) {
       const double a = aL[i * MLP_ST + tid];
-      aL[i * MLP_ST + tid] = wo[i] * go * dfac(a, L - 1, i);   // delta_L in place
+      aL[i * MLP_ST + tid] = wo[i] * go * dfac(a, kept_flag(L - 1, tid, i));   // delta_L in place (zero on padded units)
     }
   }
   __syncthreads();
-  // ---- hidden layers, last to first: the layer's buffer now holds its delta ----
+  // ---- hidden layers, last to first: the layer's strip now holds its delta ----
   for (int l = L - 1; l >= 0; --l) {
-    const int nin = l == 0 ? D : H;
-    const double* dl = actl + (size_t)l * H * MLP_ST;
-    double* ain = l == 0 ? act0 : actl + (size_t)(l - 1) * H * MLP_ST;
-    const double* w = Wl + woff[l];
-    // dW[j][i] = sum_rows delta[j][row] * ain[i][row] ; db[j] = sum_rows delta[j][row]   (block-cooperative)
-    for (int e = tid; e < H * (nin + 1); e += MLP_T) {
-      const int j = e / (nin + 1), i = e % (nin + 1);
-      const double* dj = dl + j * MLP_ST;
-      double s0 = 0.0, s1 = 0.0;
-      if (i < nin) {
-        const double* ai = ain + i * MLP_ST;
-        double s2 = 0.0, s3 = 0.0;
-        for (int r = 0; r < MLP_T; r += 8) {
-          double dv[8], av[8];
+    const int nin = l == 0 ? D : H, KPin = l == 0 ? Lo.KP0 : KPH;
+    const double* dl = sm + Lo.actl + (size_t)l * KPH * MLP_ST;
+    double* ain = l == 0 ? sm + Lo.act0 : sm + Lo.actl + (size_t)(l - 1) * KPH * MLP_ST;
+    // dW[j][i] = sum_rows delta[j][row] ain[i][row]: 16 x 16 tiles over the block's 128 rows, tiles dealt to the two waves
+    {
+      const int njt = (H + 15) / 16, nit = (nin + 15) / 16;
+      for (int t = wave; t < njt * nit; t += 2) {
+        const int jt = t / nit, it = t % nit;
+        const int ja = 16 * jt + n, ib = 16 * it + n;
+        const bool va = ja < KPH, vb = ib < KPin;
+        const double* pa = dl + (va ? ja : 0) * MLP_ST + q;
+        const double* pb = ain + (vb ? ib : 0) * MLP_ST + q;
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll 2
+        for (int r0 = 0; r0 < MLP_T; r0 += 16) {
+          double av[4], bv[4];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { dv[u] = dj[r + u]; av[u] = ai[r + u]; }
+          for (int u = 0; u < 4; ++u) { av[u] = va ? pa[r0 + 4 * u] : 0.0; bv[u] = vb ? pb[r0 + 4 * u] : 0.0; }
 #pragma unroll
-          for (int u = 0; u < 8; u += 4) {
-            s0 = fma(dv[u], av[u], s0);
-            s1 = fma(dv[u + 1], av[u + 1], s1);
-            s2 = fma(dv[u + 2], av[u + 2], s2);
-            s3 = fma(dv[u + 3], av[u + 3], s3);
-          }
+          for (int u = 0; u < 4; ++u) acc = TGP_MFMA(av[u], bv[u], acc);
         }
-        gp[woff[l] + j * nin + i] = (s0 + s1) + (s2 + s3);
-      } else {
-        for (int r = 0; r < MLP_T; r += 2) { s0 += dj[r]; s1 += dj[r + 1]; }
-        gp[woff[l] + H * nin + j] = s0 + s1;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int j = 16 * jt + q + 4 * rr, i = 16 * it + n;
+          if (j < H && i < nin) gp[mlp_woff(D, H, l) + j * nin + i] = acc[rr];
+        }
+      }
+      // db[j] = sum_rows delta[j][row]
+      for (int j = tid; j < H; j += MLP_T) {
+        const double* dj = dl + j * MLP_ST;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 2
+        for (int r = 0; r < MLP_T; r += 4) { s0 += dj[r]; s1 += dj[r + 1]; s2 += dj[r + 2]; s3 += dj[r + 3]; }
+        gp[mlp_woff(D, H, l) + H * nin + j] = (s0 + s1) + (s2 + s3);
       }
     }
     if (l == 0) break;
     __syncthreads();
-    // delta_{l-1}[i] = (sum_j W[j][i] delta_l[j]) * d(act, dropout)(a_{l-1}[i]) -- own column only, in place
-    for (int i0 = 0; i0 < H; i0 += 4) {
-      double s[4] = {0, 0, 0, 0};
-      const bool full = i0 + 4 <= H;
-      int j = 0;
-      if (full) {
-        for (; j + 4 <= H; j += 4) {
-          double dv[4], wv[4][4];
+    // delta_{l-1}[i][r] = (sum_j W_l[j][i] delta_l[j][r]) * d(act, dropout)(a_{l-1}[i][r]), in place over a_{l-1}.
+    //   A operand = W^T tile (lane: i = l&15, k = j = l>>4), B operand = delta strip rows, this wave's 64 rows.
+    {
+      const double* Wp = sm + Lo.wp(l);
+      for (int it = 0; it * 16 < KPH; ++it) {
+        d4 acc[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) dv[t] = dl[(j + t) * MLP_ST + tid];
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = {0, 0, 0, 0};
+        const bool vi = 16 * it + n < KPH;
+        const double* wcol = Wp + q * KPH + (vi ? 16 * it + n : 0);
+        const double* brow = dl + q * MLP_ST + 64 * wave + n;
+        double a = vi ? wcol[0] : 0.0, b[4];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+        for (int rt = 0; rt < 4; ++rt) b[rt] = brow[16 * rt];
+        for (int k0 = 0; k0 < KPH; k0 += 4) {
+          const int kn = k0 + 4 < KPH ? k0 + 4 : k0;
+          const double an = vi ? wcol[kn * KPH] : 0.0;
+          double bn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wv[t][u] = w[(size_t)(j + t) * H + i0 + u];
+          for (int rt = 0; rt < 4; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int rt = 0; rt < 4; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
+          a = an;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] = fma(wv[t][u], dv[t], s[u]);
+          for (int rt = 0; rt < 4; ++rt) b[rt] = bn[rt];
         }
-      }
-      for (; j < H; ++j) {
-        const double dj = dl[j * MLP_ST + tid];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i0 + u < H) s[u] = fma(w[(size_t)j * H + i0 + u], dj, s[u]);
-      }
+        for (int rt = 0; rt < 4; ++rt) {
+          const int rl = 64 * wave + 16 * rt + n;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u;
-        if (i < H) {
-          const double a = ain[i * MLP_ST + tid];
-          ain[i * MLP_ST + tid] = s[u] * dfac(a, l - 1, i);
+          for (int rr = 0; rr < 4; ++rr) {
+            const int i = 16 * it + q + 4 * rr;
+            if (i < KPH) {
+              const double a = ain[i * MLP_ST + rl];
+              ain[i * MLP_ST + rl] = acc[rt][rr] * dfac(a, kept_flag(l - 1, rl, i));
+            }
+          }
         }
       }
     }
@@ -319,11 +360,7 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(const double* __restrict__ p
   g_W[e] = s0 + s1;
 }
 
-static size_t mlp_lds_bytes(int D, int H, int L, bool bwd) {
-  const size_t pw = (size_t)((mlp_weights_per_net(D, H, L) + 1) & ~1);
-  const size_t acts = bwd ? (size_t)D + (size_t)L * H : (size_t)D + 2 * (size_t)H;
-  return (pw + acts * MLP_ST + (bwd ? MLP_T : 0)) * sizeof(double);
-}
+static size_t mlp_lds_bytes(int D, int H, int L, bool bwd) { return (size_t)mlp_lds(D, H, L, bwd).total * sizeof(double); }
 
 size_t mlp_workspace_doubles(int N, int D, int H, int L, int nnets) {
   const size_t nblk = (size_t)(N + MLP_T - 1) / MLP_T;

@@ -249,8 +249,7 @@ def mlp_spec(nets, seed=0):
             if ls[-1].linear.in_features != H:
                 return None
         spec = ops.MlpSpec(D, H, Lh, len(nets), act=act, drop_p=p, seed=seed)
-        # weights + activation strips must fit one CU's LDS (tgp_mlp.hip)
-        if (spec.weights_per_net + (D + Lh * H) * 129 + 128) * 8 > 158 * 1024:
+        if spec.lds_bytes() > 158 * 1024:      # padded weights + activation strips must fit one CU's LDS (tgp_mlp.hip)
             return None
         return spec
     except (KeyError, AttributeError, IndexError, TypeError):

@@ -442,6 +442,12 @@ class MlpSpec:
     def weights_per_net(self):
         return self.D * self.H + self.H + (self.L - 1) * (self.H * self.H + self.H) + self.H + 1
 
+    def lds_bytes(self):
+        """LDS image of the backward kernel (tgp_mlp.hip mlp_lds): padded weights + activation strips."""
+        kp0, kph = (self.D + 3) // 4 * 4, (self.H + 3) // 4 * 4
+        w = 64 * kp0 + 64 + (self.L - 1) * (64 * kph + 64) + 66
+        return (w + (kp0 + self.L * kph) * 129 + 2 + 128) * 8
+
     def struct(self, N, training):
         d = L.TgpMlp()
         d.N, d.D, d.H, d.L, d.nnets, d.act = int(N), self.D, self.H, self.L, self.nnets, self.act
@@ -501,8 +507,9 @@ def mlp_keep_mask(seed, step, net, layer, rows, units, p):
     import numpy as np
     M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
     r = np.arange(rows, dtype=np.uint64).reshape(-1, 1)
-    ug = (np.arange(units, dtype=np.uint64) >> np.uint64(2)).reshape(1, -1)
-    lane = (np.arange(units, dtype=np.uint64) & np.uint64(3)).reshape(1, -1)
+    j = np.arange(units, dtype=np.uint64)
+    ug = ((j >> np.uint64(4)) * np.uint64(4) + (j & np.uint64(3))).reshape(1, -1)    # group: the 4 accumulator regs of a lane
+    lane = ((j >> np.uint64(2)) & np.uint64(3)).reshape(1, -1)
     with np.errstate(over="ignore"):
         z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * np.uint64(step)) & M64
         z = z ^ (np.uint64(net) << np.uint64(56)) ^ (np.uint64(layer) << np.uint64(48)) ^ (ug << np.uint64(32)) ^ r
