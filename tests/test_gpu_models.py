@@ -105,16 +105,25 @@ def test_evaluation_path_matches_reference(name, flow):
     assert rel_err(model.KLD().cpu(), g["KLD"]) < 1e-12
 
 
+@pytest.mark.parametrize("resident", [True, False])
 @pytest.mark.parametrize("name,flow", [("adam5_svgp", None), ("adam5_sal2", "sal2")])
-def test_trainer_first_steps_match_reference(name, flow):
-    """Trainer sequence ELBO -> backward -> torch Adam(lr=0.01) on the drop-in classes vs the reference's history."""
+def test_trainer_first_steps_match_reference(name, flow, resident):
+    """Trainer sequence ELBO -> backward -> Adam(lr=0.01) on the drop-in classes vs the reference's history: through the
+    resident graph-captured engine the trainer switches to for full-batch Adam runs, and through the eager loop
+    (autograd Function + torch.optim.Adam) it keeps for everything else."""
+    from tgp.pytorch_amd import config as cg
     from tgp.pytorch_amd.data import DeviceLoader
     from tgp.pytorch_amd.trainers import Trainer_SP_regression
     g = load_golden(name)
     model = build_model(g, flow)
     loader = DeviceLoader(g["X"], g["Y"], 10000, shuffle=False, device=DEV)
     tr = Trainer_SP_regression(model, [loader, None, None], 1e20, False, False, torch.ones(1, device=DEV), -1, 100, True)
-    tr.train(epochs=g["history"].shape[0], lr_ALL=0.01, opt="adam", keep_parameter_groups=True)
+    cg.use_step_engine = resident
+    try:
+        tr.train(epochs=g["history"].shape[0], lr_ALL=0.01, opt="adam", keep_parameter_groups=True)
+    finally:
+        cg.use_step_engine = True
+    assert (tr._engine is not None) == resident
     hist = torch.tensor([[-l, e, k] for l, e, k in zip(tr.loss_arr, tr.ELL_arr, tr.KLD_arr)], dtype=torch.float64)
     assert rel_err(hist, g["history"]) < 1e-8
     assert rel_err(model.Z.detach().cpu()[0], g["final_Z"]) < 1e-8

@@ -50,3 +50,6 @@ pi = torch.tensor(math.pi, dtype=torch.float32)
 # the reference's jitter ladder on failure (dsp/utils.py:256-269; one host sync per step, like the reference's
 # isnan().any()); 'lazy' = never sync in ELBO(); call model.check_status() when convenient.
 status_check = "always"
+
+# Trainer_SP_regression.train: use the resident, graph-captured step engine when the run allows it (trainers.py)
+use_step_engine = True

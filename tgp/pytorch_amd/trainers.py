@@ -41,6 +41,7 @@ class Trainer_SP_regression:
         assert len(Y_std.shape) == 1 and Y_std.shape[0] == self.num_outputs
         self.Y_std = Y_std
         self.optimizer = None
+        self._engine = None
         self.loss_arr, self.ELL_arr, self.KLD_arr = [], [], []
         self.total_trainer_epochs = 0
 
@@ -72,6 +73,86 @@ class Trainer_SP_regression:
             groups.append({"params": rest, "lr": lr_all, "weight_decay": 0.0})
         return groups
 
+    # ---- resident fast path ---------------------------------------------------------------------------
+    def _engine_for(self, groups, lr_ALL, opt):
+        """The resident step engine (engine.ElboEngine: the same ELBO -> backward -> Adam sequence as the loop below, every
+        launch captured in a HIP graph, no host synchronisation per step) when the run is what main.py sets up: Adam with
+        one learning rate, weight decay on the 'NNets' group only, one full batch per epoch from a data.DeviceLoader.
+        The model's nn.Parameters are re-pointed at the engine's flat buffer, so the modules stay the parameter holders
+        and everything downstream (metrics, prediction, state_dict) sees the trained values.  Returns None otherwise."""
+        from .data import DeviceLoader
+        from .engine import ElboEngine
+        from .flow import compile_flow, mlp_spec
+        from .likelihoods import GaussianLinearMean
+        if not getattr(cg, "use_step_engine", True) or opt != "adam":
+            return None
+        ld = self.train_loader
+        if not isinstance(ld, DeviceLoader) or len(ld) != 1 or not ld.X.is_cuda or ld.Y.shape[1] != 1:
+            return None
+        model = self.model
+        if not hasattr(model, "_gp_params") or any(g["lr"] != lr_ALL for g in groups):
+            return None
+        nets, theta_list, blocks = [], [], None
+        if not isinstance(model.likelihood, GaussianLinearMean):
+            spec, theta_list, nets = compile_flow(model.G_matrix[0])
+            blocks = spec.blocks
+        nn_params = [p for net in nets for p in net.parameters()]
+        nn_ids = {id(p) for p in nn_params}
+        wd = 0.0
+        for g in groups:
+            if g["weight_decay"] != 0.0:
+                if {id(p) for p in g["params"]} != nn_ids or wd != 0.0:
+                    return None
+                wd = g["weight_decay"]
+        mspec = mlp_spec(nets, seed=cg.config_seed) if nets else None
+        if nets and mspec is None:
+            return None
+        Z, rl, ro, m, Lam, lvn = model._gp_params()
+        params = {"Z": Z.detach(), "raw_lengthscale": rl.detach(), "raw_outputscale": ro.detach(), "m": m.detach(),
+                  "Lam": Lam.detach(), "log_var_noise": lvn.detach()}
+        if theta_list:
+            params["theta"] = torch.stack([p.detach().reshape(()) for p in theta_list])
+        W = torch.cat([p.detach().reshape(-1) for p in nn_params]) if nn_params else None
+        eng = ElboEngine(ld.X, ld.Y, params, float(model.N), flow_blocks=blocks, S=getattr(model, "quad_points", None),
+                         lr=lr_ALL, device=ld.X.device, kernel=model.covariance_function.hip_kernel, mlp=mspec,
+                         mlp_weights=W, nn_weight_decay=wd, mlp_training=True)
+        # the modules' parameters become views of the engine's flat buffer
+        fp, k = eng.fp, model.covariance_function
+        with torch.no_grad():
+            model.Z.data = fp.view("Z").view_as(model.Z)
+            k.base_kernel.raw_lengthscale.data = fp.view("raw_ls").view_as(k.base_kernel.raw_lengthscale)
+            k.raw_outputscale.data = fp.view("raw_os").view_as(k.raw_outputscale)
+            model.q_U.variational_mean.data = fp.view("m").view_as(model.q_U.variational_mean)
+            model.q_U.chol_variational_covar.data = fp.view("Lam").view_as(model.q_U.chol_variational_covar)
+            model.likelihood.log_var_noise.data = fp.view("lvn").view_as(model.likelihood.log_var_noise)
+            for i, p in enumerate(theta_list):
+                p.data = fp.view("theta")[i:i + 1].view_as(p)
+            o = 0
+            for p in nn_params:
+                p.data = fp.view("nn")[o:o + p.numel()].view_as(p)
+                o += p.numel()
+        eng.capture()
+        return eng
+
+    def _train_resident(self, eng, n_epochs, epochs_total):
+        hist = torch.empty(max(n_epochs, 1), 3, dtype=torch.float64, device=eng.device)
+        t0 = time.time()
+        last = 0
+        for ep in range(n_epochs):
+            eng.replay()
+            hist[ep].copy_(eng.fp.out[:3])          # device-to-device, no synchronisation
+            self.total_trainer_epochs += 1
+            if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
+                h = hist[last:ep + 1].mean(0).cpu()     # the only host sync: once per `validate_each` epochs
+                print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
+                    ep + 1, epochs_total, float(h[0]), float(h[1]), float(h[2]), time.time() - t0))
+                t0, last = time.time(), ep + 1
+        eng.check_status()
+        h = hist[:n_epochs].cpu()
+        self.loss_arr += (-h[:, 0]).tolist()
+        self.ELL_arr += h[:, 1].tolist()
+        self.KLD_arr += h[:, 2].tolist()
+
     def ELBO_call(self, x, y):
         loss, elogl, kld = self.model.ELBO(x, y)
         loss = -loss
@@ -86,6 +167,11 @@ class Trainer_SP_regression:
             raise ValueError("percentages must sum 1, got {}".format(sum(percentages)))
         for per, specs in zip(percentages, specifications):
             groups = self._param_groups(specs, lr_ALL)
+            if getattr(self, "_engine", None) is None or not keep_parameter_groups:
+                self._engine = self._engine_for(groups, lr_ALL, opt)
+            if self._engine is not None:
+                self._train_resident(self._engine, int(epochs * per), epochs)
+                continue
             if self.optimizer is None or not keep_parameter_groups:
                 self.optimizer = return_optimizer(opt, groups, lr_ALL)
             for ep in range(int(epochs * per)):
@@ -115,6 +201,7 @@ class Trainer_SP_regression:
                         ep + 1, epochs, acc[0] / nb, acc[1] / nb, acc[2] / nb, time.time() - t0))
         if not keep_parameter_groups:
             self.optimizer = None
+            self._engine = None
 
     # ---- metrics (trainers_regression.py:108-224, 317-338) ----------------------------------------------
     def performance_metrics(self, X, Y):
