@@ -44,6 +44,7 @@ struct BigPlan {
   size_t Kc, A, B, Ab;
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
+  size_t cstride;  // second set of chunk buffers {Xaug, K', A', B', Abar'} (0 = none): forward of chunk c+1 overlaps backward of chunk c
   size_t Sk;  // split-K slabs of the M x M products
   size_t Kmmg, TpartK, TK, UK;  // MATERN32 only: derivative-weight K_MM, statistics of (Kbar o K) next to those of (Kbar o K_g)
   size_t total;
@@ -58,6 +59,41 @@ static int big_chunk_max() {
     v = (x + 127) / 128 * 128;
   }
   return v;
+}
+
+static bool big_overlap_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TGP_BIG_OVERLAP");
+    v = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return v != 0;
+}
+
+// helper stream + events for the chunk pipeline (created once per process: one process drives one GPU)
+struct BigAux {
+  hipStream_t fwd;
+  hipEvent_t e0, eF[2], eB[2];
+  bool ok;
+};
+static BigAux* big_aux() {
+  static BigAux a;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    a.ok = hipStreamCreateWithFlags(&a.fwd, hipStreamNonBlocking) == hipSuccess;
+    hipEvent_t* ev[5] = {&a.e0, &a.eF[0], &a.eF[1], &a.eB[0], &a.eB[1]};
+    for (int i = 0; i < 5 && a.ok; ++i) a.ok = hipEventCreateWithFlags(ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!a.ok) (void)hipGetLastError();
+  }
+  return a.ok ? &a : nullptr;
+}
+
+static BigPlan plan_parity(const BigPlan& p, int par) {
+  BigPlan q = p;
+  const size_t d = (size_t)par * p.cstride;
+  q.Xaug += d; q.Kc += d; q.A += d; q.B += d; q.Ab += d;
+  return q;
 }
 
 static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int kernel) {
@@ -100,6 +136,11 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.T = o; o += (size_t)p.MP * BIG_XW;
   p.Xaug = o; o += (size_t)p.NC * BIG_XW;
   p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
+  p.cstride = 0;
+  if (p.nchunks >= 2 && big_overlap_enabled()) {
+    p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
+    o += p.cstride;
+  }
   p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
   p.Gpart = o; o += (size_t)p.ksg * mm;
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
@@ -796,10 +837,24 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
   if (phases & TGP_PHASE_PREPARE)
     if (int rc = big_prepare(p, md, ws, status, true, st)) return rc;
   if (phases & TGP_PHASE_ROWS) {
+    // Chunk pipeline.  With a second set of chunk buffers the forward half of chunk c+1 (K' tiles, A', B', moments,
+    // likelihood -- a third of it bandwidth/latency-bound kernels that leave the matrix cores idle) runs on a helper
+    // stream while the caller's stream runs the backward half of chunk c; events order buffer reuse.  Under hipGraph
+    // capture the helper stream forks from and rejoins the capturing stream.
+    BigAux* aux = p.cstride ? big_aux() : nullptr;
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); } while (0)
+    if (aux) {
+      HIPCK(hipEventRecord(aux->e0, st));
+      HIPCK(hipStreamWaitEvent(aux->fwd, aux->e0, 0));
+    }
     for (int ci = 0; ci < p.nchunks; ++ci) {
       const size_t c0 = (size_t)ci * NC;
       const int nrows = (int)((size_t)p.N - c0 < (size_t)NC ? (size_t)p.N - c0 : (size_t)NC);
-      if (int rc = big_chunk_forward(p, X + c0 * p.D, nrows, ws, ws + p.mu + c0, ws + p.v + c0, true, st)) return rc;
+      const int par = aux ? (ci & 1) : 0;
+      const BigPlan pc = plan_parity(p, par);
+      hipStream_t sf = aux ? aux->fwd : st;
+      if (aux && ci >= 2) HIPCK(hipStreamWaitEvent(sf, aux->eB[par], 0));  // chunk ci-2 is done with these buffers
+      if (int rc = big_chunk_forward(pc, X + c0 * p.D, nrows, ws, ws + p.mu + c0, ws + p.v + c0, true, sf)) return rc;
       // likelihood of the chunk: partial (scale*ELL, scale*eta_bar, theta_bar) into this chunk's slot
       double* slot = ws + p.likslot + (size_t)ci * p.LS;
       if (md.lik == TGP_LIK_FLOW) {
@@ -807,42 +862,49 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
         mc.N = nrows;
         if (int rc = launch_ell_flow(mc, fp, Y + c0, ws + p.mu + c0, ws + p.v + c0, rowp ? rowp + c0 * md.RP : nullptr, slot,
                                      ws + p.mub + c0, ws + p.vb + c0, slot + 2, g.rowp ? g.rowp + c0 * md.RP : nullptr,
-                                     ws + p.likws, st))
+                                     ws + p.likws, sf))
           return rc;
       } else {
         if (int rc = launch_ell_gauss(Y + c0, ws + p.mu + c0, ws + p.v + c0, nrows, md.log_var_noise, md.scale, slot,
-                                      ws + p.mub + c0, ws + p.vb + c0, ws + p.likws, st))
+                                      ws + p.mub + c0, ws + p.vb + c0, ws + p.likws, sf))
           return rc;
       }
+      if (aux) {
+        HIPCK(hipEventRecord(aux->eF[par], sf));
+        HIPCK(hipStreamWaitEvent(st, aux->eF[par], 0));
+      }
+      // ---- backward half, caller's stream ----
       // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T
-      GemmArgs a3 = gemm_args(ws + p.B, MP, ws + p.Lq, MP, ws + p.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
-      a3.add = ws + p.A; a3.ldadd = MP; a3.gamma = -2.0;
+      GemmArgs a3 = gemm_args(ws + pc.B, MP, ws + p.Lq, MP, ws + pc.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
+      a3.add = ws + pc.A; a3.ldadd = MP; a3.gamma = -2.0;
       a3.row_scale = ws + p.vb + c0; a3.rowv = ws + p.mub + c0; a3.colv = ws + p.mpad;
       a3.xcd = 1;
       GEMM(false, true, a3);
       // Kbar' = Abar' J  (into the B' buffer)
-      GemmArgs a4 = gemm_args(ws + p.Ab, MP, ws + p.J, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+      GemmArgs a4 = gemm_args(ws + pc.Ab, MP, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
       a4.xcd = 1;
       GEMM(false, false, a4);
       // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
       // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
-      GemmArgs at = gemm_args(ws + p.B, MP, ws + p.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
-      at.a_mul = ws + p.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
+      GemmArgs at = gemm_args(ws + pc.B, MP, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+      at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
       if (p.kernel != TGP_KERNEL_SCALE_RBF) {
         GemmArgs atk = at;
         atk.C = ws + p.TpartK;
         GEMM(true, false, atk);
-        hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, X + c0 * p.D, nrows, ws, 1);
+        hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
         LAUNCH_CHECK();
       }
       GEMM(true, false, at);
       // G slabs (+)= A'^T diag(vbar) A', lower block triangle
-      GemmArgs ag = gemm_args(ws + p.A, MP, ws + p.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
+      GemmArgs ag = gemm_args(ws + pc.A, MP, ws + pc.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
       ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;
       GEMM(true, false, ag);
-      hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, p, ws, c0, ci ? 1 : 0);
+      hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
       LAUNCH_CHECK();
+      if (aux) HIPCK(hipEventRecord(aux->eB[par], st));
     }
+#undef HIPCK
     hipLaunchKernelGGL(k_big_reduce, dim3((unsigned)((mm + (size_t)MP * BIG_XW + MP + 255) / 256)), dim3(256), 0, st, p, ws);
     LAUNCH_CHECK();
     if (mu != nullptr) {
