@@ -146,6 +146,44 @@ __device__ __forceinline__ double cov_gweight(int kernel, double s2, double d2) 
   return s2 * exp_fast(-0.5 * d2);
 }
 
+// 1/sqrt(d): v_rsq_f64 estimate + two Newton steps (same scheme as rsqrt_nr below, declared here for the flows)
+__device__ __forceinline__ double rsqrt_nr_fwd(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
+// log(x) for finite normal x > 0 with a short instruction stream (the library log is ~70 f64 instructions of
+// double-double arithmetic; the SAL blocks call it once per quadrature node).  x = m 2^e, m in [sqrt(1/2), sqrt 2):
+// log m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716, odd series to s^19 (truncation 4e-18), Estrin in z = s^2.
+__device__ __forceinline__ double log_fast(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double den = m + 1.0;
+  double y = __builtin_amdgcn_rcp(den);
+  y = fma(fma(-den, y, 1.0), y, y);
+  y = fma(fma(-den, y, 1.0), y, y);
+  const double num = m - 1.0;
+  double s_ = num * y;
+  s_ = fma(fma(-den, s_, num), y, s_);  // one correction step of the quotient
+  const double z = s_ * s_, z2 = z * z, z4 = z2 * z2;
+  const double p01 = fma(z, 2.0 / 5.0, 2.0 / 3.0);
+  const double p23 = fma(z, 2.0 / 9.0, 2.0 / 7.0);
+  const double p45 = fma(z, 2.0 / 13.0, 2.0 / 11.0);
+  const double p67 = fma(z, 2.0 / 17.0, 2.0 / 15.0);
+  const double p8 = 2.0 / 19.0;
+  const double q0 = fma(p23, z2, p01), q1 = fma(p67, z2, p45);
+  const double P = fma(fma(p8, z4, q1), z4, q0);
+  const double lm = fma(s_ * z, P, s_ + s_);
+  const double ed = (double)e;
+  return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+}
+
 // 1/x from v_rcp_f64 + two Newton steps (no v_div_scale / v_div_fixup: operands here are finite, normal, non-zero)
 __device__ __forceinline__ double rcp_fast(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -364,11 +402,16 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       const bool addf = flags & TGP_FLAG_ADD_F0;
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
-        const double sf = sqrt(f[u] * f[u] + 1.0);
-        const double uu = log(f[u] + sf);  // flow.py:904-905
+        // sqrt(f^2+1) and its reciprocal from one v_rsq_f64 + Newton (1/sf is needed anyway); asinh keeps the
+        // reference's log(f + sqrt(f^2+1)) form (flow.py:904-905) on the short-chain log
+        const double q1 = f[u] * f[u] + 1.0;
+        const double isf = rsqrt_nr_fwd(q1);
+        double sf = q1 * isf;
+        sf = fma(fma(-sf, sf, q1), 0.5 * isf, sf);
+        const double uu = log_fast(f[u] + sf);
         const double e = exp_fast(bb * uu - a), ei = rcp_fast(e);
         const double ch = 0.5 * (e + ei);
-        double g = 0.5 * (e - ei), gp = bb * ch * rcp_fast(sf);
+        double g = 0.5 * (e - ei), gp = bb * ch * isf;
         if (addf) { g += f[u]; gp += 1.0; }
         stack[((sl + 0) * NB + u) * sstride] = uu;
         stack[((sl + 1) * NB + u) * sstride] = ch;
