@@ -163,6 +163,8 @@ int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const do
  * A (M,M) symmetric, L (M,M) lower (strict upper zeroed); Linv (M,M) = L^-1 or NULL. */
 int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_t* status, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* Workspace of tgp_cholesky_f64: 0 for M <= 128 (factorised in one CU's LDS), the blocked multi-kernel path above. */
+size_t tgp_cholesky_workspace_bytes(int32_t M);
 
 /* Dense float64 contraction on the matrix cores, the building block of the M > 128 path (the reference's
  * torch.bmm / triangular_solve calls at models/sparse_MF_SP.py:354,376-382 on (M,M)x(M,N) operands):

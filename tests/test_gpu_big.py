@@ -242,3 +242,24 @@ def test_big_non_psd_reports_pivot():
                                            p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], 400.0)
     torch.cuda.synchronize()
     assert int(status[0]) == 151
+
+
+@pytest.mark.parametrize("M", [130, 300, 1000])
+def test_big_standalone_cholesky_matches_torch(M):
+    """tgp_cholesky_f64 above 128 (blocked multi-kernel factorisation + block-row inverse) against torch.linalg."""
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M)
+    B = torch.randn(M, M, generator=g, dtype=torch.float64)
+    A = B @ B.T / M + torch.eye(M, dtype=torch.float64)
+    Lo, Li, status = ops.cholesky(A.to(dev), want_inverse=True)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    Lref = torch.linalg.cholesky(A)
+    assert rel_err(Lo.cpu(), Lref) < 1e-12
+    assert rel_err(Li.cpu(), torch.linalg.inv(Lref)) < 1e-10
+    assert float(torch.triu(Lo, 1).abs().max()) == 0.0
+    A[M // 2, M // 2] = -1.0                      # not positive definite: LAPACK-style info = first failing pivot
+    _, _, status = ops.cholesky(A.to(dev))
+    torch.cuda.synchronize()
+    assert int(status[0]) == M // 2 + 1

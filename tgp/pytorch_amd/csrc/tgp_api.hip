@@ -182,14 +182,23 @@ int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const do
   return launch_knm(X, Z, raw_ls, raw_os, N, M, D, K, static_cast<hipStream_t>(stream));
 }
 
+size_t tgp_cholesky_workspace_bytes(int32_t M) {
+  if (M <= TGP_FUSED_MAX_M) return 0;
+  return big_cholesky_workspace_doubles(M) * sizeof(double);
+}
+
 int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_t* status, void* workspace,
                      size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (!A) return -1;
   if (M < 1) return -2;
-  if (M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
+  if (M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
   if (!L) return -3;
   if (!status) return -5;
+  if (M > TGP_FUSED_MAX_M) {  // blocked multi-kernel factorisation of the general-M path; needs tgp_cholesky_workspace_bytes(M)
+    if (!workspace) return -6;
+    return launch_big_cholesky(A, M, L, Linv, status, static_cast<double*>(workspace), workspace_bytes / sizeof(double),
+                               static_cast<hipStream_t>(stream));
+  }
   return launch_cholesky(A, M, L, Linv, status, static_cast<hipStream_t>(stream));
 }
 

@@ -735,25 +735,13 @@ static int gemm_mm(bool ta, bool tb, GemmArgs g, const BigPlan& p, double* ws, h
     if (int rc_ = gemm_mm((ta), (tb), (args), p, ws, st)) return rc_;  \
   } while (0)
 
-static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
+// Blocked right-looking Cholesky of the padded matrix in p.Lm (lower block triangle filled, J zeroed) and, if wanted, the
+// block-row inverse J = L^-1 (torch.cholesky, dsp/utils.py:239).  Diagonal blocks of J are always produced (the panel
+// solve multiplies by them).
+static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool want_inverse, hipStream_t st) {
   const int MP = p.MP, nb = MP / 128;
-  const size_t mm = (size_t)MP * MP;
-  hipLaunchKernelGGL(k_big_hdr, dim3(1), dim3(256), 0, st, p, md, ws, status);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_big_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
-  LAUNCH_CHECK();
-  static bool potrf_attr = false;
-  if (!potrf_attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_potrf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)POTRF_LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
-    potrf_attr = true;
-  }
   double* Lm = ws + p.Lm;
   double* J = ws + p.J;
-  // blocked right-looking Cholesky (torch.cholesky, dsp/utils.py:239)
   for (int kb = 0; kb < nb; ++kb) {
     hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
     LAUNCH_CHECK();
@@ -768,6 +756,7 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
       GEMM(false, true, gemm_args(panel, MP, panel, MP, trail, MP, rem, rem, 128, -1.0, 1.0, TRI_C_LOWER));
     }
   }
+  if (!want_inverse) return 0;
   // block-row inverse: J[i, 0:i] = -J_ii (L[i, 0:i] J[0:i, 0:i])
   for (int i = 1; i < nb; ++i) {
     const double* Li = Lm + (size_t)i * 128 * MP;
@@ -776,6 +765,19 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
     const double* Jii = J + (size_t)i * 128 * MP + (size_t)i * 128;
     GEMM(false, false, gemm_args(Jii, MP, tmp, MP, J + (size_t)i * 128 * MP, MP, 128, 128 * i, 128, -1.0, 0.0));
   }
+  return 0;
+}
+
+static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
+  const int MP = p.MP, nb = MP / 128;
+  const size_t mm = (size_t)MP * MP;
+  hipLaunchKernelGGL(k_big_hdr, dim3(1), dim3(256), 0, st, p, md, ws, status);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_big_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
+  LAUNCH_CHECK();
+  if (int rc = big_factorise(p, ws, status, true, st)) return rc;
   if (!train) return 0;
   hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, st, p, md, ws);
   LAUNCH_CHECK();
@@ -784,7 +786,7 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   GEMM_MM(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER));
   hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, st, ws + p.S_, MP);
   LAUNCH_CHECK();
-  GEMM_MM(true, false, gemm_args(J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
+  GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
   hipLaunchKernelGGL(k_big_wvec, dim3((MP + 255) / 256), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   return 0;
@@ -950,6 +952,52 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
     hipLaunchKernelGGL(k_big_final, dim3(1), dim3(256), 0, st, p, md, g, out, ws);
     LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// ---- stand-alone Cholesky for M > 128 (tgp_cholesky_f64): pad, factorise, unpad --------------------------------
+__global__ __launch_bounds__(256) void k_big_chol_in(BigPlan p, const double* __restrict__ A, double* __restrict__ ws,
+                                                     int32_t* __restrict__ status) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int MP = p.MP, M = p.M;
+  const int row = (int)(e / MP), col = (int)(e % MP);
+  if (e == 0) { status[0] = 0; status[1] = 0; }
+  double k = row == col ? 1.0 : 0.0;
+  if (row < M && col < M) {
+    k = A[(size_t)row * M + col];
+    if (k != k) status[1] = 1;
+  }
+  ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
+  ws[p.J + e] = 0.0;
+}
+__global__ __launch_bounds__(256) void k_big_chol_out(BigPlan p, const double* __restrict__ ws, double* __restrict__ Lo,
+                                                      double* __restrict__ Jo) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = p.M;
+  if (e >= (size_t)M * M) return;
+  const int row = (int)(e / M), col = (int)(e % M);
+  const size_t src = (size_t)row * p.MP + col;
+  Lo[e] = col <= row ? ws[p.Lm + src] : 0.0;
+  if (Jo) Jo[e] = col <= row ? ws[p.J + src] : 0.0;
+}
+
+size_t big_cholesky_workspace_doubles(int M) {
+  BigPlan p;
+  if (make_big_plan(p, 128, 1, M, 1, 0, 0, 0, TGP_LIK_GAUSS, TGP_KERNEL_SCALE_MATERN32) != 0) return 0;  // any-M plan
+  return p.total;
+}
+
+int launch_big_cholesky(const double* A, int M, double* Lo, double* Jo, int32_t* status, double* ws, size_t ws_doubles,
+                        hipStream_t st) {
+  BigPlan p;
+  if (int rc = make_big_plan(p, 128, 1, M, 1, 0, 0, 0, TGP_LIK_GAUSS, TGP_KERNEL_SCALE_MATERN32)) return rc;
+  if (ws_doubles < p.total) return TGP_E_WORKSPACE;
+  const size_t mm = (size_t)p.MP * p.MP;
+  hipLaunchKernelGGL(k_big_chol_in, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, A, ws, status);
+  LAUNCH_CHECK();
+  if (int rc = big_factorise(p, ws, status, Jo != nullptr, st)) return rc;
+  hipLaunchKernelGGL(k_big_chol_out, dim3((unsigned)(((size_t)M * M + 255) / 256)), dim3(256), 0, st, p, ws, Lo, Jo);
+  LAUNCH_CHECK();
   return 0;
 }
 

@@ -41,6 +41,9 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                     uint32_t phases, hipStream_t st);
 int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
                        size_t ws_doubles, hipStream_t st);
+size_t big_cholesky_workspace_doubles(int M);
+int launch_big_cholesky(const double* A, int M, double* Lo, double* Jo, int32_t* status, double* ws, size_t ws_doubles,
+                        hipStream_t st);
 int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                       int ldb, double beta, double* C, int ldc, hipStream_t st);
 

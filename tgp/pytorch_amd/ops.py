@@ -292,8 +292,10 @@ def cholesky(A, want_inverse=False):
     Lo = torch.empty_like(A)
     Li = torch.empty_like(A) if want_inverse else None
     status = torch.zeros(4, dtype=torch.int32, device=A.device)
-    L.check(lib.tgp_cholesky_f64(L.ptr(A), M, L.ptr(Lo), L.ptr(Li), L.ptr(status), None, 0, L.stream_ptr()),
-            "tgp_cholesky_f64")
+    nws = lib.tgp_cholesky_workspace_bytes(M)
+    ws = torch.empty(nws // 8 + 16, dtype=torch.float64, device=A.device) if nws else None
+    L.check(lib.tgp_cholesky_f64(L.ptr(A), M, L.ptr(Lo), L.ptr(Li), L.ptr(status), L.ptr(ws),
+                                 ws.numel() * 8 if ws is not None else 0, L.stream_ptr()), "tgp_cholesky_f64")
     return Lo, Li, status
 
 
