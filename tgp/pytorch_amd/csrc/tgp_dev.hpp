@@ -540,4 +540,153 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "checkpoint" evaluation (stand-alone likelihood kernel, general-M path): the forward keeps ONE value per block and
+// node -- the block's input -- and the reverse sweep recomputes the block from it.  Twice the transcendentals of the
+// store mode, but 5 instead of 35 stack slots for the 5 x 6 tanh flow: the kernel is no longer limited to one
+// workgroup per CU by the LDS stack, and 3 workgroups x NB = 4 nodes per lane give the f64 pipes the ~12 independent
+// dependency chains per SIMD they need (the store-mode kernel ran at 1/18 of its instruction-issue bound).
+// Shared-parameter partials: summed over the NB nodes in registers, over the wave by shuffles (fixed tree), added by
+// lane 0 into the wave's own accumulator row accw[param] -- no atomics, fixed order.
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ inline void flow_forward_ckpt(const FlowDev& F, double (&f)[NB], const double* __restrict__ rp, double* stack,
+                                         int sstride) {
+  for (int b = 0; b < F.nblk; ++b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) stack[(b * NB + u) * sstride] = f[u];
+    if (kind == TGP_FLOW_AFFINE) {
+      double a = pr ? rp[poff] : F.tp[poff];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
+      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) f[u] = a * f[u] + bb;
+    } else if (kind == TGP_FLOW_SAL) {
+      const double a = pr ? rp[poff] : F.tp[poff];
+      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const double q1 = f[u] * f[u] + 1.0;
+        const double isf = rsqrt_nr_fwd(q1);
+        double sf = q1 * isf;
+        sf = fma(fma(-sf, sf, q1), 0.5 * isf, sf);
+        const double e = exp_fast(bb * log_fast(f[u] + sf) - a), ei = rcp_fast(e);
+        const double g = 0.5 * (e - ei);
+        f[u] = addf ? g + f[u] : g;
+      }
+    } else {
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+      double g[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) g[u] = addf ? f[u] : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double a = F.tp[poff + 4 * k], bt = F.tp[poff + 4 * k + 1], c = F.tp[poff + 4 * k + 2],
+                     idt = rcp_fast(F.tp[poff + 4 * k + 3]);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const double th = 1.0 - 2.0 * rcp_fast(exp_fast(2.0 * (f[u] - c) * idt) + 1.0);
+          g[u] += a + bt * th;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) f[u] = g[u];
+    }
+  }
+}
+
+// c[u] = d(objective)/dG on entry, d(objective)/df0 on exit.  All lanes of the wave must call this together.
+template <int NB>
+__device__ inline void flow_backward_ckpt(const FlowDev& F, double (&c)[NB], const double* __restrict__ rp, const double* stack,
+                                          int sstride, double* accw, bool lane0, double* accr, int rstride) {
+  for (int b = F.nblk - 1; b >= 0; --b) {
+    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const bool pr = flags & TGP_FLAG_PER_ROW;
+    double fin[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) fin[u] = stack[(b * NB + u) * sstride];
+    if (kind == TGP_FLOW_AFFINE) {
+      double a, fa;
+      if (pr) {
+        a = rp[poff]; fa = 1.0;
+        if (flags & TGP_FLAG_RESTRICT) { fa = sigmoid_d(a); a = softplus_d(a); }
+      } else {
+        a = F.tp[poff]; fa = F.tg[poff];
+      }
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { pa += c[u] * fin[u]; pb += c[u]; c[u] *= a; }
+      pa *= fa;
+      if (pr) {
+        accr[(poff + 0) * rstride] += pa;
+        accr[(poff + 1) * rstride] += pb;
+      } else {
+        pa = wave_sum(pa); pb = wave_sum(pb);
+        if (lane0) { accw[poff + 0] += pa; accw[poff + 1] += pb; }
+      }
+    } else if (kind == TGP_FLOW_SAL) {
+      const double a = pr ? rp[poff] : F.tp[poff];
+      double bb = pr ? rp[poff + 1] : F.tp[poff + 1], fb = pr ? 1.0 : F.tg[poff + 1];
+      if (pr && (flags & TGP_FLAG_RESTRICT)) { fb = sigmoid_d(bb); bb = softplus_d(bb); }
+      const bool addf = flags & TGP_FLAG_ADD_F0;
+      double pa = 0.0, pb = 0.0;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const double q1 = fin[u] * fin[u] + 1.0;
+        const double isf = rsqrt_nr_fwd(q1);
+        double sf = q1 * isf;
+        sf = fma(fma(-sf, sf, q1), 0.5 * isf, sf);
+        const double uu = log_fast(fin[u] + sf);
+        const double e = exp_fast(bb * uu - a), ei = rcp_fast(e);
+        const double ch = 0.5 * (e + ei);
+        double gp = bb * ch * isf;
+        if (addf) gp += 1.0;
+        pa -= c[u] * ch;
+        pb += c[u] * uu * ch;
+        c[u] *= gp;
+      }
+      pb *= fb;
+      if (pr) {
+        accr[(poff + 0) * rstride] += pa;
+        accr[(poff + 1) * rstride] += pb;
+      } else {
+        pa = wave_sum(pa); pb = wave_sum(pb);
+        if (lane0) { accw[poff + 0] += pa; accw[poff + 1] += pb; }
+      }
+    } else {
+      double gp[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) gp[u] = (flags & TGP_FLAG_ADD_F0) ? 1.0 : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const int o = poff + 4 * k;
+        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = rcp_fast(F.tp[o + 3]);
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const double t = (fin[u] - cc) * idt;
+          const double th = 1.0 - 2.0 * rcp_fast(exp_fast(2.0 * t) + 1.0);
+          const double se = bt * (1.0 - th * th) * idt;
+          p0 += c[u];
+          p1 += c[u] * th;
+          p2 -= c[u] * se;
+          p3 -= c[u] * se * t;
+          gp[u] += se;
+        }
+        p0 = wave_sum(p0); p1 = wave_sum(p1 * F.tg[o + 1]); p2 = wave_sum(p2); p3 = wave_sum(p3 * F.tg[o + 3]);
+        if (lane0) {
+          accw[o + 0] += p0;
+          accw[o + 1] += p1;
+          accw[o + 2] += p2;
+          accw[o + 3] += p3;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) c[u] *= gp[u];
+    }
+  }
+}
+
 }  // namespace tgp

@@ -92,6 +92,7 @@ __device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, 
 // ---------------------------------------------------------------------------------------------------
 // TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), four lanes per row
 // ---------------------------------------------------------------------------------------------------
+#define ELLF_NB 4 /* quadrature nodes in flight per lane */
 __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, const double* __restrict__ Y,
                                                    const double* __restrict__ mu, const double* __restrict__ v,
                                                    const double* __restrict__ rowp, double* __restrict__ part,
@@ -100,17 +101,18 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = md.P, RP = md.RP;
-  double* stack = sm;                                                 // nslots * 256
-  double* accq = stack + (size_t)(fp.nslots > 0 ? fp.nslots : 1) * 256;  // P * 64 (shared parameters, quad-reduced)
-  double* accr = accq + (size_t)(P > 0 ? P : 1) * 64;                 // RP * 256 (per-row parameters, lane-private)
-  double* red = accr + (size_t)RP * 256;                              // 16
-  double* tp = red + 16;                                              // P+2
-  double* tg = tp + (P + 2) / 2 * 2;                                  // P+2
-  for (int i = tid; i < P * 64 + RP * 256; i += 256) accq[i] = 0.0;
+  const int nb = fp.nblk > 0 ? fp.nblk : 1;
+  double* stack = sm;                                       // nblk * NB * 256: block inputs (checkpoint mode)
+  double* accw = stack + (size_t)nb * ELLF_NB * 256;        // 4 waves x P: per-wave shared-parameter accumulators
+  double* accr = accw + (size_t)4 * (P > 0 ? P : 1);        // RP * 256 (per-row parameters, lane-private)
+  double* red = accr + (size_t)RP * 256;                    // 16
+  double* tp = red + 16;                                    // P+2
+  double* tg = tp + (P + 2) / 2 * 2;                        // P+2
+  for (int i = tid; i < 4 * (P > 0 ? P : 1) + RP * 256; i += 256) accw[i] = 0.0;
   flow_params_lds(md, fp, tp, tg);
-  // 64 rows per block, 4 lanes per row (lanes l, l^16, l^32, l^48 -- the quad flow_backward_store reduces over);
-  // lane group q takes the quadrature nodes s = q, q+4, ...  Every lane runs the same trip count (cross-lane sums
-  // inside the reverse sweep); nodes past S and padding rows carry weight 0.
+  // 64 rows per block, 4 lanes per row (lanes l, l^16, l^32, l^48); lane group q takes the quadrature nodes
+  // s = q + 4 (NB j + u).  Every lane runs the same trip count (wave-wide sums inside the reverse sweep); nodes past S
+  // and padding rows carry weight 0.
   const int qn = lane >> 4;
   const int n = blockIdx.x * 64 + wave * 16 + (lane & 15);
   const bool valid = n < md.N;
@@ -120,19 +122,27 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   double ellp = 0.0, etap = 0.0, cm = 0.0, cv = 0.0;
   const double m_ = mu[nc], sq = sqrt(2.0 * v[nc]), y = Y[nc];
   const double* rp = rowp ? rowp + (size_t)nc * RP : nullptr;
-  for (int s0 = 0; s0 < md.S; s0 += 4) {
-    const int s = s0 + qn, sc = s < md.S ? s : md.S - 1;
-    const double xsn = md.xs[sc], wsn = (valid && s < md.S) ? md.wn[sc] : 0.0;
-    double f[1] = {m_ + sq * xsn}, c[1];
-    flow_forward_store<1>(F, f, rp, stack + tid, 256);
-    const double r = y - f[0];
-    ellp += wsn * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
-    etap += wsn * (-0.5 + 0.5 * einv * r * r);
-    c[0] = md.scale * einv * wsn * r;
-    flow_backward_store<1>(F, c, rp, stack + tid, 256, fp.nslots, accq + wave * 16 + (lane & 15), 64, qn == 0,
-                           accr + tid, 256);
-    cm += c[0];
-    cv += c[0] * xsn;
+  double* aw = accw + (size_t)wave * (P > 0 ? P : 1);
+  for (int s0 = 0; s0 < md.S; s0 += 4 * ELLF_NB) {
+    double f[ELLF_NB], c[ELLF_NB], xsn[ELLF_NB], wsn[ELLF_NB];
+#pragma unroll
+    for (int u = 0; u < ELLF_NB; ++u) {
+      const int s = s0 + 4 * u + qn, sc = s < md.S ? s : md.S - 1;
+      xsn[u] = md.xs[sc];
+      wsn[u] = (valid && s < md.S) ? md.wn[sc] : 0.0;
+      f[u] = m_ + sq * xsn[u];
+    }
+    flow_forward_ckpt<ELLF_NB>(F, f, rp, stack + tid, 256);
+#pragma unroll
+    for (int u = 0; u < ELLF_NB; ++u) {
+      const double r = y - f[u];
+      ellp += wsn[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+      etap += wsn[u] * (-0.5 + 0.5 * einv * r * r);
+      c[u] = md.scale * einv * wsn[u] * r;
+    }
+    flow_backward_ckpt<ELLF_NB>(F, c, rp, stack + tid, 256, aw, lane == 0, accr + tid, 256);
+#pragma unroll
+    for (int u = 0; u < ELLF_NB; ++u) { cm += c[u]; cv += c[u] * xsn[u]; }
   }
   cm = quad_sum(cm);
   cv = quad_sum(cv);
@@ -152,10 +162,7 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
     pb[0] = md.scale * (red[0] + red[1] + red[2] + red[3]);
     pb[1] = md.scale * (red[4] + red[5] + red[6] + red[7]);
   }
-  for (int j = wave; j < P; j += 4) {
-    const double s = wave_sum(accq[j * 64 + lane]);
-    if (lane == 0) pb[2 + j] = s;
-  }
+  for (int j = tid; j < P; j += 256) pb[2 + j] = (accw[j] + accw[P + j]) + (accw[2 * P + j] + accw[3 * P + j]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -289,8 +296,8 @@ int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, 
   return 0;
 }
 
-static int flow_lds(const tgp_model& md, int nslots, size_t* bytes) {
-  const size_t d = (size_t)(nslots > 0 ? nslots : 1) * 256 + (size_t)(md.P > 0 ? md.P : 1) * 64 + (size_t)md.RP * 256 + 16 +
+static int flow_lds(const tgp_model& md, int nblk, size_t* bytes) {
+  const size_t d = (size_t)(nblk > 0 ? nblk : 1) * ELLF_NB * 256 + (size_t)(md.P > 0 ? md.P : 1) * 4 + (size_t)md.RP * 256 + 16 +
                    2 * (size_t)(md.P + 2);
   *bytes = d * sizeof(double);
   return *bytes > 160 * 1024 - 1024 ? TGP_E_LDS : 0;
@@ -300,7 +307,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st) {
   size_t lds;
-  if (int rc = flow_lds(md, fp.nslots, &lds)) return rc;
+  if (int rc = flow_lds(md, fp.nblk, &lds)) return rc;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
   const int nb = (md.N + 63) / 64;
