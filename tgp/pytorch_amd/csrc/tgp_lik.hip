@@ -92,7 +92,10 @@ __device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, 
 // ---------------------------------------------------------------------------------------------------
 // TGP quadrature likelihood with gradients (likelihoods/GaussianNonLinearMean.py:64-150), four lanes per row
 // ---------------------------------------------------------------------------------------------------
-#define ELLF_NB 4 /* quadrature nodes in flight per lane */
+
+// LPR lanes share a data row (64 / LPR rows per wave: row = lane % RW, node group = lane / RW), NB nodes in flight per
+// lane.  The launcher picks LPR from N so that a chunk of ~16k rows still yields ~1000 workgroups.
+template <int LPR, int NB>
 __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, const double* __restrict__ Y,
                                                    const double* __restrict__ mu, const double* __restrict__ v,
                                                    const double* __restrict__ rowp, double* __restrict__ part,
@@ -102,19 +105,24 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = md.P, RP = md.RP;
   const int nb = fp.nblk > 0 ? fp.nblk : 1;
+  constexpr int RW = 64 / LPR;                              // rows per wave
   double* stack = sm;                                       // nblk * NB * 256: block inputs (checkpoint mode)
-  double* accw = stack + (size_t)nb * ELLF_NB * 256;        // 4 waves x P: per-wave shared-parameter accumulators
+  double* accw = stack + (size_t)nb * NB * 256;             // 4 waves x P: per-wave shared-parameter accumulators
   double* accr = accw + (size_t)4 * (P > 0 ? P : 1);        // RP * 256 (per-row parameters, lane-private)
   double* red = accr + (size_t)RP * 256;                    // 16
   double* tp = red + 16;                                    // P+2
   double* tg = tp + (P + 2) / 2 * 2;                        // P+2
   for (int i = tid; i < 4 * (P > 0 ? P : 1) + RP * 256; i += 256) accw[i] = 0.0;
   flow_params_lds(md, fp, tp, tg);
-  // 64 rows per block, 4 lanes per row (lanes l, l^16, l^32, l^48); lane group q takes the quadrature nodes
-  // s = q + 4 (NB j + u).  Every lane runs the same trip count (wave-wide sums inside the reverse sweep); nodes past S
-  // and padding rows carry weight 0.
-  const int qn = lane >> 4;
-  const int n = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  // lane group q takes the quadrature nodes s = q + LPR (NB j + u).  Every lane runs the same trip count (wave-wide
+  // sums inside the reverse sweep); nodes past S and padding rows carry weight 0.
+  const int qn = lane / RW;
+  const int n = blockIdx.x * (4 * RW) + wave * RW + (lane % RW);
+  auto group_sum = [&](double x) {   // over the LPR lanes of a row: lanes differing in the bits above log2(RW)
+#pragma unroll
+    for (int o = RW; o < 64; o <<= 1) x += __shfl_xor(x, o);
+    return x;
+  };
   const bool valid = n < md.N;
   const int nc = valid ? n : md.N - 1;
   const double eta = md.log_var_noise[0], einv = exp(-eta);
@@ -123,31 +131,31 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   const double m_ = mu[nc], sq = sqrt(2.0 * v[nc]), y = Y[nc];
   const double* rp = rowp ? rowp + (size_t)nc * RP : nullptr;
   double* aw = accw + (size_t)wave * (P > 0 ? P : 1);
-  for (int s0 = 0; s0 < md.S; s0 += 4 * ELLF_NB) {
-    double f[ELLF_NB], c[ELLF_NB], xsn[ELLF_NB], wsn[ELLF_NB];
+  for (int s0 = 0; s0 < md.S; s0 += LPR * NB) {
+    double f[NB], c[NB], xsn[NB], wsn[NB];
 #pragma unroll
-    for (int u = 0; u < ELLF_NB; ++u) {
-      const int s = s0 + 4 * u + qn, sc = s < md.S ? s : md.S - 1;
+    for (int u = 0; u < NB; ++u) {
+      const int s = s0 + LPR * u + qn, sc = s < md.S ? s : md.S - 1;
       xsn[u] = md.xs[sc];
       wsn[u] = (valid && s < md.S) ? md.wn[sc] : 0.0;
       f[u] = m_ + sq * xsn[u];
     }
-    flow_forward_ckpt<ELLF_NB>(F, f, rp, stack + tid, 256);
+    flow_forward_ckpt<NB>(F, f, rp, stack + tid, 256);
 #pragma unroll
-    for (int u = 0; u < ELLF_NB; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const double r = y - f[u];
       ellp += wsn[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
       etap += wsn[u] * (-0.5 + 0.5 * einv * r * r);
       c[u] = md.scale * einv * wsn[u] * r;
     }
-    flow_backward_ckpt<ELLF_NB>(F, c, rp, stack + tid, 256, aw, lane == 0, accr + tid, 256);
+    flow_backward_ckpt<NB>(F, c, rp, stack + tid, 256, aw, lane == 0, accr + tid, 256);
 #pragma unroll
-    for (int u = 0; u < ELLF_NB; ++u) { cm += c[u]; cv += c[u] * xsn[u]; }
+    for (int u = 0; u < NB; ++u) { cm += c[u]; cv += c[u] * xsn[u]; }
   }
-  cm = quad_sum(cm);
-  cv = quad_sum(cv);
+  cm = group_sum(cm);
+  cv = group_sum(cv);
   for (int j = 0; j < RP; ++j) {
-    const double a = quad_sum(accr[(size_t)j * 256 + tid]);
+    const double a = group_sum(accr[(size_t)j * 256 + tid]);
     if (valid && qn == 0 && g_rowp) g_rowp[(size_t)n * RP + j] = a;
   }
   if (valid && qn == 0) {
@@ -296,8 +304,8 @@ int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, 
   return 0;
 }
 
-static int flow_lds(const tgp_model& md, int nblk, size_t* bytes) {
-  const size_t d = (size_t)(nblk > 0 ? nblk : 1) * ELLF_NB * 256 + (size_t)(md.P > 0 ? md.P : 1) * 4 + (size_t)md.RP * 256 + 16 +
+static int flow_lds(const tgp_model& md, int nblk, int NB, size_t* bytes) {
+  const size_t d = (size_t)(nblk > 0 ? nblk : 1) * NB * 256 + (size_t)(md.P > 0 ? md.P : 1) * 4 + (size_t)md.RP * 256 + 16 +
                    2 * (size_t)(md.P + 2);
   *bytes = d * sizeof(double);
   return *bytes > 160 * 1024 - 1024 ? TGP_E_LDS : 0;
@@ -306,12 +314,24 @@ static int flow_lds(const tgp_model& md, int nblk, size_t* bytes) {
 int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, const double* mu, const double* v, const double* rowp,
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st) {
-  size_t lds;
-  if (int rc = flow_lds(md, fp.nblk, &lds)) return rc;
-  static size_t lds_cur = 48 * 1024;
-  if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow), lds, &lds_cur)) return rc;
+  // 4 lanes per row; nodes in flight per lane: all of the lane's nodes when the checkpoint stack fits (the per-step
+  // wave reductions of the shared-parameter partials are then paid once), else fewer
+  size_t lds = 0;
+  int NB = md.S > 16 ? 8 : 4;
+  while (NB > 1 && (flow_lds(md, fp.nblk, NB, &lds) != 0 || lds > 120 * 1024)) NB >>= 1;
+  if (int rc = flow_lds(md, fp.nblk, NB, &lds)) return rc;
   const int nb = (md.N + 63) / 64;
-  hipLaunchKernelGGL(k_ell_flow, dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp);
+  static size_t cur[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+#define ELLF_LAUNCH(nbv, slot)                                                                                            \
+  do {                                                                                                                    \
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow<4, nbv>), lds, &cur[slot])) return rc;               \
+    hipLaunchKernelGGL((k_ell_flow<4, nbv>), dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp); \
+  } while (0)
+  if (NB == 8) ELLF_LAUNCH(8, 0);
+  else if (NB == 4) ELLF_LAUNCH(4, 1);
+  else if (NB == 2) ELLF_LAUNCH(2, 2);
+  else ELLF_LAUNCH(1, 3);
+#undef ELLF_LAUNCH
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_parts, dim3((2 + md.P + 31) / 32), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);
   LAUNCH_CHECK();
