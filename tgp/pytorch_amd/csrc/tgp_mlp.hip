@@ -4,7 +4,7 @@
 // at BASELINE config C4, with dropout active in training (MC dropout, sparse_MF_SP.py:133-134).
 //
 // All nets of a flow have one architecture, so they run as ONE launch: grid = (row blocks, nets), 128 rows per
-// block = 2 waves x 64 rows.  A net's weights (zero-padded to 64 units x pad4(inputs)) and the block's activation
+// block = 4 waves x 32 rows.  A net's weights (zero-padded to 64 units x pad4(inputs)) and the block's activation
 // strips [unit][row] live in LDS; every layer product runs on v_mfma_f64_16x16x4_f64 with the weight tile as the A
 // operand and four 16-row groups of the strip as B operands (the strip layout is k-major, conflict-free).
 //   forward : out[n][net]
@@ -24,7 +24,9 @@ namespace tgp {
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-#define MLP_T 128      /* rows per block = 2 waves x 64 rows */
+#define MLP_T 128      /* rows per block */
+#define MLP_NT 256     /* threads per block = 4 waves x 32 rows (one block per CU by LDS: all four SIMDs get a wave) */
+#define MLP_RT 2       /* 16-row MFMA column tiles per wave */
 #define MLP_ST 129     /* LDS stride of an activation strip [unit][row] (k-major for the layer products) */
 #define MLP_HP 64      /* units padded to four 16-wide MFMA tiles */
 #define MLP_MAXH 64
@@ -52,16 +54,16 @@ __device__ __forceinline__ double mlp_act(int act, double z) { return act == 0 ?
 // global -> LDS copy of one hidden layer's weights into the zero-padded [HP][KP] image (+ bias [HP])
 __device__ __forceinline__ void mlp_stage_layer(const double* __restrict__ src, int H, int nin, int KP, double* Wp, double* bp,
                                                 int tid) {
-  for (int base = 0; base < MLP_HP * KP; base += 8 * MLP_T) {
+  for (int base = 0; base < MLP_HP * KP; base += 8 * MLP_NT) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = base + u * MLP_T + tid, j = e / KP, i = e % KP;
+      const int e = base + u * MLP_NT + tid, j = e / KP, i = e % KP;
       v[u] = (e < MLP_HP * KP && j < H && i < nin) ? src[j * nin + i] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = base + u * MLP_T + tid;
+      const int e = base + u * MLP_NT + tid;
       if (e < MLP_HP * KP) Wp[e] = v[u];
     }
   }
@@ -113,33 +115,33 @@ __device__ __forceinline__ void mlp_layer_mfma(const double* Wp, const double* b
   const int n = lane & 15, q = lane >> 4;
   const unsigned th = mlp_thresh(p);
   for (int jt = 0; jt * 16 < KPout; ++jt) {
-    d4 acc[4];
+    d4 acc[MLP_RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < MLP_RT; ++rt)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) acc[rt][rr] = bp[16 * jt + q + 4 * rr];
     // operands of k-step k0+4 are requested before the four MFMAs of k-step k0 issue (one wave per SIMD: nothing else
     // would hide the LDS latency)
     const double* wrow = Wp + (16 * jt + n) * KP + q;
-    const double* brow = ain + q * MLP_ST + 64 * wave + n;
-    double a = wrow[0], b[4];
+    const double* brow = ain + q * MLP_ST + 16 * MLP_RT * wave + n;
+    double a = wrow[0], b[MLP_RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) b[rt] = brow[16 * rt];
+    for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = brow[16 * rt];
     for (int k0 = 0; k0 < KP; k0 += 4) {
       const int kn = k0 + 4 < KP ? k0 + 4 : k0;
       const double an = wrow[kn];
-      double bn[4];
+      double bn[MLP_RT];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
+      for (int rt = 0; rt < MLP_RT; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
+      for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
       a = an;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) b[rt] = bn[rt];
+      for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = bn[rt];
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-      const int rl = 64 * wave + 16 * rt + n;
+    for (int rt = 0; rt < MLP_RT; ++rt) {
+      const int rl = 16 * MLP_RT * wave + 16 * rt + n;
       const uint64_t h4 = drop ? mlp_hash4(seed, step, net, layer, row0 + rl, 4 * jt + q) : 0;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -164,11 +166,13 @@ __device__ __forceinline__ void mlp_stage_all(const MlpArgs& m, const MlpLds& Lo
   if (tid < MLP_HP) sm[Lo.wo + tid] = tid < m.H ? src[tid] : 0.0;
   if (tid == 0) sm[Lo.wo + MLP_HP] = src[m.H];
   // inputs: a0 [KP0][ST], this block's rows (padding rows repeat the last row; their d out is zero)
-  const int row = blockIdx.x * MLP_T + tid, rc = row < m.N ? row : m.N - 1;
-  for (int d = 0; d < Lo.KP0; ++d) sm[Lo.act0 + d * MLP_ST + tid] = d < m.D ? m.X[(size_t)rc * m.D + d] : 0.0;
+  if (tid < MLP_T) {
+    const int row = blockIdx.x * MLP_T + tid, rc = row < m.N ? row : m.N - 1;
+    for (int d = 0; d < Lo.KP0; ++d) sm[Lo.act0 + d * MLP_ST + tid] = d < m.D ? m.X[(size_t)rc * m.D + d] : 0.0;
+  }
 }
 
-__global__ __launch_bounds__(MLP_T, 2) void k_mlp_fwd(MlpArgs m, double* __restrict__ out) {
+__global__ __launch_bounds__(MLP_NT, 2) void k_mlp_fwd(MlpArgs m, double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, net = blockIdx.y, H = m.H, L = m.L;
@@ -184,21 +188,24 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_fwd(MlpArgs m, double* __restr
     mlp_layer_mfma(sm + Lo.wp(l), sm + Lo.bp(l), l == 0 ? Lo.KP0 : Lo.KPH, ain, aout, Lo.KPH, lane, wave, m.act, drop, m.p, scale,
                    m.seed, step, net, l, blockIdx.x * MLP_T);
     ain = aout;
-    __builtin_amdgcn_wave_barrier();  // a wave reads back only its own 64 columns
+    __builtin_amdgcn_wave_barrier();  // a wave reads back only its own 32 columns
   }
-  const int row = blockIdx.x * MLP_T + tid;
-  const double* wo = sm + Lo.wo;
-  double s0 = wo[MLP_HP], s1 = 0.0;
-  for (int i = 0; i + 2 <= Lo.KPH; i += 2) {
-    s0 = fma(wo[i], ain[i * MLP_ST + tid], s0);
-    s1 = fma(wo[i + 1], ain[(i + 1) * MLP_ST + tid], s1);
+  __syncthreads();  // row r's strip column was written by wave r / 32, the output dot runs on threads 0..127
+  if (tid < MLP_T) {
+    const int row = blockIdx.x * MLP_T + tid;
+    const double* wo = sm + Lo.wo;
+    double s0 = wo[MLP_HP], s1 = 0.0;
+    for (int i = 0; i + 2 <= Lo.KPH; i += 2) {
+      s0 = fma(wo[i], ain[i * MLP_ST + tid], s0);
+      s1 = fma(wo[i + 1], ain[(i + 1) * MLP_ST + tid], s1);
+    }
+    if (row < m.N) out[(size_t)row * m.nnets + net] = s0 + s1;
   }
-  if (row < m.N) out[(size_t)row * m.nnets + net] = s0 + s1;
 }
 
 // backward; partial weight gradients of this (row block, net) into part[(blockIdx.x * nnets + net) * PW ...].
 // The delta of a layer overwrites that layer's activation strip in place (own element only).
-__global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* __restrict__ g_out, double* __restrict__ part) {
+__global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* __restrict__ g_out, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
   mlp_stage_all(m, Lo, sm, net, tid);
   const int row = blockIdx.x * MLP_T + tid;
   double* gos = sm + Lo.gos;
-  gos[tid] = row < m.N ? g_out[(size_t)row * m.nnets + net] : 0.0;
+  if (tid < MLP_T) gos[tid] = row < m.N ? g_out[(size_t)row * m.nnets + net] : 0.0;
   __syncthreads();
   const int step = m.step_dev ? m.step_dev[0] : 0;
   const bool drop = m.training && m.p > 0.0;
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
   double* gp = part + ((size_t)blockIdx.x * m.nnets + net) * PW;
   // ---- output layer: out = wo . aL + bo :  dwo[i] = sum_rows go * aL[i][row], dbo = sum_rows go ----
   double* aL = sm + Lo.actl + (size_t)(L - 1) * KPH * MLP_ST;
-  for (int i = tid; i <= H; i += MLP_T) {
+  for (int i = tid; i <= H; i += MLP_NT) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 2
     for (int r = 0; r < MLP_T; r += 4) {
@@ -254,11 +261,13 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
     return (unsigned)((h4 >> (16 * ((j >> 2) & 3))) & 0xFFFFu) >= th;
   };
   {
+    // delta_L in place (zero on padded units): 256 threads over the 128 x KPH strip, two half-ranges of units
     const double* wo = sm + Lo.wo;
-    const double go = gos[tid];
-    for (int i = 0; i < KPH; ++i) {
-      const double a = aL[i * MLP_ST + tid];
-      aL[i * MLP_ST + tid] = wo[i] * go * dfac(a, kept_flag(L - 1, tid, i));   // delta_L in place (zero on padded units)
+    const int rl = tid & (MLP_T - 1), half = tid >> 7, hk = (KPH + 1) / 2;
+    const double go = gos[rl];
+    for (int i = half * hk; i < min(KPH, (half + 1) * hk); ++i) {
+      const double a = aL[i * MLP_ST + rl];
+      aL[i * MLP_ST + rl] = wo[i] * go * dfac(a, kept_flag(L - 1, rl, i));
     }
   }
   __syncthreads();
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
     // dW[j][i] = sum_rows delta[j][row] ain[i][row]: 16 x 16 tiles over the block's 128 rows, tiles dealt to the two waves
     {
       const int njt = (H + 15) / 16, nit = (nin + 15) / 16;
-      for (int t = wave; t < njt * nit; t += 2) {
+      for (int t = wave; t < njt * nit; t += MLP_NT / 64) {
         const int jt = t / nit, it = t % nit;
         const int ja = 16 * jt + n, ib = 16 * it + n;
         const bool va = ja < KPH, vb = ib < KPin;
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
         }
       }
       // db[j] = sum_rows delta[j][row]
-      for (int j = tid; j < H; j += MLP_T) {
+      for (int j = tid; j < H; j += MLP_NT) {
         const double* dj = dl + j * MLP_ST;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 2
@@ -307,30 +316,30 @@ __global__ __launch_bounds__(MLP_T, 2) void k_mlp_bwd(MlpArgs m, const double* _
     {
       const double* Wp = sm + Lo.wp(l);
       for (int it = 0; it * 16 < KPH; ++it) {
-        d4 acc[4];
+        d4 acc[MLP_RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = {0, 0, 0, 0};
+        for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = {0, 0, 0, 0};
         const bool vi = 16 * it + n < KPH;
         const double* wcol = Wp + q * KPH + (vi ? 16 * it + n : 0);
-        const double* brow = dl + q * MLP_ST + 64 * wave + n;
-        double a = vi ? wcol[0] : 0.0, b[4];
+        const double* brow = dl + q * MLP_ST + 16 * MLP_RT * wave + n;
+        double a = vi ? wcol[0] : 0.0, b[MLP_RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) b[rt] = brow[16 * rt];
+        for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = brow[16 * rt];
         for (int k0 = 0; k0 < KPH; k0 += 4) {
           const int kn = k0 + 4 < KPH ? k0 + 4 : k0;
           const double an = vi ? wcol[kn * KPH] : 0.0;
-          double bn[4];
+          double bn[MLP_RT];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
+          for (int rt = 0; rt < MLP_RT; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
+          for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
           a = an;
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) b[rt] = bn[rt];
+          for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = bn[rt];
         }
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          const int rl = 64 * wave + 16 * rt + n;
+        for (int rt = 0; rt < MLP_RT; ++rt) {
+          const int rl = 16 * MLP_RT * wave + 16 * rt + n;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int i = 16 * it + q + 4 * rr;
@@ -387,7 +396,7 @@ int launch_mlp_forward(const tgp_mlp& d, const double* X, const double* W, const
   const size_t lds = mlp_lds_bytes(d.D, d.H, d.L, false);
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_mlp_fwd), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(k_mlp_fwd, dim3((d.N + MLP_T - 1) / MLP_T, d.nnets), dim3(MLP_T), lds, st, mlp_args(d, X, W, step_dev), out);
+  hipLaunchKernelGGL(k_mlp_fwd, dim3((d.N + MLP_T - 1) / MLP_T, d.nnets), dim3(MLP_NT), lds, st, mlp_args(d, X, W, step_dev), out);
   LAUNCH_CHECK();
   return 0;
 }
@@ -400,7 +409,7 @@ int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, cons
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_mlp_bwd), lds, &lds_cur)) return rc;
   const int nblk = (d.N + MLP_T - 1) / MLP_T;
-  hipLaunchKernelGGL(k_mlp_bwd, dim3(nblk, d.nnets), dim3(MLP_T), lds, st, mlp_args(d, X, W, step_dev), g_out, ws);
+  hipLaunchKernelGGL(k_mlp_bwd, dim3(nblk, d.nnets), dim3(MLP_NT), lds, st, mlp_args(d, X, W, step_dev), g_out, ws);
   LAUNCH_CHECK();
   const size_t len = (size_t)d.nnets * mlp_weights_per_net(d.D, d.H, d.L);
   hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, ws, nblk, len, g_W);
