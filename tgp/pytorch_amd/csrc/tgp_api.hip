@@ -1,6 +1,7 @@
 // tgp_api.hip -- the extern "C" surface of libtgp_hip.so (declared in include/tgp_hip.h).
 // Argument checking, plan/workspace bookkeeping and the launch sequence of one ELBO step:
-//   k_prep_a -> k_prep_b -> k_rows<MT,DP> -> k_reduce -> k_bwd1..5            (9 launches, no host sync)
+//   M <= 128 : k_prep_a -> k_rows<MT,DP,MODE> -> k_reduce -> k_bwd12 -> k_bwd34 -> k_bwd5   (6 launches, no host sync)
+//   M  > 128 : the chunked GEMM pipeline of tgp_big.hip (same entry points, chosen by M / kernel)
 #include <cstdio>
 #include <cstring>
 #include "tgp_dev.hpp"

@@ -4,7 +4,8 @@ ELBO -> (-ELBO).backward() -> Adam.step()) with everything resident on the GPU.
 * every trainable tensor is a view into ONE flat float64 buffer (parameters, gradients, Adam moments),
   so the optimiser is a single launch and the multi-GPU exchange is a single all-reduce;
 * the C-ABI argument structs are built once (pointers never change), so one step is
-  `tgp_elbo_step_f64` + `tgp_adam_dev_f64` = 11 kernel launches with no host synchronisation;
+  `tgp_elbo_step_f64` + `tgp_adam_dev_groups_f64` = 7 kernel launches (M <= 128) with no host synchronisation, plus
+  the MLP forward/backward launches for input-dependent flows;
 * `capture()` records that sequence into a HIP graph (torch.cuda.CUDAGraph is only the stream/graph
   plumbing) and `replay()` re-launches it;
 * multi-GPU (one process per GPU): rows are sharded, every rank runs the same M x M work, and ONE
