@@ -545,16 +545,29 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
   const double* Zs = ws + p.Zs;
   for (int it = tid; it < M * (D + 1); it += 256) {
     const int j = it / (D + 1), d = it % (D + 1);
-    double cs = 0.0;
-    for (int ib = 0; ib < MT; ++ib) cs += ws[p.PP + ((size_t)ib * MP + j) * PPW + DP];
+    // all 26 partials of this item are requested before the first one is used (a loop over the MT row blocks with a
+    // runtime bound pays one L2 round trip per element)
+    const int dd = d < D ? d : 0;
+    double csv[TGP_MAX_MT], Rv[TGP_MAX_MT];
+#pragma unroll
+    for (int ib = 0; ib < TGP_MAX_MT; ++ib) {
+      const size_t base = p.PP + ((size_t)(ib < MT ? ib : 0) * MP + j) * PPW;
+      csv[ib] = ws[base + DP];
+      Rv[ib] = ws[base + dd];
+    }
     const double t0 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
+    const double t1v = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
+    const double t2v = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
+    double cs = 0.0;
+#pragma unroll
+    for (int ib = 0; ib < TGP_MAX_MT; ++ib) cs += ib < MT ? csv[ib] : 0.0;
     if (d == D) {
       term[it] = cs + t0;
     } else {
       double R = 0.0;
-      for (int ib = 0; ib < MT; ++ib) R += ws[p.PP + ((size_t)ib * MP + j) * PPW + d];
-      const double t1 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + d);
-      const double t2 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + d);
+#pragma unroll
+      for (int ib = 0; ib < TGP_MAX_MT; ++ib) R += ib < MT ? Rv[ib] : 0.0;
+      const double t1 = t1v, t2 = t2v;
       const double zj = Zs[j * DP + d];
       // dELL/dzs_jd = [T1 - zs T0] (rows) + 2 sum_i Ep_ij (zs_id - zs_jd) (K_MM, Ep symmetric)
       g.Z[j * D + d] = (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d];
@@ -562,12 +575,19 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
       term[it] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
     }
   }
+  // m, theta first: their loads are independent of the reduction below and overlap with it
+  for (int i = tid; i < M; i += 256) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
+  if (g.theta != nullptr)
+    for (int i = tid; i < p.P; i += 256) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
   __syncthreads();
-  if (tid <= D) {
+  // column sums of term[M][D+1]: one wave per column (a single thread per column walked M LDS reads in a chain)
+  for (int d = tid >> 6; d <= D; d += 4) {
     double s = 0.0;
-    for (int j = 0; j < M; ++j) s += term[j * (D + 1) + tid];
-    if (tid < D) {
-      g.raw_ls[tid] = s * ws[p.ils + tid] * sigmoid_d(md.raw_ls[tid]);
+    for (int j = tid & 63; j < M; j += 64) s += term[j * (D + 1) + d];
+    s = wave_sum(s);
+    if ((tid & 63) != 0) continue;
+    if (d < D) {
+      g.raw_ls[d] = s * ws[p.ils + d] * sigmoid_d(md.raw_ls[d]);
     } else {
       const double s2b = red_tail(p, ws, p.slab_C + C_SVB) + s / s2;
       g.raw_os[0] = s2b * hdr[H_SIG_OS];
@@ -579,10 +599,6 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
       out[3] = 0.0;
     }
   }
-  // m: sbar = A mubar summed over rows, minus the KL part (dKL/dm = m)
-  for (int i = tid; i < M; i += 256) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
-  if (g.theta != nullptr)
-    for (int i = tid; i < p.P; i += 256) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
 }
 
 // ---------------------------------------------------------------------------------------------------
