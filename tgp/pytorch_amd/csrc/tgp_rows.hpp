@@ -164,13 +164,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   TGP_STAMP(a.ws, p, 0);
   // ---- stage the small shared operands ----
-  for (int i = tid; i < MP * DP; i += 256) zs[i] = ws[p.Zs + i];
-  for (int i = tid; i < MP; i += 256) mv[i] = ws[p.mpad + i];
-  if (tid < 16) ils[tid] = ws[p.ils + tid];
-  if (p.lik == TGP_LIK_FLOW) {
-    for (int i = tid; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; }
-    for (int i = tid; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
-    for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
+  // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
+  //  paid one L2 round trip each)
+  {
+    constexpr int NZ = (MP * DP + 255) / 256;
+    double zv[NZ];
+#pragma unroll
+    for (int u = 0; u < NZ; ++u) zv[u] = tid + 256 * u < MP * DP ? ws[p.Zs + tid + 256 * u] : 0.0;
+    const double mv0 = tid < MP ? ws[p.mpad + tid] : 0.0;
+    const double il0 = tid < 16 ? ws[p.ils + tid] : 0.0;
+    const bool fl = p.lik == TGP_LIK_FLOW;
+    const double tp0 = (fl && tid < P) ? ws[p.tp + tid] : 0.0, tg0 = (fl && tid < P) ? ws[p.tg + tid] : 0.0;
+    const double xs0 = (fl && tid < p.S) ? a.xs[tid] : 0.0, wn0 = (fl && tid < p.S) ? a.wn[tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < NZ; ++u)
+      if (tid + 256 * u < MP * DP) zs[tid + 256 * u] = zv[u];
+    if (tid < MP) mv[tid] = mv0;
+    if (tid < 16) ils[tid] = il0;
+    if (fl) {
+      if (tid < P) { tpL[tid] = tp0; tgL[tid] = tg0; }
+      if (tid < p.S) { xsL[tid] = xs0; wnL[tid] = wn0; }
+      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; }
+      for (int i = tid + 256; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
+      for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
+    }
   }
   if (TRAIN) {
     const int nacc = P * 64 + RP * 256;
