@@ -4,7 +4,7 @@
 //   A operand: lane l holds A[i = l&15][k = l>>4]        (one f64)
 //   B operand: lane l holds B[k = l>>4][j = l&15]        (one f64)
 //   C/D      : lane l, register r holds D[row = (l>>4) + 4r][col = l&15]
-// (layout verified on hardware with exact integer data, scratch/mfma_probe.hip).  Consequence used
+// (layout verified on hardware with exact integer data, tools/probes/mfma_probe.hip).  Consequence used
 // everywhere below: accumulator register r of a 16x16 tile IS the B operand of k-step r of a product
 // that contracts over the tile's ROW index -- GEMM chains need no LDS round trip.
 #pragma once
@@ -107,7 +107,7 @@ __device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : l
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // exp(x) with a SHORT dependency chain.  A dependent f64 FMA costs ~32 cycles on gfx950 (measured,
-// scratch/mfma_rate.hip) and the row kernel runs one wave per SIMD, so the ~25-deep chain of the library exp is
+// tools/probes/mfma_rate.hip) and the row kernel runs one wave per SIMD, so the ~25-deep chain of the library exp is
 // what the K tiles and the flow quadrature were waiting on.  Cody-Waite reduction x = k ln2 + r, |r| <= 0.347,
 // degree-13 Taylor polynomial evaluated by Estrin's scheme (depth 4), scaled by v_ldexp_f64.
 // Truncation r^14/14! < 5e-18; total error a few ulp.  Arguments are clamped to the finite range.
