@@ -263,3 +263,23 @@ def test_big_standalone_cholesky_matches_torch(M):
     _, _, status = ops.cholesky(A.to(dev))
     torch.cuda.synchronize()
     assert int(status[0]) == M // 2 + 1
+
+
+def test_big_jitter_ladder_recovers():
+    """The reference's psd_safe_cholesky protocol (dsp/utils.py:256-269) on the general-M path: the duplicated inducing
+    point of test_big_non_psd_reports_pivot -> status -> retry with jitter 1e-8 -> NumericalWarning, finite results,
+    identical to the step launched with that jitter up front (the retry is a plain re-launch)."""
+    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd import ops
+    dev = _dev()
+    prob = orc.synthetic_problem(400, 4, 200, seed=7, flow=None, S=8)
+    prob["params"]["Z"][150] = prob["params"]["Z"][20]
+    p = {k: t.to(dev) for k, t in prob["params"].items()}
+    args = (prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"],
+            p["log_var_noise"], 400.0)
+    with pytest.warns(ops.NumericalWarning):
+        out, grads, status, _ = ops.elbo_step_safe(*args)
+    assert int(status[0]) == 0
+    assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(t).all()) for t in grads.values())
+    out2, grads2, status2, _ = ops.elbo_step(*args, jitter=1e-8)
+    assert int(status2[0]) == 0 and torch.equal(out.cpu(), out2.cpu())
