@@ -140,6 +140,7 @@ class ElboEngine:
         if self.mlp is not None:
             d = self.mlp.struct(self.N, True)
             self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
+        self._side = None
         self.graph = None
         self._warm = False
 
@@ -176,10 +177,29 @@ class ElboEngine:
                                                   self.mlp_ws.numel() * 8, L.stream_ptr()), "tgp_mlp_backward_f64")
 
     def forward_backward(self):
-        """MLPs -> fused ELBO step -> MLP backward: every gradient of the flat buffer is written."""
-        self.mlp_forward()
-        self.elbo()
-        self.mlp_backward()
+        """MLPs -> fused ELBO step -> MLP backward: every gradient of the flat buffer is written.
+
+        With MLPs the two halves that do not depend on each other run on a side stream: the MLP forward (needs X and
+        the weights only) under the M x M prepare phase (K_MM, Cholesky, KL), and the MLP backward (needs d/d rowp from
+        the row kernel only) under the M x M adjoint.  Fork and join are event waits, valid under graph capture."""
+        if self.mlp is None:
+            self.elbo()
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.mlp_forward()
+        self.elbo(1)                 # prepare
+        main.wait_stream(side)
+        self.elbo(2)                 # rows: consumes rowp, produces g_rowp
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.mlp_backward()
+        self.elbo(4)                 # M x M adjoint + gradient assembly
+        main.wait_stream(side)
 
     def step(self):
         self.forward_backward()
