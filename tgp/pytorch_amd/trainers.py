@@ -144,6 +144,7 @@ class Trainer_SP_regression:
             self.total_trainer_epochs += 1
             if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
                 h = hist[last:ep + 1].mean(0).cpu()     # the only host sync: once per `validate_each` epochs
+                eng.check_status()                      # a failed Cholesky surfaces here, not thousands of epochs later
                 print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
                     ep + 1, epochs_total, float(h[0]), float(h[1]), float(h[2]), time.time() - t0))
                 t0, last = time.time(), ep + 1
