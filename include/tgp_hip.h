@@ -87,6 +87,10 @@ typedef struct tgp_model {
   double jitter;   /* added to diag(K_MM) before the Cholesky (0 unless retrying)       */
   double kl_scale; /* weight of the KL gradient in this call: 1/world_size so that an
                       all-reduce(sum) over row shards counts it once                    */
+  double jitter_ladder; /* > 0: psd_safe_cholesky's retry ladder (dsp/utils.py:256-269) runs ON THE DEVICE -- a failed
+                      factorisation is repeated with jitter_ladder * 10^i, i = 0..2, added to diag(K_MM); status[2] = the
+                      level that succeeded (1..3) or 0.  0: no retry, status[0] reports the pivot (host ladder:
+                      ops.elbo_step_safe).  Fused path (M <= 128, scale_rbf) only; ignored elsewhere.  */
   /* parameters (reference nn.Parameter names in brackets) */
   const double* Z;             /* (M,D)   [Z]                                               */
   const double* raw_ls;        /* (D)     [covariance_function.base_kernel.raw_lengthscale] */

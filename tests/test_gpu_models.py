@@ -468,3 +468,28 @@ def test_engine_id_tgp_hip_mlps_match_oracle_adam_history(graph):
     assert rel_err(torch.tensor(hist, dtype=torch.float64), torch.tensor(ref, dtype=torch.float64)) < 1e-8
     assert rel_err(eng.fp.view("nn").cpu(), Wn.detach()) < 1e-7
     assert rel_err(eng.fp.view("Z").cpu(), leaves["Z"].detach()) < 1e-7
+
+
+def test_device_jitter_ladder_inside_the_captured_step():
+    """The resident engine cannot ask the host to retry a failed Cholesky: psd_safe_cholesky's ladder (dsp/utils.py:256-269)
+    runs inside k_prep_a.  Duplicated inducing points: without the ladder the status word reports the pivot; with it the
+    step succeeds with jitter 1e-8, status[2] names the level, the engine warns once, and the result equals the step
+    launched with that jitter up front."""
+    from tgp.pytorch_amd import ops
+    from tgp.pytorch_amd.engine import ElboEngine
+    prob = orc.synthetic_problem(128, 3, 16, seed=1, flow=None, S=8)
+    prob["params"]["Z"][1] = prob["params"]["Z"][0]
+    e0 = ElboEngine(prob["X"], prob["Y"], prob["params"], 128.0, device=DEV, jitter_ladder=0.0)
+    e0.elbo()
+    torch.cuda.synchronize()
+    assert int(e0.status[0]) > 0
+    e1 = ElboEngine(prob["X"], prob["Y"], prob["params"], 128.0, device=DEV, jitter_ladder=1e-8)
+    e1.elbo()
+    with pytest.warns(ops.NumericalWarning):
+        e1.check_status()
+    assert int(e1.status[0]) == 0 and int(e1.status[2]) == 1
+    p = {k: v.to(DEV) for k, v in prob["params"].items()}
+    out, grads, status, _ = ops.elbo_step(prob["X"].to(DEV), prob["Y"].to(DEV), p["Z"], p["raw_lengthscale"],
+                                           p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], 128.0, jitter=1e-8)
+    assert torch.equal(e1.fp.out[:3].cpu(), out[:3].cpu())
+    assert torch.equal(e1.fp.gview("Z").cpu(), grads["Z"].cpu())

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // K_MM element (lower triangle only: the factorisation never reads above the diagonal; the strict-upper TILES later
   // receive J^T); identity on the padding keeps L and L^-1 well defined
   bool has_nan = false;
+  double jit = md.jitter;  // raised by the on-device retry ladder below
   auto kmm_elem = [&](int rr, int cc) {
     double k;
     if (rr < M) {
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       }
       k = s2 * exp_fast(-0.5 * d2);
       has_nan |= (k != k);
-      if (rr == cc) k += md.jitter;
+      if (rr == cc) k += jit;
     } else {
       k = (rr == cc) ? 1.0 : 0.0;
     }
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   //               waves 1..7 (off the chain)   : iteration 0: fill K_MM column block 0 below tile (0,0) and tile (1,1);
   //                                              iteration j >= 1: the other panel tiles (i > j, j-1) and the inverse
   //                                              tiles (j-1, c < j-1) of step j-1, then K_MM column block j below its diagonal tile and tile (j+1,j+1)
+  // psd_safe_cholesky on the device (dsp/utils.py:256-269): when md.jitter_ladder > 0 a failed factorisation is
+  // repeated with jitter_ladder * 10^i, i = 0..2, added to the diagonal, without the host; status[2] reports the
+  // level that succeeded (0 = none needed) so that the caller can issue the reference's warning lazily.
+  int attempt = 0;
+  for (;; ++attempt) {
   for (int j = 0; j <= MT; ++j) {
     const int j0 = 16 * j;
     if (wave == 0) {
@@ -304,6 +310,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   }
   if (has_nan) s_nan = 1;
   __syncthreads();
+  if (s_info == 0 || s_nan != 0 || !(md.jitter_ladder > 0.0) || attempt == 3) break;
+  __syncthreads();  // everybody has read s_info
+  if (tid == 0) s_info = 0;
+  jit = md.jitter + md.jitter_ladder * (attempt == 0 ? 1.0 : (attempt == 1 ? 10.0 : 100.0));
+  __syncthreads();
+  }
   // ---- write L, J (lower tiles) and J^T (upper tiles), one wave per tile, 128-byte row segments.  A single CU
   //      stores at ~30-50 GB/s, so block 0 writes only what is non-zero; the structurally-zero tiles are written
   //      by the (otherwise idle) tile blocks of this same launch ----
@@ -332,6 +344,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   if (tid == 0) {
     status[0] = s_info;
     status[1] = s_nan;
+    status[2] = s_info == 0 ? attempt : 0;
   }
 #ifdef TGP_STAMPS
   if (tid == 0) {

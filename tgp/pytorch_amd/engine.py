@@ -86,7 +86,8 @@ class FlatParams:
 class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
                  eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
-                 kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True):
+                 kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True,
+                 jitter_ladder=1e-8):
         """`mlp` (ops.MlpSpec) + `mlp_weights` (packed, nnets * weights_per_net): input-dependent flow (ID_TGP) whose
         per-row parameters come from the HIP MLP kernels inside the step; `nn_weight_decay` is the reference's Adam
         group for the 'NNets' parameters (main.py:276-288)."""
@@ -127,6 +128,10 @@ class ElboEngine:
         self.md, self._keep = ops._model_struct(self.X, fp.view("Z"), fp.view("raw_ls"), fp.view("raw_os"), fp.view("m"),
                                                 fp.view("Lam"), fp.view("lvn"), scale, 0.0, 1.0 / self.world_size,
                                                 self.flow, fp.view("theta") if P else None, self.S, kernel)
+        # psd_safe_cholesky's retry ladder (dsp/utils.py:256-269) runs on the device inside the captured step (fused path);
+        # `jitter_ladder` is its base value (the reference: 1e-8 in float64, or cg.global_jitter), 0 disables it
+        self.md.jitter_ladder = float(jitter_ladder or 0.0)
+        self._warned_jitter = 0
         self.gs = L.TgpGrads()
         self.gs.Z, self.gs.raw_ls, self.gs.raw_os = (L.ptr(fp.gview(k)) for k in ("Z", "raw_ls", "raw_os"))
         self.gs.m, self.gs.Lam, self.gs.log_var_noise = (L.ptr(fp.gview(k)) for k in ("m", "Lam", "lvn"))
@@ -245,6 +250,11 @@ class ElboEngine:
         st = self.status.cpu()
         if int(st[1]):
             raise ops.NanError("cholesky: K_MM contains NaN")
+        if int(st[2]) > self._warned_jitter:
+            import warnings
+            self._warned_jitter = int(st[2])
+            warnings.warn("A not p.d., added jitter of %g to the diagonal" % (self.md.jitter_ladder * 10 ** (int(st[2]) - 1)),
+                          ops.NumericalWarning)
         if int(st[0]):
             raise ops.NotPSDError("K_MM not positive definite at pivot %d (engine runs without the jitter ladder; "
                                   "use ops.elbo_step_safe to retry with jitter)" % int(st[0]))

@@ -26,7 +26,7 @@ class TgpModel(C.Structure):
     _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("S", C.c_int32), ("nblk", C.c_int32),
                 ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("kernel", C.c_int32), ("reserved0", C.c_int32),
                 ("scale", C.c_double),
-                ("jitter", C.c_double), ("kl_scale", C.c_double), ("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp),
+                ("jitter", C.c_double), ("kl_scale", C.c_double), ("jitter_ladder", C.c_double), ("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp),
                 ("m", _dp), ("Lam", _dp), ("log_var_noise", _dp), ("theta", _dp), ("program", _dp), ("xs", _dp),
                 ("wn", _dp)]
 

@@ -115,7 +115,8 @@ class Trainer_SP_regression:
         W = torch.cat([p.detach().reshape(-1) for p in nn_params]) if nn_params else None
         eng = ElboEngine(ld.X, ld.Y, params, float(model.N), flow_blocks=blocks, S=getattr(model, "quad_points", None),
                          lr=lr_ALL, device=ld.X.device, kernel=model.covariance_function.hip_kernel, mlp=mspec,
-                         mlp_weights=W, nn_weight_decay=wd, mlp_training=True)
+                         mlp_weights=W, nn_weight_decay=wd, mlp_training=True,
+                         jitter_ladder=cg.global_jitter if cg.global_jitter is not None else 1e-8)
         # the modules' parameters become views of the engine's flat buffer
         fp, k = eng.fp, model.covariance_function
         with torch.no_grad():
