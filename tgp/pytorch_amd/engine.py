@@ -146,6 +146,7 @@ class ElboEngine:
             d = self.mlp.struct(self.N, True)
             self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
         self._side = None
+        self.pipeline_steps = True      # ID_TGP, one rank: capture the rotated unit (see capture())
         self.graph = None
         self._warm = False
 
@@ -168,18 +169,27 @@ class ElboEngine:
                                               L.ptr(self.step_dev), 1, L.stream_ptr())
         L.check(rc, "tgp_adam_dev_groups_f64")
 
-    def mlp_forward(self):
+    def mlp_forward(self, step=None):
         if self.mlp is not None:
             d = self.mlp.struct(self.N, self.mlp_training)
-            L.check(self.lib.tgp_mlp_forward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")), L.ptr(self.step_dev),
-                                                 L.ptr(self.rowp), L.stream_ptr()), "tgp_mlp_forward_f64")
+            L.check(self.lib.tgp_mlp_forward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")),
+                                                 L.ptr(self.step_dev if step is None else step), L.ptr(self.rowp),
+                                                 L.stream_ptr()), "tgp_mlp_forward_f64")
 
-    def mlp_backward(self):
+    def mlp_backward(self, step=None):
         if self.mlp is not None:
             d = self.mlp.struct(self.N, self.mlp_training)
-            L.check(self.lib.tgp_mlp_backward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")), L.ptr(self.step_dev),
-                                                  L.ptr(self.g_rowp), L.ptr(self.fp.gview("nn")), L.ptr(self.mlp_ws),
-                                                  self.mlp_ws.numel() * 8, L.stream_ptr()), "tgp_mlp_backward_f64")
+            L.check(self.lib.tgp_mlp_backward_f64(d, L.ptr(self.X), L.ptr(self.fp.view("nn")),
+                                                  L.ptr(self.step_dev if step is None else step), L.ptr(self.g_rowp),
+                                                  L.ptr(self.fp.gview("nn")), L.ptr(self.mlp_ws), self.mlp_ws.numel() * 8,
+                                                  L.stream_ptr()), "tgp_mlp_backward_f64")
+
+    def _adam_segment(self, lo, hi, weight_decay, step):
+        fp = self.fp
+        rc = self.lib.tgp_adam_dev_f64(L.ptr(fp.data[lo:hi]), L.ptr(fp.grad[lo:hi]), L.ptr(fp.exp_avg[lo:hi]),
+                                       L.ptr(fp.exp_avg_sq[lo:hi]), hi - lo, self.lr, self.betas[0], self.betas[1], self.eps,
+                                       float(weight_decay), L.ptr(step), 1, L.stream_ptr())
+        L.check(rc, "tgp_adam_dev_f64")
 
     def forward_backward(self):
         """MLPs -> fused ELBO step -> MLP backward: every gradient of the flat buffer is written.
@@ -207,6 +217,8 @@ class ElboEngine:
         main.wait_stream(side)
 
     def step(self):
+        if self.graph == "rotated":      # the captured unit straddles two steps: eager steps would repeat half of one
+            return self.replay()
         self.forward_backward()
         self.allreduce()
         self.adam()
@@ -218,6 +230,35 @@ class ElboEngine:
         if not self._warm:
             self.forward_backward()          # first launch sets kernel attributes; must happen outside capture
         torch.cuda.synchronize()
+        if self.mlp is not None and self.world_size == 1 and self.pipeline_steps:
+            # Rotated unit.  The long pole of an ID_TGP step is the MLP backward (97 us), and nothing of step t depends on it
+            # except the network weights' own Adam update and the NEXT step's MLP forward.  So the captured unit starts
+            # at the row kernel:   main: rows(t) -> M x M adjoint(t) -> Adam(GP params) -> prepare(t+1)
+            #                      side:            MLP backward(t) -> Adam(network weights) -> MLP forward(t+1)
+            # joined at the end.  Same operations in the same per-step order as step(); prepare(0) and MLP forward(0)
+            # run here, eagerly, once.  Two device step counters (one per Adam group; the dropout masks follow the
+            # network group's) keep both launches graph-replayable.
+            n_plain = self.fp.offsets["nn"]
+            self.step_nn = self.step_dev.clone()
+            self.elbo(1)
+            self.mlp_forward(self.step_nn)
+            torch.cuda.synchronize()
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1):
+                main = torch.cuda.current_stream()
+                side = self._side
+                self.elbo(2)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.mlp_backward(self.step_nn)
+                    self._adam_segment(n_plain, self.fp.n, self.nn_wd, self.step_nn)
+                    self.mlp_forward(self.step_nn)
+                self.elbo(4)
+                self._adam_segment(0, n_plain, 0.0, self.step_dev)
+                self.elbo(1)
+                main.wait_stream(side)
+            self.graph = "rotated"
+            return
         if self.world_size > 1 and not with_allreduce:
             # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -237,7 +278,7 @@ class ElboEngine:
             self.graph = "full"
 
     def replay(self):
-        if self.graph == "full":
+        if self.graph in ("full", "rotated"):
             self.g1.replay()
         else:
             self.g1.replay()
