@@ -74,3 +74,26 @@ def test_workspace_query_covers_both_paths(lib):
     lib.tgp_gemm_f64.restype = ctypes.c_int
     assert lib.tgp_gemm_f64(0, 0, 0, 100, 128, 16, ctypes.c_double(1.0), None, 128, None, 128, ctypes.c_double(0.0), None,
                             128, None) == -4      # m not a multiple of 128: refused before touching the device
+
+
+def test_host_only_queries_of_the_newer_entry_points(lib):
+    """Workspace queries never touch the device: Matern (always the general path), large-M Cholesky, MLP partials."""
+    lib.tgp_workspace_bytes_kernel.restype = ctypes.c_size_t
+    rbf = lib.tgp_workspace_bytes_kernel(8611, 4, 100, 32, 6, 30, 0, 0)
+    mat = lib.tgp_workspace_bytes_kernel(8611, 4, 100, 32, 6, 30, 0, 1)
+    assert rbf == lib.tgp_workspace_bytes(8611, 4, 100, 32, 6, 30, 0) and mat > rbf
+    lib.tgp_cholesky_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.tgp_cholesky_workspace_bytes(100) == 0 and lib.tgp_cholesky_workspace_bytes(1000) > 8 * 1024 * 1024
+    from tgp.pytorch_amd import lib as L
+    from tgp.pytorch_amd import ops
+    spec = ops.MlpSpec(4, 50, 2, 6, act="relu", drop_p=0.25, seed=0)
+    assert spec.weights_per_net == 4 * 50 + 50 + 50 * 50 + 50 + 50 + 1 == 2851       # 6 nets of 4 -> 50 -> 50 -> 1 (SURVEY a12)
+    lib.tgp_mlp_workspace_bytes.restype = ctypes.c_size_t
+    lib.tgp_mlp_workspace_bytes.argtypes = [ctypes.POINTER(L.TgpMlp)]
+    nb = lib.tgp_mlp_workspace_bytes(spec.struct(8611, True))
+    assert nb >= 68 * 6 * 2851 * 8                                                   # one partial per (row block, net)
+    assert spec.lds_bytes() < 160 * 1024
+    # the dropout mask restated on the host: deterministic, keeps ~1-p, changes with the step
+    m1, m2 = ops.mlp_keep_mask(7, 3, 0, 1, 2000, 50, 0.25), ops.mlp_keep_mask(7, 3, 0, 1, 2000, 50, 0.25)
+    assert (m1 == m2).all() and abs(m1.mean() - 0.75) < 0.01
+    assert (ops.mlp_keep_mask(7, 4, 0, 1, 2000, 50, 0.25) != m1).mean() > 0.2
