@@ -59,8 +59,8 @@ def rows_kernel_flops(w):
 
 
 def make_problem(w, seed):
-    from oracle import tgp_oracle as orc          # test infrastructure: only used to BUILD the synthetic inputs
-    return orc.synthetic_problem(w["N"], w["D"], w["M"], seed=seed, flow=w["flow"], S=w["S"])
+    from tgp.pytorch_amd.synthetic import synthetic_problem
+    return synthetic_problem(w["N"], w["D"], w["M"], seed=seed, flow=w["flow"], S=w["S"])
 
 
 def make_mlp(w, seed):

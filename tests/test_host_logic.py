@@ -105,3 +105,32 @@ def test_cpu_tensors_are_rejected_loudly():
     m = build(None)
     with pytest.raises(L.TgpError):
         m.ELBO(torch.randn(5, 4), torch.randn(5, 1))
+
+
+def _same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    if isinstance(a, torch.Tensor):
+        return a.dtype == b.dtype and torch.equal(a, b)
+    if isinstance(a, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    return a == b
+
+
+@pytest.mark.parametrize("flow", [None, "sal2", "idsal3", "tanh3x2", "tanh5x6"])
+@pytest.mark.parametrize("perturb", [True, False])
+def test_product_generator_draws_what_the_oracle_generator_draws(flow, perturb):
+    """bench.py builds its inputs with tgp.pytorch_amd.synthetic (product code, no oracle import); the parity tests
+    build theirs with the oracle's generator.  Same seeds -> the same bits, also under a float32 default dtype."""
+    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd.synthetic import synthetic_problem
+    old = torch.get_default_dtype()
+    try:
+        torch.set_default_dtype(torch.float32)
+        mine = synthetic_problem(257, 4, 19, seed=5, flow=flow, S=20, perturb=perturb)
+    finally:
+        torch.set_default_dtype(old)
+    ref = orc.synthetic_problem(257, 4, 19, seed=5, flow=flow, S=20, perturb=perturb)
+    assert _same(ref, mine)
