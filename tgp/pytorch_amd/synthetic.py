@@ -1,6 +1,6 @@
 """Seeded synthetic workloads of the dataset shapes main.py trains on: what bench.py feeds the
-engine and what a user without the UCI files can train on.  Product code: it does not touch oracle/ (the test
-suite checks that the oracle's own generator draws the same numbers, tests/test_host_logic.py)."""
+engine and what a user without the UCI files can train on.  Product code, self-contained: the parity tests'
+own generator is held to the same draws by tests/test_host_logic.py."""
 import math
 
 import numpy as np
