@@ -8,6 +8,7 @@
 // everywhere below: accumulator register r of a 16x16 tile IS the B operand of k-step r of a product
 // that contracts over the tile's ROW index -- GEMM chains need no LDS round trip.
 #pragma once
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../../include/tgp_hip.h"
@@ -192,27 +193,133 @@ __device__ __forceinline__ double rcp_fast(double x) {
   return y;
 }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
+// ---- N independent evaluations written STAGE BY STAGE.  The row kernel runs one wave per SIMD, so the only latency
+// hiding the f64 pipe gets is independent instructions of the same wave; unrolled node-by-node the chains below were
+// emitted back to back (hipcc keeps source order inside a block: ~9.5 cycles per instruction measured instead of 4).
+// Same operations in the same order per element as the scalar functions: bitwise the same results. ----
+#define TGP_EACH(u, N) _Pragma("unroll") for (int u = 0; u < (N); ++u)
+template <int N>
+__device__ __forceinline__ void exp_fast_n(double (&x)[N]) {
+  double k[N], r[N], r2[N], r4[N], r8[N], p01[N], p23[N], p45[N], p67[N], p89[N], pab[N], pcd[N];
+  TGP_EACH(u, N) x[u] = fmin(fmax(x[u], -745.0), 709.0);
+  TGP_EACH(u, N) k[u] = rint(x[u] * 1.4426950408889634074);
+  TGP_EACH(u, N) r[u] = fma(-k[u], 6.93147180369123816490e-01, x[u]);
+  TGP_EACH(u, N) r[u] = fma(-k[u], 1.90821492927058770002e-10, r[u]);
+  TGP_EACH(u, N) r2[u] = r[u] * r[u];
+  TGP_EACH(u, N) p01[u] = 1.0 + r[u];
+  TGP_EACH(u, N) p23[u] = fma(r[u], 1.0 / 6.0, 0.5);
+  TGP_EACH(u, N) p45[u] = fma(r[u], 1.0 / 120.0, 1.0 / 24.0);
+  TGP_EACH(u, N) p67[u] = fma(r[u], 1.0 / 5040.0, 1.0 / 720.0);
+  TGP_EACH(u, N) p89[u] = fma(r[u], 1.0 / 362880.0, 1.0 / 40320.0);
+  TGP_EACH(u, N) pab[u] = fma(r[u], 1.0 / 39916800.0, 1.0 / 3628800.0);
+  TGP_EACH(u, N) pcd[u] = fma(r[u], 1.0 / 6227020800.0, 1.0 / 479001600.0);
+  TGP_EACH(u, N) r4[u] = r2[u] * r2[u];
+  TGP_EACH(u, N) p01[u] = fma(p23[u], r2[u], p01[u]);   // q0
+  TGP_EACH(u, N) p45[u] = fma(p67[u], r2[u], p45[u]);   // q1
+  TGP_EACH(u, N) p89[u] = fma(pab[u], r2[u], p89[u]);   // q2
+  TGP_EACH(u, N) r8[u] = r4[u] * r4[u];
+  TGP_EACH(u, N) p01[u] = fma(p45[u], r4[u], p01[u]);   // s0
+  TGP_EACH(u, N) p89[u] = fma(pcd[u], r4[u], p89[u]);   // s1
+  TGP_EACH(u, N) x[u] = ldexp(fma(p89[u], r8[u], p01[u]), (int)k[u]);
 }
+template <int N>
+__device__ __forceinline__ void rcp_fast_n(double (&x)[N]) {
+  double y[N];
+  TGP_EACH(u, N) y[u] = __builtin_amdgcn_rcp(x[u]);
+  TGP_EACH(u, N) y[u] = fma(fma(-x[u], y[u], 1.0), y[u], y[u]);
+  TGP_EACH(u, N) x[u] = fma(fma(-x[u], y[u], 1.0), y[u], y[u]);
+}
+template <int N>
+__device__ __forceinline__ void rsqrt_nr_fwd_n(const double (&d)[N], double (&y)[N]) {
+  TGP_EACH(u, N) y[u] = __builtin_amdgcn_rsq(d[u]);
+  TGP_EACH(u, N) y[u] = y[u] * fma(-(0.5 * d[u]) * y[u], y[u], 1.5);
+  TGP_EACH(u, N) y[u] = y[u] * fma(-(0.5 * d[u]) * y[u], y[u], 1.5);
+}
+template <int N>
+__device__ __forceinline__ void log_fast_n(double (&x)[N]) {
+  double m[N], den[N], y[N], num[N], s_[N], z[N], z2[N], z4[N], p01[N], p23[N], p45[N], p67[N], ed[N];
+  TGP_EACH(u, N) {
+    m[u] = __builtin_amdgcn_frexp_mant(x[u]);
+    int e = __builtin_amdgcn_frexp_exp(x[u]);
+    const bool lo = m[u] < 0.70710678118654752440;
+    m[u] = lo ? m[u] + m[u] : m[u];
+    e = lo ? e - 1 : e;
+    ed[u] = (double)e;
+  }
+  TGP_EACH(u, N) den[u] = m[u] + 1.0;
+  TGP_EACH(u, N) num[u] = m[u] - 1.0;
+  TGP_EACH(u, N) y[u] = __builtin_amdgcn_rcp(den[u]);
+  TGP_EACH(u, N) y[u] = fma(fma(-den[u], y[u], 1.0), y[u], y[u]);
+  TGP_EACH(u, N) y[u] = fma(fma(-den[u], y[u], 1.0), y[u], y[u]);
+  TGP_EACH(u, N) s_[u] = num[u] * y[u];
+  TGP_EACH(u, N) s_[u] = fma(fma(-den[u], s_[u], num[u]), y[u], s_[u]);
+  TGP_EACH(u, N) z[u] = s_[u] * s_[u];
+  TGP_EACH(u, N) z2[u] = z[u] * z[u];
+  TGP_EACH(u, N) p01[u] = fma(z[u], 2.0 / 5.0, 2.0 / 3.0);
+  TGP_EACH(u, N) p23[u] = fma(z[u], 2.0 / 9.0, 2.0 / 7.0);
+  TGP_EACH(u, N) p45[u] = fma(z[u], 2.0 / 13.0, 2.0 / 11.0);
+  TGP_EACH(u, N) p67[u] = fma(z[u], 2.0 / 17.0, 2.0 / 15.0);
+  TGP_EACH(u, N) z4[u] = z2[u] * z2[u];
+  TGP_EACH(u, N) p01[u] = fma(p23[u], z2[u], p01[u]);  // q0
+  TGP_EACH(u, N) p45[u] = fma(p67[u], z2[u], p45[u]);  // q1
+  TGP_EACH(u, N) p45[u] = fma(2.0 / 19.0, z4[u], p45[u]);
+  TGP_EACH(u, N) p01[u] = fma(p45[u], z4[u], p01[u]);  // P
+  TGP_EACH(u, N) p01[u] = fma(s_[u] * z[u], p01[u], s_[u] + s_[u]);  // log m
+  TGP_EACH(u, N) x[u] = fma(ed[u], 6.93147180369123816490e-01, fma(ed[u], 1.90821492927058770002e-10, p01[u]));
+}
+
 // sum over the four 16-lane groups (lanes l, l^16, l^32, l^48): every lane gets the total
-__device__ __forceinline__ double quad_sum(double x) {
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+// (gfx950 v_permlane16_swap / v_permlane32_swap: VALU lane exchanges, no trip through the LDS crossbar.  With both
+//  operands = x the pair returned is {x of the even rows / low half, x of the odd rows / high half} in every lane.)
+__device__ __forceinline__ double xor_sum16(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xor_sum32(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double quad_sum(double x) { return xor_sum32(xor_sum16(x)); }
+// x[l] + x[(l + R) % 16 within its row of 16 lanes] on DPP (row_ror:R); equals x[l] + x[l ^ R] once x is 2R-periodic
+template <int R>
+__device__ __forceinline__ double ror_sum(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, 0x120 + R, 0xf, 0xf, false);
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, 0x120 + R, 0xf, 0xf, false);
+  return x + __hiloint2double(h2, l2);
+}
+// butterfly sum over the 64 lanes in the order xor 32, 16, 8, 4, 2, 1 (every lane gets the total), without LDS traffic
+__device__ __forceinline__ double wave_sum(double x) {
+  x = xor_sum16(xor_sum32(x));
+  return ror_sum<1>(ror_sum<2>(ror_sum<4>(ror_sum<8>(x))));
 }
 
 // ---------------------------------------------------------------------------------------------------
 // one-wave 16x16 Cholesky + triangular inverse (the serial core of both blocked factorisations)
 // ---------------------------------------------------------------------------------------------------
-// uniform broadcast of lane `src`'s double (src compile-time constant after unrolling)
-__device__ __forceinline__ double bcast_lane(double x, int src) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, src);
-  hi = __builtin_amdgcn_readlane(hi, src);
-  return __hiloint2double(hi, lo);
+// Broadcast of lane `src` OF EACH ROW OF 16 LANES to that row (src a constant after unrolling): one v_mov_b64_dpp
+// row_newbcast instead of two v_readlane_b32 -- the readlanes were half the instructions of the tile factorisation,
+// which is bound by instruction issue, not by its dependency chain (tools/probes/potrf_rate.hip).  The callers give
+// all four rows of the wave the same data (lane & 15), so a per-row broadcast is a wave-wide one.
+// (measured, one 16x16 tile: 7059 cycles with readlanes, 4569 with this; folding the broadcast into v_fmac_f64_dpp by
+//  hand needs an s_nop per instruction for the DPP read hazard and came out slower, 5435)
+template <int K>
+__device__ __forceinline__ double bcast_row_k(double x) {
+  return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + K, 0xf, 0xf, true);
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}) -- the DPP control
+// word is an immediate, so the lane index has to be a constant expression (a `#pragma unroll` index is not one)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
 // 1/sqrt(d) from the hardware estimate v_rsq_f64 plus two Newton steps (y <- y (1.5 - 0.5 d y^2)): the diagonal
@@ -234,23 +341,32 @@ __device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], i
   // formed inside step k: its dot product is independent of the pivot's rsqrt/Newton chain and of the rank-1 update,
   // and the fully unrolled code lets the scheduler interleave the two dependency chains (the factorisation alone
   // sets the latency; the inverse rides in its shadow).
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double d = bcast_lane(a[k], k);
-    if (!(d > 0.0) && bad == 0) bad = k + 1;  // uniform; also catches NaN
+  static_for<16>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double d = bcast_row_k<k>(a[k]);
+    if (!(d > 0.0) && bad == 0) bad = k + 1;  // the same in every lane; also catches NaN
     const double rinv = rsqrt_nr(d);
     // x_k = -(sum_{m<k} L_km x_m) / L_kk for column `lane` (two partial sums halve the dependent-add chain)
     double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int m = 0; m < k; m += 2) {
-      s0 = fma(bcast_lane(a[m], k), x[m], s0);
-      if (m + 1 < k) s1 = fma(bcast_lane(a[m + 1], k), x[m + 1], s1);
-    }
+    static_for<16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (m < k) {
+        if constexpr ((m & 1) == 0) s0 = fma(bcast_row_k<k>(a[m]), x[m], s0);
+        else s1 = fma(bcast_row_k<k>(a[m]), x[m], s1);
+      }
+    });
     x[k] = (lane == k) ? rinv : (lane < k ? -(s0 + s1) * rinv : 0.0);
     a[k] = (lane == k) ? d * rinv : a[k] * rinv;  // column k of L (rows >= k meaningful)
-#pragma unroll
-    for (int j = k + 1; j < 16; ++j) a[j] = fma(-a[k], bcast_lane(a[k], j), a[j]);  // a_ij -= L_ik L_jk (rows i >= j)
-  }
+    static_for<16>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j > k) {
+        a[j] = fma(-a[k], bcast_row_k<j>(a[k]), a[j]);  // a_ij -= L_ik L_jk (rows i >= j)
+        // the update is DONE here: without the pin hipcc sinks it to the step that consumes a[j] and keeps the
+        // broadcast alive until then -- 15 live doubles per pivot, 246 VGPRs, spills in the callers
+        asm volatile("" : "+v"(a[j]));
+      }
+    });
+  });
   return bad;
 }
 
@@ -317,7 +433,25 @@ struct FlowDev {
   int nblk;
   const double* tp;
   const double* tg;
+  const double* ti = nullptr;  // optional: 1 / tp[i] (rcp_fast) for every i, prepared once by the caller
 };
+// Block descriptor b of an LDS-resident program (16-byte aligned, 4 x int32 per block) in one read.  The store-mode
+// sweeps request descriptor b+1 (b-1) BEFORE working on block b: with one wave per SIMD an un-prefetched descriptor
+// costs a full LDS round trip per block.
+struct FlowBlk { int kind, K, poff, flags; };
+__device__ __forceinline__ FlowBlk flow_blk(const int32_t* prog, int b) {
+  const int4 v = *reinterpret_cast<const int4*>(prog + 4 * b);
+  return FlowBlk{v.x, v.y, v.z, v.w};
+}
+// 1 / tp[i]: from the caller's table when there is one (the row kernel: one reciprocal chain less per tanh step)
+__device__ __forceinline__ double flow_rcp_param(const FlowDev& F, int i) {
+  return F.ti != nullptr ? F.ti[i] : rcp_fast(F.tp[i]);
+}
+// accumulator update in LDS without the read round trip of `*p += v` (ds_add_f64; one wave per SIMD has nothing to
+// hide that latency with).  Each address is only ever touched by one lane: the sum order stays fixed.
+__device__ __forceinline__ void lds_acc(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // asinh exactly as the reference writes it (flow.py:904-905)
 __device__ __forceinline__ double asinh_ref(double f) { return log(f + sqrt(f * f + 1.0)); }
@@ -382,8 +516,10 @@ template <int NB>
 __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], const double* __restrict__ rp,
                                           double* stack, int sstride) {
   int sl = 0;
+  FlowBlk nx = flow_blk(F.prog, 0);
   for (int b = 0; b < F.nblk; ++b) {
-    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const int kind = nx.kind, K = nx.K, poff = nx.poff, flags = nx.flags;
+    nx = flow_blk(F.prog, b + 1 < F.nblk ? b + 1 : b);
     const bool pr = flags & TGP_FLAG_PER_ROW;
     if (kind == TGP_FLOW_AFFINE) {
       double a = pr ? rp[poff] : F.tp[poff];
@@ -400,20 +536,24 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
       if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
       const bool addf = flags & TGP_FLAG_ADD_F0;
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        // sqrt(f^2+1) and its reciprocal from one v_rsq_f64 + Newton (1/sf is needed anyway); asinh keeps the
-        // reference's log(f + sqrt(f^2+1)) form (flow.py:904-905) on the short-chain log
-        const double q1 = f[u] * f[u] + 1.0;
-        const double isf = rsqrt_nr_fwd(q1);
-        double sf = q1 * isf;
-        sf = fma(fma(-sf, sf, q1), 0.5 * isf, sf);
-        const double uu = log_fast(f[u] + sf);
-        const double e = exp_fast(bb * uu - a), ei = rcp_fast(e);
-        const double ch = 0.5 * (e + ei);
-        double g = 0.5 * (e - ei), gp = bb * ch * isf;
+      // sqrt(f^2+1) and its reciprocal from one v_rsq_f64 + Newton (1/sf is needed anyway); asinh keeps the
+      // reference's log(f + sqrt(f^2+1)) form (flow.py:904-905) on the short-chain log.  Stage by stage over the nodes.
+      double q1[NB], isf[NB], sf[NB], uu[NB], e[NB], ei[NB];
+      TGP_EACH(u, NB) q1[u] = f[u] * f[u] + 1.0;
+      rsqrt_nr_fwd_n<NB>(q1, isf);
+      TGP_EACH(u, NB) sf[u] = q1[u] * isf[u];
+      TGP_EACH(u, NB) sf[u] = fma(fma(-sf[u], sf[u], q1[u]), 0.5 * isf[u], sf[u]);
+      TGP_EACH(u, NB) uu[u] = f[u] + sf[u];
+      log_fast_n<NB>(uu);
+      TGP_EACH(u, NB) e[u] = bb * uu[u] - a;
+      exp_fast_n<NB>(e);
+      TGP_EACH(u, NB) ei[u] = e[u];
+      rcp_fast_n<NB>(ei);
+      TGP_EACH(u, NB) {
+        const double ch = 0.5 * (e[u] + ei[u]);
+        double g = 0.5 * (e[u] - ei[u]), gp = bb * ch * isf[u];
         if (addf) { g += f[u]; gp += 1.0; }
-        stack[((sl + 0) * NB + u) * sstride] = uu;
+        stack[((sl + 0) * NB + u) * sstride] = uu[u];
         stack[((sl + 1) * NB + u) * sstride] = ch;
         stack[((sl + 2) * NB + u) * sstride] = gp;
         f[u] = g;
@@ -429,10 +569,15 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       }
       for (int k = 0; k < K; ++k) {
         const double a = F.tp[poff + 4 * k], bt = F.tp[poff + 4 * k + 1], c = F.tp[poff + 4 * k + 2],
-                     idt = rcp_fast(F.tp[poff + 4 * k + 3]);
+                     idt = flow_rcp_param(F, poff + 4 * k + 3);
+        double e[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const double th = 1.0 - 2.0 * rcp_fast(exp_fast(2.0 * (f[u] - c) * idt) + 1.0);
+        for (int u = 0; u < NB; ++u) e[u] = 2.0 * (f[u] - c) * idt;
+        exp_fast_n<NB>(e);
+        TGP_EACH(u, NB) e[u] += 1.0;
+        rcp_fast_n<NB>(e);
+        TGP_EACH(u, NB) {
+          const double th = 1.0 - 2.0 * e[u];
           stack[((sl + 1 + k) * NB + u) * sstride] = th;
           g[u] += a + bt * th;
         }
@@ -452,13 +597,18 @@ template <int NB>
 __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], const double* __restrict__ rp,
                                            const double* stack, int sstride, int nslots, double* accq, int qstride,
                                            bool qlead, double* accr, int rstride) {
+  // (accq / accr live in LDS: lds_acc.  Every block reads all its LDS operands -- parameters AND stack slots -- before
+  //  the first use: one exposed LDS round trip per block step instead of three or four.)
   int sl = nslots;
+  FlowBlk nx = flow_blk(F.prog, F.nblk - 1);
   for (int b = F.nblk - 1; b >= 0; --b) {
-    const int kind = F.prog[4 * b], K = F.prog[4 * b + 1], poff = F.prog[4 * b + 2], flags = F.prog[4 * b + 3];
+    const int kind = nx.kind, K = nx.K, poff = nx.poff, flags = nx.flags;
+    nx = flow_blk(F.prog, b > 0 ? b - 1 : 0);
     const bool pr = flags & TGP_FLAG_PER_ROW;
     if (kind == TGP_FLOW_AFFINE) {
       sl -= 1;
-      double a, fa;
+      double a, fa, fin[NB];
+      TGP_EACH(u, NB) fin[u] = stack[(sl * NB + u) * sstride];
       if (pr) {
         a = rp[poff]; fa = 1.0;
         if (flags & TGP_FLAG_RESTRICT) { fa = sigmoid_d(a); a = softplus_d(a); }
@@ -466,22 +616,27 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
         a = F.tp[poff]; fa = F.tg[poff];
       }
       double pa = 0.0, pb = 0.0;
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        pa += c[u] * stack[(sl * NB + u) * sstride];
+      TGP_EACH(u, NB) {
+        pa += c[u] * fin[u];
         pb += c[u];
         c[u] *= a;
       }
       pa *= fa;
       if (pr) {
-        accr[(poff + 0) * rstride] += pa;
-        accr[(poff + 1) * rstride] += pb;
+        lds_acc(accr + (poff + 0) * rstride, pa);
+        lds_acc(accr + (poff + 1) * rstride, pb);
       } else {
         pa = quad_sum(pa); pb = quad_sum(pb);
-        if (qlead) { accq[(poff + 0) * qstride] += pa; accq[(poff + 1) * qstride] += pb; }
+        if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
       }
     } else if (kind == TGP_FLOW_SAL) {
       sl -= 3;
+      double uu[NB], ch[NB], gp[NB];
+      TGP_EACH(u, NB) {
+        uu[u] = stack[((sl + 0) * NB + u) * sstride];
+        ch[u] = stack[((sl + 1) * NB + u) * sstride];
+        gp[u] = stack[((sl + 2) * NB + u) * sstride];
+      }
       double fb = 1.0;
       if (pr) {
         if (flags & TGP_FLAG_RESTRICT) fb = sigmoid_d(rp[poff + 1]);
@@ -489,53 +644,54 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
         fb = F.tg[poff + 1];
       }
       double pa = 0.0, pb = 0.0;
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const double uu = stack[((sl + 0) * NB + u) * sstride], ch = stack[((sl + 1) * NB + u) * sstride];
-        pa -= c[u] * ch;
-        pb += c[u] * uu * ch;
-        c[u] *= stack[((sl + 2) * NB + u) * sstride];
+      TGP_EACH(u, NB) {
+        pa -= c[u] * ch[u];
+        pb += c[u] * uu[u] * ch[u];
+        c[u] *= gp[u];
       }
       pb *= fb;
       if (pr) {
-        accr[(poff + 0) * rstride] += pa;
-        accr[(poff + 1) * rstride] += pb;
+        lds_acc(accr + (poff + 0) * rstride, pa);
+        lds_acc(accr + (poff + 1) * rstride, pb);
       } else {
         pa = quad_sum(pa); pb = quad_sum(pb);
-        if (qlead) { accq[(poff + 0) * qstride] += pa; accq[(poff + 1) * qstride] += pb; }
+        if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
       }
     } else {
       sl -= 1 + K;
       double gp[NB], fin[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
+      TGP_EACH(u, NB) {
         gp[u] = (flags & TGP_FLAG_ADD_F0) ? 1.0 : 0.0;
         fin[u] = stack[(sl * NB + u) * sstride];
       }
       for (int k = 0; k < K; ++k) {
         const int o = poff + 4 * k;
-        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = rcp_fast(F.tp[o + 3]);
+        double th[NB];
+        TGP_EACH(u, NB) th[u] = stack[((sl + 1 + k) * NB + u) * sstride];
+        const double bt = F.tp[o + 1], cc = F.tp[o + 2], idt = flow_rcp_param(F, o + 3), g1 = F.tg[o + 1], g3 = F.tg[o + 3];
         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const double th = stack[((sl + 1 + k) * NB + u) * sstride];
-          const double se = bt * (1.0 - th * th) * idt;  // d/df of this step
+        double se[NB], cs[NB], dz[NB];
+        TGP_EACH(u, NB) se[u] = 1.0 - th[u] * th[u];
+        TGP_EACH(u, NB) dz[u] = fin[u] - cc;
+        TGP_EACH(u, NB) se[u] = bt * se[u] * idt;  // d/df of this step
+        TGP_EACH(u, NB) cs[u] = c[u] * se[u];
+        TGP_EACH(u, NB) dz[u] = cs[u] * dz[u] * idt;
+        TGP_EACH(u, NB) {
           p0 += c[u];
-          p1 += c[u] * th;
-          p2 -= c[u] * se;
-          p3 -= c[u] * se * (fin[u] - cc) * idt;
-          gp[u] += se;
+          p1 += c[u] * th[u];
+          p2 -= cs[u];
+          p3 -= dz[u];
+          gp[u] += se[u];
         }
-        p0 = quad_sum(p0); p1 = quad_sum(p1 * F.tg[o + 1]); p2 = quad_sum(p2); p3 = quad_sum(p3 * F.tg[o + 3]);
+        p0 = quad_sum(p0); p1 = quad_sum(p1 * g1); p2 = quad_sum(p2); p3 = quad_sum(p3 * g3);
         if (qlead) {
-          accq[(o + 0) * qstride] += p0;
-          accq[(o + 1) * qstride] += p1;
-          accq[(o + 2) * qstride] += p2;
-          accq[(o + 3) * qstride] += p3;
+          lds_acc(accq + (o + 0) * qstride, p0);
+          lds_acc(accq + (o + 1) * qstride, p1);
+          lds_acc(accq + (o + 2) * qstride, p2);
+          lds_acc(accq + (o + 3) * qstride, p3);
         }
       }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) c[u] *= gp[u];
+      TGP_EACH(u, NB) c[u] *= gp[u];
     }
   }
 }

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < 4; ++i) ws[p.hdr + H_STAMP + 12 + i] = tph[i];
     ws[p.hdr + H_STAMP + 16] = (double)(tn_ - tlast);
-    for (int i = 1; i < 5; ++i) ws[p.hdr + H_STAMP + 18 + i] = twv[i];  // wave-0 chain, shader cycles summed over block columns
+    for (int i = 1; i < 5; ++i) ws[p.hdr + H_STAMP + 18 + i] = twv[i];
+
   }
 #endif
 }

@@ -37,7 +37,7 @@ struct RowArgs {
 
 // LDS carve-up (offsets in doubles)
 struct RowLds {
-  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, xs, wn, stack, acc, red, prog, total;
+  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, ti, xs, wn, stack, acc, red, prog, total;
 };
 
 // mode: 0 = moments only; 1 = training, TGP_NODES_IN_FLIGHT quadrature nodes in flight per lane; 2 = training, one
@@ -52,6 +52,7 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
   L.mv = take(p.MP);
   L.tp = take(p.P + 1);
   L.tg = take(p.P + 1);
+  L.ti = take(p.P + 1);
   L.xs = take(p.S + 1);
   L.wn = take(p.S + 1);
   L.prog = take((size_t)2 * p.nblk + 2);  // 4 int32 per block
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   double* mv = sm + L.mv;
   double* tpL = sm + L.tp;
   double* tgL = sm + L.tg;
+  double* tiL = sm + L.ti;
   double* xsL = sm + L.xs;
   double* wnL = sm + L.wn;
   int32_t* progL = reinterpret_cast<int32_t*>(sm + L.prog);
@@ -163,6 +165,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   TGP_STAMP(a.ws, p, 0);
+#ifdef TGP_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 11] = (double)clock64();
+#endif
+  // this lane's data row and the step header: requested with the first staging loads (they need nothing from LDS;
+  // behind the staging barrier they cost a memory round trip of their own)
+  const int n = blockIdx.x * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
+  const bool valid = n < N;
+  const int nc = valid ? n : N - 1;
+  double xraw[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) xraw[d] = d < D ? a.X[(size_t)nc * D + d] : 0.0;
+  const double y = TRAIN ? a.Y[nc] : 0.0;
+  const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
   // ---- stage the small shared operands ----
   // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
   //  paid one L2 round trip each)
@@ -182,9 +197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (tid < MP) mv[tid] = mv0;
     if (tid < 16) ils[tid] = il0;
     if (fl) {
-      if (tid < P) { tpL[tid] = tp0; tgL[tid] = tg0; }
+      if (tid < P) { tpL[tid] = tp0; tgL[tid] = tg0; tiL[tid] = rcp_fast(tp0); }
       if (tid < p.S) { xsL[tid] = xs0; wnL[tid] = wn0; }
-      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; }
+      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; tiL[i] = rcp_fast(tpL[i]); }
       for (int i = tid + 256; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
       for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
     }
@@ -196,14 +211,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
 
   TGP_STAMP(a.ws, p, 1);
-  const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
-  const int n = blockIdx.x * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
-  const bool valid = n < N;
-  const int nc = valid ? n : N - 1;
-
   double x[DP];
 #pragma unroll
-  for (int d = 0; d < DP; ++d) x[d] = d < D ? a.X[(size_t)nc * D + d] * ils[d] : 0.0;
+  for (int d = 0; d < DP; ++d) x[d] = d < D ? xraw[d] * ils[d] : 0.0;
 
   // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
   //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
@@ -243,16 +253,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- K tile in B-operand layout: Kr[ks] = K[m = 4 ks + q][row nl] ----
   double Kr[4 * MT];
+  // (four tiles' worth of exponentials at a time, stage by stage: independent chains for the single wave of this SIMD;
+  //  padding rows mm >= M are computed from the zero-filled Zs rows and multiplied by 0)
 #pragma unroll
-  for (int ks = 0; ks < 4 * MT; ++ks) {
-    const int mm = 4 * ks + q;
-    double d2 = 0.0;
+  for (int k0 = 0; k0 < 4 * MT; k0 += 4) {
+    double e[4];
+    TGP_EACH(u, 4) {
+      const int mm = 4 * (k0 + u) + q;
+      double d2 = 0.0;
 #pragma unroll
-    for (int d = 0; d < DP; ++d) {
-      const double t = x[d] - zs[mm * DP + d];
-      d2 += t * t;
+      for (int d = 0; d < DP; ++d) {
+        const double t = x[d] - zs[mm * DP + d];
+        d2 += t * t;
+      }
+      e[u] = -0.5 * d2;
     }
-    Kr[ks] = mm < M ? s2 * exp_fast(-0.5 * d2) : 0.0;
+    exp_fast_n<4>(e);
+    // (a masked multiplier, not a select: hipcc turns `cond ? s2 * e : 0` back into a branch around the whole chain)
+    TGP_EACH(u, 4) Kr[k0 + u] = (4 * (k0 + u) + q < M ? s2 : 0.0) * e[u];
   }
 
   TGP_STAMP(a.ws, p, 2);
@@ -295,7 +313,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   TGP_STAMP(a.ws, p, 5);
   // ---- expected log-likelihood and its adjoints ----
   double mub = 0.0, vb = 0.0, ellp = 0.0, etap = 0.0;
-  const double y = a.Y[nc];
   if (p.lik == TGP_LIK_GAUSS) {
     // GaussianLinearMean.expected_log_prob (likelihoods/GaussianLinearMean.py:81-87)
     const double r = y - mu;
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } else {
     // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): this lane takes the
     // quadrature nodes s = q, q+4, q+8, ... of its row
-    FlowDev F{progL, p.nblk, tpL, tgL};
+    FlowDev F{progL, p.nblk, tpL, tgL, tiL};
     const double sq = sqrt(2.0 * v);
     const double* rp = a.rowp != nullptr ? a.rowp + (size_t)nc * RP : nullptr;
     double cm = 0.0, cv = 0.0;
@@ -489,6 +506,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
   }
   TGP_STAMP(a.ws, p, 10);
+#ifdef TGP_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 23] = (double)clock64();
+#endif
   for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
   if (a.g_rowp != nullptr && q == 0 && valid) {
     const double* rbase = acc + (size_t)P * 64;
