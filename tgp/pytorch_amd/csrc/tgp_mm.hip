@@ -249,6 +249,30 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // psd_safe_cholesky on the device (dsp/utils.py:256-269): when md.jitter_ladder > 0 a failed factorisation is
   // repeated with jitter_ladder * 10^i, i = 0..2, added to the diagonal, without the host; status[2] reports the
   // level that succeeded (0 = none needed) so that the caller can issue the reference's warning lazily.
+  // Write-out of lower tile (ti, tj): L, J and the J^T tile (tj, ti), by one wave, 128-byte row segments.  A single CU
+  // stores at ~30-50 GB/s, so block 0 writes only what is non-zero (the structurally-zero tiles are written by the
+  // otherwise idle tile blocks of this launch) and it does so DURING the factorisation: everything in tile row ti is
+  // final after iteration ti+1, so waves 1..7 store row j-2 at the end of iteration j, in the shadow of wave 0's
+  // chain; only the last row is left for after the loop.  (A retry of the jitter ladder simply stores again.)
+  auto write_tile = [&](int ti, int tj) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      double l, jv;
+      if (ti == tj) {
+        l = cc <= rr ? A[rr * LD + cc] : 0.0;
+        jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
+      } else {
+        l = A[rr * LD + cc];
+        jv = A[cc * LD + rr];
+      }
+      ws[p.L + (size_t)rr * MP + cc] = l;
+      ws[p.J + (size_t)rr * MP + cc] = jv;
+      // J^T tile (tj, ti), rows = cols of the J tile: element [16 tj + q+4u][16 ti + r] = J[16 ti + r][16 tj + q+4u]
+      const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
+      ws[p.JT + (size_t)rt * MP + ct] = (ti == tj) ? Dt[ti * 256 + (ct & 15) * 16 + (rt & 15)] : A[rt * LD + ct];
+    }
+  };
   int attempt = 0;
   for (;; ++attempt) {
   for (int j = 0; j <= MT; ++j) {
@@ -304,6 +328,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       }
       if (j < MT) fill_block(j, 16 * (j + 1), MP);                      // rest of block j: read from iteration j+1 on
       if (j + 1 < MT) fill_block(j + 1, 16 * (j + 1), 16 * (j + 2));     // diagonal tile (j+1, j+1): wave 0, iteration j+1
+      if (j >= 2)
+        for (int tj = wave - 1; tj <= j - 2; tj += PREP_THREADS / 64 - 1) write_tile(j - 2, tj);
     }
     __syncthreads();
     PSTAMP(j < 4 ? j : 3);
@@ -316,31 +342,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   jit = md.jitter + md.jitter_ladder * (attempt == 0 ? 1.0 : (attempt == 1 ? 10.0 : 100.0));
   __syncthreads();
   }
-  // ---- write L, J (lower tiles) and J^T (upper tiles), one wave per tile, 128-byte row segments.  A single CU
-  //      stores at ~30-50 GB/s, so block 0 writes only what is non-zero; the structurally-zero tiles are written
-  //      by the (otherwise idle) tile blocks of this same launch ----
-  for (int t = wave; t < p.ntri; t += PREP_THREADS / 64) {
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      double l, jv;
-      if (ti == tj) {
-        l = cc <= rr ? A[rr * LD + cc] : 0.0;
-        jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
-      } else {
-        l = A[rr * LD + cc];
-        jv = A[cc * LD + rr];
-      }
-      ws[p.L + (size_t)rr * MP + cc] = l;
-      ws[p.J + (size_t)rr * MP + cc] = jv;
-      // J^T tile (tj, ti), rows = cols of the J tile: element [16 tj + q+4u][16 ti + r] = J[16 ti + r][16 tj + q+4u]
-      const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
-      ws[p.JT + (size_t)rt * MP + ct] = (ti == tj) ? Dt[ti * 256 + (ct & 15) * 16 + (rt & 15)] : A[rt * LD + ct];
-    }
-  }
+  // ---- the last tile row (the earlier rows left during the factorisation, see write_tile) ----
+  for (int tj = wave; tj < MT; tj += PREP_THREADS / 64) write_tile(MT - 1, tj);
   if (tid == 0) {
     status[0] = s_info;
     status[1] = s_nan;

@@ -178,6 +178,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int d = 0; d < DP; ++d) xraw[d] = d < D ? a.X[(size_t)nc * D + d] : 0.0;
   const double y = TRAIN ? a.Y[nc] : 0.0;
   const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
+
+  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
+  //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
+  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out.
+  //      Panels are prefetched TWO ahead through two register sets (the early panels feed only 4-8 MFMAs, far less
+  //      than one L2 round trip), and the first two are requested here, at the top of the kernel: the K tile takes
+  //      about 1 us, far less than their round trip.
+  const double* __restrict__ JT = ws + p.JT;
+  const double* __restrict__ Jm = ws + p.J;
+  const double* __restrict__ Lq = ws + p.Lq;
+  const double* __restrict__ LqT = ws + p.LqT;
+  double* pan = tile;  // 2 x (MP x 16)
+  double stg[2][MT];
+  // panel sequence of one phase: pp < MT -> lower-type panel pp of matrix M1 (rows [0, 16(pp+1)));
+  //                              pp >= MT -> upper-type panel pp-MT of matrix M2 (rows [16 (pp-MT), MP))
+  // (row-block u of a panel exists iff u < nb with nb = i+1 (lower) / MT-i (upper): a compile-time predicate once the
+  //  tile loops are unrolled -- a `row < r1` test would cost an exec-mask branch around every load and store)
+  auto issue = [&](const double* __restrict__ M1, const double* __restrict__ M2, int pp, double (&st)[MT]) {
+    const bool lower = pp < MT;
+    const int i = lower ? pp : pp - MT;
+    const double* __restrict__ Mt = (lower ? M1 : M2) + (size_t)((lower ? 0 : 16 * i) + (tid >> 4)) * MP + 16 * i + (tid & 15);
+    const int nb = lower ? i + 1 : MT - i;
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+      if (u < nb) st[u] = Mt[(size_t)16 * u * MP];
+  };
+  auto commit = [&](int pp, const double (&st)[MT]) {
+    const bool lower = pp < MT;
+    const int i = lower ? pp : pp - MT;
+    const int nb = lower ? i + 1 : MT - i;
+    double* buf = pan + (pp & 1) * (MP * 16) + ((lower ? 0 : 16 * i) + (tid >> 4)) * 16 + (tid & 15);
+#pragma unroll
+    for (int u = 0; u < MT; ++u)
+      if (u < nb) buf[16 * u * 16] = st[u];
+  };
+  issue(JT, Lq, 0, stg[0]);
+  if (MT * 2 > 1) issue(JT, Lq, 1, stg[1]);
   // ---- stage the small shared operands ----
   // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
   //  paid one L2 round trip each)
@@ -215,41 +252,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int d = 0; d < DP; ++d) x[d] = d < D ? xraw[d] * ils[d] : 0.0;
 
-  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
-  //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
-  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out.
-  //      Panels are prefetched TWO ahead through two register sets (the early panels feed only 4-8 MFMAs, far less
-  //      than one L2 round trip), and the first two are requested before the K tile is computed.
-  const double* __restrict__ JT = ws + p.JT;
-  const double* __restrict__ Jm = ws + p.J;
-  const double* __restrict__ Lq = ws + p.Lq;
-  const double* __restrict__ LqT = ws + p.LqT;
-  double* pan = tile;  // 2 x (MP x 16)
-  double stg[2][MT];
-  // panel sequence of one phase: pp < MT -> lower-type panel pp of matrix M1 (rows [0, 16(pp+1)));
-  //                              pp >= MT -> upper-type panel pp-MT of matrix M2 (rows [16 (pp-MT), MP))
-  // (row-block u of a panel exists iff u < nb with nb = i+1 (lower) / MT-i (upper): a compile-time predicate once the
-  //  tile loops are unrolled -- a `row < r1` test would cost an exec-mask branch around every load and store)
-  auto issue = [&](const double* __restrict__ M1, const double* __restrict__ M2, int pp, double (&st)[MT]) {
-    const bool lower = pp < MT;
-    const int i = lower ? pp : pp - MT;
-    const double* __restrict__ Mt = (lower ? M1 : M2) + (size_t)((lower ? 0 : 16 * i) + (tid >> 4)) * MP + 16 * i + (tid & 15);
-    const int nb = lower ? i + 1 : MT - i;
-#pragma unroll
-    for (int u = 0; u < MT; ++u)
-      if (u < nb) st[u] = Mt[(size_t)16 * u * MP];
-  };
-  auto commit = [&](int pp, const double (&st)[MT]) {
-    const bool lower = pp < MT;
-    const int i = lower ? pp : pp - MT;
-    const int nb = lower ? i + 1 : MT - i;
-    double* buf = pan + (pp & 1) * (MP * 16) + ((lower ? 0 : 16 * i) + (tid >> 4)) * 16 + (tid & 15);
-#pragma unroll
-    for (int u = 0; u < MT; ++u)
-      if (u < nb) buf[16 * u * 16] = st[u];
-  };
-  issue(JT, Lq, 0, stg[0]);
-  if (MT * 2 > 1) issue(JT, Lq, 1, stg[1]);
 
   // ---- K tile in B-operand layout: Kr[ks] = K[m = 4 ks + q][row nl] ----
   double Kr[4 * MT];
