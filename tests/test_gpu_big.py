@@ -229,10 +229,12 @@ def test_big_step_is_bit_reproducible():
 
 
 def test_big_non_psd_reports_pivot():
-    """Duplicate inducing points make K_MM singular: status[0] is the first failing pivot (LAPACK info), as for M <= 128."""
+    """Duplicate inducing points make K_MM singular: status[0] is the first failing pivot (LAPACK info), as for M <= 128.
+    (Whether a singular pivot comes out <= 0 is a matter of rounding; the last row duplicating the first one does for
+    every seed tried: d = K_00 - fl(sqrt(K_00))^2 - sum of squares, and fl(sqrt 2)^2 > 2.)"""
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(400, 4, 200, seed=7, flow=None, S=8)
-    prob["params"]["Z"][150] = prob["params"]["Z"][20]
+    prob["params"]["Z"][199] = prob["params"]["Z"][0]
     g = dict(prob)
     g.update(program=None)
     from tgp.pytorch_amd import ops
@@ -241,7 +243,7 @@ def test_big_non_psd_reports_pivot():
     out, grads, status, _ = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
                                            p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], 400.0)
     torch.cuda.synchronize()
-    assert int(status[0]) == 151
+    assert int(status[0]) == 200
 
 
 @pytest.mark.parametrize("M", [130, 300, 1000])
@@ -273,7 +275,7 @@ def test_big_jitter_ladder_recovers():
     from tgp.pytorch_amd import ops
     dev = _dev()
     prob = orc.synthetic_problem(400, 4, 200, seed=7, flow=None, S=8)
-    prob["params"]["Z"][150] = prob["params"]["Z"][20]
+    prob["params"]["Z"][199] = prob["params"]["Z"][0]
     p = {k: t.to(dev) for k, t in prob["params"].items()}
     args = (prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"],
             p["log_var_noise"], 400.0)

@@ -104,8 +104,6 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
 // ---------------------------------------------------------------------------------------------------
 // scalar helpers (torch semantics)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double softplus_d(double x) { return x > 20.0 ? x : log1p(exp(x)); }  // F.softplus, threshold 20
-__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
 // exp(x) with a SHORT dependency chain.  A dependent f64 FMA costs ~32 cycles on gfx950 (measured,
 // tools/probes/mfma_rate.hip) and the row kernel runs one wave per SIMD, so the ~25-deep chain of the library exp is
@@ -192,6 +190,17 @@ __device__ __forceinline__ double rcp_fast(double x) {
   y = fma(fma(-x, y, 1.0), y, y);
   return y;
 }
+
+// F.softplus (threshold 20) and sigmoid on the short-chain exp / log above.  The library log1p(exp(x)) is ~250
+// dependent f64 instructions, and the lengthscale transform sits at the very start of k_prep_a's critical chain.
+// log1p(e) = log(u) e / (u - 1), u = 1 + e (exact when u == 1 is handled apart): accurate for tiny e too.
+__device__ __forceinline__ double softplus_d(double x) {
+  if (x > 20.0) return x;
+  const double e = exp_fast(x), u = 1.0 + e;
+  if (u == 1.0) return e;
+  return log_fast(u) * (e * rcp_fast(u - 1.0));
+}
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp_fast(-x)); }
 
 // ---- N independent evaluations written STAGE BY STAGE.  The row kernel runs one wave per SIMD, so the only latency
 // hiding the f64 pipe gets is independent instructions of the same wave; unrolled node-by-node the chains below were
