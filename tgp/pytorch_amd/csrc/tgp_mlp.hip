@@ -24,10 +24,10 @@ namespace tgp {
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-#define MLP_T 128      /* rows per block */
-#define MLP_NT 256     /* threads per block = 4 waves x 32 rows (one block per CU by LDS: all four SIMDs get a wave) */
-#define MLP_RT 2       /* 16-row MFMA column tiles per wave */
-#define MLP_ST 129     /* LDS stride of an activation strip [unit][row] (k-major for the layer products) */
+#define MLP_T 64       /* rows per block */
+#define MLP_NT 256     /* threads per block = 4 waves x 16 rows; the LDS image (81 KB at C4) lets TWO blocks share a CU */
+#define MLP_RT 1      /* 16-row MFMA column tiles per wave */
+#define MLP_ST 65      /* LDS stride of an activation strip [unit][row] (k-major for the layer products) */
 #define MLP_HP 64      /* units padded to four 16-wide MFMA tiles */
 #define MLP_MAXH 64
 #define MLP_MAXL 3
@@ -52,24 +52,40 @@ __device__ __forceinline__ unsigned mlp_thresh(double p) { return (unsigned)(p *
 __device__ __forceinline__ double mlp_act(int act, double z) { return act == 0 ? fmax(z, 0.0) : tanh(z); }
 
 // global -> LDS copy of one hidden layer's weights into the zero-padded [HP][KP] image (+ bias [HP])
+// global -> LDS copy of one hidden layer's weights into the zero-padded [HR][KP] image (+ bias [HR]).
+// (the image has HR = pad4(H) rows, not 64: the MFMA tiles read rows >= HR as zeros through a predicate -- 5 KB
+//  that decide whether two blocks fit a CU.  Requesting all arrays before the first store was tried: the copy is bound
+//  by its index arithmetic, not by the round trips, and it got slower.)
 __device__ __forceinline__ void mlp_stage_layer(const double* __restrict__ src, int H, int nin, int KP, double* Wp, double* bp,
                                                 int tid) {
-  for (int base = 0; base < MLP_HP * KP; base += 8 * MLP_NT) {
+  const int HR = mlp_pad4(H);
+  // (row, column) of element e = tid, tid + NT, ...: one division per thread, then increments (an e / KP, e % KP per
+  // element with a runtime KP was most of the copy's instructions)
+  const int dj = MLP_NT / KP, di = MLP_NT % KP;
+  int j = tid / KP, i = tid % KP;
+  for (int base = 0; base < HR * KP; base += 8 * MLP_NT) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = base + u * MLP_NT + tid, j = e / KP, i = e % KP;
-      v[u] = (e < MLP_HP * KP && j < H && i < nin) ? src[j * nin + i] : 0.0;
+      const int e = base + u * MLP_NT + tid;
+      v[u] = (e < HR * KP && j < H && i < nin) ? src[j * nin + i] : 0.0;
+      j += dj; i += di;
+      if (i >= KP) { i -= KP; ++j; }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = base + u * MLP_NT + tid;
-      if (e < MLP_HP * KP) Wp[e] = v[u];
+      if (e < HR * KP) Wp[e] = v[u];
     }
   }
-  if (tid < MLP_HP) bp[tid] = tid < H ? src[H * nin + tid] : 0.0;
+  if (tid < HR) bp[tid] = tid < H ? src[H * nin + tid] : 0.0;
 }
 
+#ifdef TGP_STAMPS
+#define MSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) mst[i] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
 struct MlpArgs {
   int N, D, H, L, nnets, act, training;
   double p;
@@ -80,19 +96,19 @@ struct MlpArgs {
 };
 
 // LDS image shared by both kernels:
-//   per hidden layer l: Wp_l [64][KP_l] (zero padded), b_l [64] ; output layer wo [64], bo [2]
+//   per hidden layer l: Wp_l [KPH][KP_l] (zero padded), b_l [KPH] ; output layer wo [KPH], bo [2]
 //   a0 [KP_0][ST] ; a_1 .. a_L [KPH][ST]  (KP_0 = pad4(D), KPH = pad4(H); padded units are exact zeros)
 // (offsets are closed-form: an array indexed by the layer would live in scratch memory)
 struct MlpLds {
   int KP0, KPH, L, wo, act0, actl, gos, total;
-  __host__ __device__ int wp(int l) const { return l == 0 ? 0 : MLP_HP * KP0 + MLP_HP + (l - 1) * (MLP_HP * KPH + MLP_HP); }
-  __host__ __device__ int bp(int l) const { return wp(l) + MLP_HP * (l == 0 ? KP0 : KPH); }
+  __host__ __device__ int wp(int l) const { return l == 0 ? 0 : KPH * KP0 + KPH + (l - 1) * (KPH * KPH + KPH); }
+  __host__ __device__ int bp(int l) const { return wp(l) + KPH * (l == 0 ? KP0 : KPH); }
 };
 __host__ __device__ inline MlpLds mlp_lds(int D, int H, int L, bool bwd) {
   MlpLds o;
   o.KP0 = mlp_pad4(D); o.KPH = mlp_pad4(H); o.L = L;
-  int p = o.bp(L - 1) + MLP_HP;
-  o.wo = p; p += MLP_HP + 2;
+  int p = o.bp(L - 1) + o.KPH;
+  o.wo = p; p += o.KPH + 2;
   o.act0 = p; p += o.KP0 * MLP_ST;
   o.actl = p; p += (bwd ? L : (L > 1 ? 2 : 1)) * o.KPH * MLP_ST;
   p = (p + 1) & ~1;
@@ -119,25 +135,15 @@ __device__ __forceinline__ void mlp_layer_mfma(const double* Wp, const double* b
 #pragma unroll
     for (int rt = 0; rt < MLP_RT; ++rt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[rt][rr] = bp[16 * jt + q + 4 * rr];
-    // operands of k-step k0+4 are requested before the four MFMAs of k-step k0 issue (one wave per SIMD: nothing else
-    // would hide the LDS latency)
-    const double* wrow = Wp + (16 * jt + n) * KP + q;
-    const double* brow = ain + q * MLP_ST + 16 * MLP_RT * wave + n;
-    double a = wrow[0], b[MLP_RT];
+      for (int rr = 0; rr < 4; ++rr) acc[rt][rr] = 16 * jt + q + 4 * rr < KPout ? bp[16 * jt + q + 4 * rr] : 0.0;
+    // operands of eight k-steps are requested before their MFMAs (tile_mm_f): a one-deep prefetch made every k-step
+    // wait for an LDS round trip (about 150 cycles per MFMA instead of 64)
+    const bool vj = 16 * jt + n < KPout;   // rows of the weight image beyond pad4(H) do not exist: zeros
+    const double* wrow = Wp + (vj ? 16 * jt + n : 0) * KP + q;
 #pragma unroll
-    for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = brow[16 * rt];
-    for (int k0 = 0; k0 < KP; k0 += 4) {
-      const int kn = k0 + 4 < KP ? k0 + 4 : k0;
-      const double an = wrow[kn];
-      double bn[MLP_RT];
-#pragma unroll
-      for (int rt = 0; rt < MLP_RT; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
-#pragma unroll
-      for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
-      a = an;
-#pragma unroll
-      for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = bn[rt];
+    for (int rt = 0; rt < MLP_RT; ++rt) {
+      const double* brow = ain + q * MLP_ST + 16 * MLP_RT * wave + 16 * rt + n;
+      acc[rt] = tile_mm_f<8>([&](int k) { return vj ? wrow[k] : 0.0; }, [&](int k) { return brow[k * MLP_ST]; }, 0, KP, acc[rt]);
     }
 #pragma unroll
     for (int rt = 0; rt < MLP_RT; ++rt) {
@@ -163,8 +169,8 @@ __device__ __forceinline__ void mlp_stage_all(const MlpArgs& m, const MlpLds& Lo
     src += m.H * nin + m.H;
     nin = m.H;
   }
-  if (tid < MLP_HP) sm[Lo.wo + tid] = tid < m.H ? src[tid] : 0.0;
-  if (tid == 0) sm[Lo.wo + MLP_HP] = src[m.H];
+  if (tid < Lo.KPH) sm[Lo.wo + tid] = tid < m.H ? src[tid] : 0.0;
+  if (tid == 0) sm[Lo.wo + Lo.KPH] = src[m.H];
   // inputs: a0 [KP0][ST], this block's rows (padding rows repeat the last row; their d out is zero)
   if (tid < MLP_T) {
     const int row = blockIdx.x * MLP_T + tid, rc = row < m.N ? row : m.N - 1;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_fwd(MlpArgs m, double* __rest
   if (tid < MLP_T) {
     const int row = blockIdx.x * MLP_T + tid;
     const double* wo = sm + Lo.wo;
-    double s0 = wo[MLP_HP], s1 = 0.0;
+    double s0 = wo[Lo.KPH], s1 = 0.0;
     for (int i = 0; i + 2 <= Lo.KPH; i += 2) {
       s0 = fma(wo[i], ain[i * MLP_ST + tid], s0);
       s1 = fma(wo[i + 1], ain[(i + 1) * MLP_ST + tid], s1);
@@ -213,11 +219,16 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
   const int PW = mlp_weights_per_net(D, H, L);
   const MlpLds Lo = mlp_lds(D, H, L, true);
   const int KPH = Lo.KPH;
+#ifdef TGP_STAMPS
+  double* mst = part + (size_t)gridDim.x * m.nnets * PW;  // the 16 spare doubles behind the partials
+#endif
+  MSTAMP(0);
   mlp_stage_all(m, Lo, sm, net, tid);
   const int row = blockIdx.x * MLP_T + tid;
   double* gos = sm + Lo.gos;
   if (tid < MLP_T) gos[tid] = row < m.N ? g_out[(size_t)row * m.nnets + net] : 0.0;
   __syncthreads();
+  MSTAMP(1);
   const int step = m.step_dev ? m.step_dev[0] : 0;
   const bool drop = m.training && m.p > 0.0;
   const double scale = drop ? 1.0 / (1.0 - m.p) : 1.0;
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
     }
   }
   __syncthreads();
+  MSTAMP(2);
   double* gp = part + ((size_t)blockIdx.x * m.nnets + net) * PW;
   // ---- output layer: out = wo . aL + bo :  dwo[i] = sum_rows go * aL[i][row], dbo = sum_rows go ----
   double* aL = sm + Lo.actl + (size_t)(L - 1) * KPH * MLP_ST;
@@ -249,6 +261,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
     gp[mlp_woff(D, H, L) + i] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
+  MSTAMP(3);
   // derivative of (activation -> dropout) through the stored value a; `kept` only matters for tanh
   auto dfac = [&](double a, bool kept) {
     if (m.act == 0) return a > 0.0 ? scale : 0.0;
@@ -261,9 +274,10 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
     return (unsigned)((h4 >> (16 * ((j >> 2) & 3))) & 0xFFFFu) >= th;
   };
   {
-    // delta_L in place (zero on padded units): 256 threads over the 128 x KPH strip, two half-ranges of units
+    // delta_L in place (zero on padded units): 256 threads over the MLP_T x KPH strip, MLP_NT / MLP_T ranges of units
     const double* wo = sm + Lo.wo;
-    const int rl = tid & (MLP_T - 1), half = tid >> 7, hk = (KPH + 1) / 2;
+    constexpr int parts = MLP_NT / MLP_T;
+    const int rl = tid % MLP_T, half = tid / MLP_T, hk = (KPH + parts - 1) / parts;
     const double go = gos[rl];
     for (int i = half * hk; i < min(KPH, (half + 1) * hk); ++i) {
       const double a = aL[i * MLP_ST + rl];
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
     }
   }
   __syncthreads();
+  MSTAMP(4);
   // ---- hidden layers, last to first: the layer's strip now holds its delta ----
   for (int l = L - 1; l >= 0; --l) {
     const int nin = l == 0 ? D : H, KPin = l == 0 ? Lo.KP0 : KPH;
@@ -286,14 +301,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
         const double* pa = dl + (va ? ja : 0) * MLP_ST + q;
         const double* pb = ain + (vb ? ib : 0) * MLP_ST + q;
         d4 acc = {0, 0, 0, 0};
-#pragma unroll 2
-        for (int r0 = 0; r0 < MLP_T; r0 += 16) {
-          double av[4], bv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { av[u] = va ? pa[r0 + 4 * u] : 0.0; bv[u] = vb ? pb[r0 + 4 * u] : 0.0; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc = TGP_MFMA(av[u], bv[u], acc);
-        }
+        acc = tile_mm_f<8>([&](int k) { return va ? pa[k] : 0.0; }, [&](int k) { return vb ? pb[k] : 0.0; }, 0, MLP_T, acc);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int j = 16 * jt + q + 4 * rr, i = 16 * it + n;
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
         gp[mlp_woff(D, H, l) + H * nin + j] = (s0 + s1) + (s2 + s3);
       }
     }
+    MSTAMP(5 + 2 * (L - 1 - l));
     if (l == 0) break;
     __syncthreads();
     // delta_{l-1}[i][r] = (sum_j W_l[j][i] delta_l[j][r]) * d(act, dropout)(a_{l-1}[i][r]), in place over a_{l-1}.
@@ -321,21 +330,11 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
         for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = {0, 0, 0, 0};
         const bool vi = 16 * it + n < KPH;
         const double* wcol = Wp + q * KPH + (vi ? 16 * it + n : 0);
-        const double* brow = dl + q * MLP_ST + 16 * MLP_RT * wave + n;
-        double a = vi ? wcol[0] : 0.0, b[MLP_RT];
 #pragma unroll
-        for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = brow[16 * rt];
-        for (int k0 = 0; k0 < KPH; k0 += 4) {
-          const int kn = k0 + 4 < KPH ? k0 + 4 : k0;
-          const double an = vi ? wcol[kn * KPH] : 0.0;
-          double bn[MLP_RT];
-#pragma unroll
-          for (int rt = 0; rt < MLP_RT; ++rt) bn[rt] = brow[kn * MLP_ST + 16 * rt];
-#pragma unroll
-          for (int rt = 0; rt < MLP_RT; ++rt) acc[rt] = TGP_MFMA(a, b[rt], acc[rt]);
-          a = an;
-#pragma unroll
-          for (int rt = 0; rt < MLP_RT; ++rt) b[rt] = bn[rt];
+        for (int rt = 0; rt < MLP_RT; ++rt) {
+          const double* brow = dl + q * MLP_ST + 16 * MLP_RT * wave + 16 * rt + n;
+          acc[rt] = tile_mm_f<8>([&](int k) { return vi ? wcol[k * KPH] : 0.0; }, [&](int k) { return brow[k * MLP_ST]; }, 0, KPH,
+                                 acc[rt]);
         }
 #pragma unroll
         for (int rt = 0; rt < MLP_RT; ++rt) {
@@ -352,6 +351,7 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
       }
     }
     __syncthreads();
+    MSTAMP(6 + 2 * (L - 1 - l));
   }
 }
 

@@ -447,8 +447,9 @@ class MlpSpec:
     def lds_bytes(self):
         """LDS image of the backward kernel (tgp_mlp.hip mlp_lds): padded weights + activation strips."""
         kp0, kph = (self.D + 3) // 4 * 4, (self.H + 3) // 4 * 4
-        w = 64 * kp0 + 64 + (self.L - 1) * (64 * kph + 64) + 66
-        return (w + (kp0 + self.L * kph) * 129 + 2 + 128) * 8
+        w = kph * kp0 + kph + (self.L - 1) * (kph * kph + kph) + kph + 2
+        n = w + (kp0 + self.L * kph) * 65           # strips [unit][64 rows + 1]
+        return ((n + 1) // 2 * 2 + 64) * 8           # + d out of the block's 64 rows
 
     def struct(self, N, training):
         d = L.TgpMlp()
