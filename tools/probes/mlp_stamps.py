@@ -1,0 +1,20 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import tgp.pytorch_amd.lib as L
+L.LIB_PATH = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools/probes/stamp/libtgp_hip.so")
+import bench
+from tgp.pytorch_amd.engine import ElboEngine
+w = bench.WORKLOADS["idtgp_power_sal3"]
+prob = bench.make_problem(w, 0)
+spec, W = bench.make_mlp(w, 0)
+eng = ElboEngine(prob["X"], prob["Y"], prob["params"], float(prob["N_total"]), flow_blocks=prob["program"], S=w["S"], mlp=spec, mlp_weights=W)
+for _ in range(3):
+    eng.forward_backward()
+torch.cuda.synchronize()
+st = eng.mlp_ws[-16:].cpu().tolist()
+nblk = (eng.N + 63) // 64
+PW = spec.weights_per_net
+off = nblk * spec.nnets * PW
+st = eng.mlp_ws[off:off + 10].cpu().tolist()
+names = ["stage", "fwd recompute", "out layer", "delta_L", "dW2+db2", "delta-prop", "dW1+db1"]
+print("k_mlp_bwd block 0:", "  ".join("%s %.1f" % (names[i], (st[i + 1] - st[i]) * 0.01) for i in range(7)), " total %.1f us" % ((st[7] - st[0]) * 0.01))
