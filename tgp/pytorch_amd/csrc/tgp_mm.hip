@@ -409,7 +409,9 @@ __device__ __forceinline__ double red_tail(const Plan& p, const double* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bwd12 (grid = MT workgroups, one per column block c; 8 waves)
+// k_bwd12 (grid = 2 MT workgroups of 8 waves: two per column block c -- one forms Lbar(:, c) and Q(:, c), the other the
+//          L_q-gradient tiles of block row c; both need only G(:, c).  With one workgroup per c the 2 MT - c tiles of the
+//          first phase took two rounds of the 8 waves on the critical block c = 0)
 //   Gs    = G(:, c)  (sum of the partials, staged in LDS)
 //   Lbar(:, c) = -tril(w s^T + 2 H' G)(:, c)                      -> LDS
 //   dELBO/dLam(c-rows, :) = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)) -> final gradient (strict upper = 0)
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   double* LbL = Gs + (size_t)MP * 16;  // MP x 16
   double* svL = LbL + (size_t)MP * 16; // 16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const int c = blockIdx.x, c0 = 16 * c;
+  const bool lam_block = (int)blockIdx.x >= MT;
+  const int c = blockIdx.x % MT, c0 = 16 * c;
   const double* __restrict__ Gp = ws + p.Gp;
   const size_t mm = (size_t)MP * MP;
   for (int i = tid; i < MP * 16; i += BWD_THREADS) {
@@ -442,8 +445,9 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ Lm = ws + p.L;
   const double* __restrict__ w = ws + p.w;
-  // ---- Lbar tiles (i >= c) and Lam-gradient tiles (all j) ----
-  for (int t = wave; t < (MT - c) + MT; t += BWD_THREADS / 64) {
+  // ---- Lbar tiles (i >= c) / Lam-gradient tiles (all j) ----
+  const int t_lo = lam_block ? MT - c : 0, t_hi = lam_block ? (MT - c) + MT : MT - c;
+  for (int t = t_lo + wave; t < t_hi; t += BWD_THREADS / 64) {
     if (t < MT - c) {
       const int i0 = 16 * (c + t);
       d4 acc = {0, 0, 0, 0};
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
       }
     }
   }
+  if (lam_block) return;
   __syncthreads();
   // ---- Q(i, c) = Phi(M1) + Phi(M1)^T with M1 = L^T Lbar ;  (L^T)[i,k] = L[k,i] = 0 for k < i ----
   double* Q = ws + p.Q;
@@ -789,7 +794,7 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st) {
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd12, dim3(p.MT), dim3(BWD_THREADS), (size_t)(2 * p.MP * 16 + 16) * sizeof(double), st, p, md, g, ws);
+  hipLaunchKernelGGL(k_bwd12, dim3(2 * p.MT), dim3(BWD_THREADS), (size_t)(2 * p.MP * 16 + 16) * sizeof(double), st, p, md, g, ws);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), (size_t)p.MT * 256 * sizeof(double), st, p, ws);
   LAUNCH_CHECK();
