@@ -374,15 +374,22 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
   const int part = blockIdx.y;
   const int b0 = (int)((long long)p.nblocks * part / TGP_RSPLIT), b1 = (int)((long long)p.nblocks * (part + 1) / TGP_RSPLIT);
   const double* sl = ws + p.slabs + e;
+  // 16 slabs per batch, all requested before the first add, the ragged end inside the batch (clamped index, zero
+  // weight): the slabs come from the Infinity Cache / HBM at 1-2 us per dependent round trip, and the former scalar
+  // tail loop paid one round trip per leftover slab (2 of this kernel's 5 us at Power size)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int b = b0;
-  for (; b + 8 <= b1; b += 8) {
-    double t[8];
+  for (int b = b0; b < b1; b += 16) {
+    double t[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = sl[(size_t)(b + u) * p.slab_len];
-    s0 += t[0] + t[4]; s1 += t[1] + t[5]; s2 += t[2] + t[6]; s3 += t[3] + t[7];
+    for (int u = 0; u < 16; ++u) {
+      const int bu = b + u < b1 ? b + u : b1 - 1;
+      t[u] = sl[(size_t)bu * p.slab_len];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? t[u] : 0.0;
+    s0 += (t[0] + t[4]) + (t[8] + t[12]); s1 += (t[1] + t[5]) + (t[9] + t[13]);
+    s2 += (t[2] + t[6]) + (t[10] + t[14]); s3 += (t[3] + t[7]) + (t[11] + t[15]);
   }
-  for (; b < b1; ++b) s0 += sl[(size_t)b * p.slab_len];
   const double s = (s0 + s1) + (s2 + s3);
   if (e < p.slab_T) {
     // tile t = (ti,tj), ti >= tj, row-major over the lower triangle of tiles
