@@ -438,7 +438,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
   __syncthreads();
   TGP_STAMP(a.ws, p, 17);
-  TGP_STAMP(a.ws, p, 17);
   // Row-blocks of G are dealt to the waves in balanced groups -- MT odd: {MT-1}, {MT-2, 0}, {MT-3, 1}, ...; MT even:
   // {MT-1, 0}, {MT-2, 1}, ... (every group holds MT or MT+1 of the MT(MT+1)/2 lower tiles) -- so that the 16 A-operand
   // fragments of a row-block are read from LDS ONCE, kept in registers (first raw for s = A mubar, then scaled by vbar for
