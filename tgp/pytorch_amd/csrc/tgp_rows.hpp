@@ -80,11 +80,12 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
 // One output tile of a triangular GEMM of the row kernel: NSTEPS k-steps (4 rows of the operand panel each) starting
 // at k-step `step0`.  `a0` = &panel[q*16 + nl] (k-step s is 64 doubles further), fb(s) = B operand of local step s.
 // Operands are read from LDS in batches of 8 BEFORE their MFMAs (left to itself hipcc emits ds_read -> wait -> mfma
-// one by one: ~120 cycles per MFMA instead of 64); two accumulator chains hide the dependent-issue latency.
+// one by one: ~120 cycles per MFMA instead of 64).  ONE accumulator: back-to-back MFMAs on the same accumulator are
+// forwarded inside the matrix pipe (64 cycles apart); two alternating accumulators measured slower (gemmphase_rate.hip).
 // (nsteps is a constant after the caller's tile loop is unrolled; MAXSTEPS bounds the unrolling.)
 template <int MAXSTEPS, class FB>
 __device__ __forceinline__ d4 mfma_chain(const double* a0, int step0, int nsteps, FB fb) {
-  d4 c = {0, 0, 0, 0}, c2 = {0, 0, 0, 0};
+  d4 c = {0, 0, 0, 0};
 #pragma unroll
   for (int s0 = 0; s0 < MAXSTEPS; s0 += 8) {
     double av[8];
@@ -93,15 +94,12 @@ __device__ __forceinline__ d4 mfma_chain(const double* a0, int step0, int nsteps
       if (s0 + u < nsteps) av[u] = a0[(step0 + s0 + u) * 64];
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (s0 + u < nsteps) {
-        if (u & 1) c2 = TGP_MFMA(av[u], fb(s0 + u), c2);
-        else c = TGP_MFMA(av[u], fb(s0 + u), c);
-      }
+      if (s0 + u < nsteps) c = TGP_MFMA(av[u], fb(s0 + u), c);
     // pin the shape of this batch in the emitted code: all LDS reads first, then the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
   }
-  return c + c2;
+  return c;
 }
 
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
