@@ -195,6 +195,66 @@ def test_input_dependent_flow_gradients_reach_the_mlps():
         assert rel_err(a.cpu(), b.cpu()) < 1e-7
 
 
+def test_fully_bayesian_log_likelihood_applies_mc_dropout():
+    """Fully Bayesian ID_TGP evaluation (sparse_MF_SP.py:753-776): enable_eval_dropout() re-enables only the Dropout
+    layers after eval(), and every MC sample draws a fresh mask.  The HIP MLP path must follow the LAYERS' state (the
+    container's .training is False there): S_MC samples -> logsumexp - log S, each sample's mask = the hash mask of
+    the step counter (ops.mlp_keep_mask), restated here on the host for the first sample."""
+    from tgp.pytorch_amd import ops
+    from tgp.pytorch_amd.flow import compile_flow, instance_flow
+    from tgp.pytorch_amd.flows import SAL
+    from tgp.pytorch_amd.kernels import instance_kernel
+    from tgp.pytorch_amd.likelihoods import GaussianNonLinearMean
+    from tgp.pytorch_amd.models import sparse_MF_SP
+    torch.manual_seed(0)
+    prob = orc.synthetic_problem(200, 4, 20, seed=2, flow="idsal3", S=16)
+    p = prob["params"]
+    idf = instance_flow(SAL(3, input_dependent=True, input_dim=4, num_hidden_layers=2, batch_norm=0, dropout=0.25,
+                            hidden_dim=50, hidden_activation="relu", inference="MC_dropout"))
+    idf.turn_off_initializer_parameters()
+    K = instance_kernel("scale_rbf", ard_num_dim=4, num_multioutput=1, kernel_is_shared=False,
+                        init_params={"length_scale": 2.0, "kernel_scale": 2.0})
+    model = sparse_MF_SP(["zero", K], prob["X"], p["Z"].clone(), 200, GaussianNonLinearMean(1, 0.05, False, 16), 1, True,
+                         False, False, False, False, [idf], "single", 0.0,
+                         init_params={"variational_distribution": {"variance_scale": 1e-5, "mean_scale": 0.0}}).to(DEV)
+    with torch.no_grad():
+        model.q_U.variational_mean.data = p["m"].reshape(1, -1).to(DEV)
+        model.q_U.chol_variational_covar.data = p["Lam"].reshape(1, 20, 20).to(DEV)
+    X, Y = prob["X"].to(DEV), prob["Y"].to(DEV)
+    Ystd = torch.ones(1, device=DEV)
+    model.set_is_training(False)
+    model.be_fully_bayesian(False)
+    plain, _ = model.test_log_likelihood(X, Y, False, Ystd)
+    plain2, _ = model.test_log_likelihood(X, Y, False, Ystd)
+    assert torch.equal(plain, plain2)                       # no dropout: deterministic
+    model.be_fully_bayesian(True)
+    b1, _ = model.test_log_likelihood(X, Y, False, Ystd, S_MC_NNet=8)
+    b2, _ = model.test_log_likelihood(X, Y, False, Ystd, S_MC_NNet=8)
+    assert bool(torch.isfinite(b1).all()) and bool(torch.isfinite(b2).all())
+    assert float((b1 - plain).abs()) > 1e-6                 # the masks are applied ...
+    assert float((b1 - b2).abs()) > 1e-9                    # ... and redrawn for every call
+    # one sample, restated: per-row parameters from the nets with the host mask of the NEXT step counter value
+    _, _, nets = compile_flow(model.G_matrix[0])
+    mspec = model._cfg["mlp"]
+    step = int(model._cfg["mlp_step"][0]) + 1
+    W = torch.cat([q.reshape(-1) for net in nets for q in net.parameters()]).detach()
+    masks = [[torch.from_numpy(ops.mlp_keep_mask(mspec.seed, step, k, l, 200, mspec.H, mspec.drop_p)).to(torch.float64)
+              for l in range(mspec.L)] for k in range(mspec.nnets)]
+    rowp_ref = _torch_mlps(prob["X"], W.cpu(), mspec, masks)
+    one, _ = model.test_log_likelihood(X, Y, False, Ystd, S_MC_NNet=1)
+    model._eval_mode()
+    with torch.no_grad():
+        mq, cq = model.marginal_variational_qf_parameters(X.repeat(1, 1, 1), diagonal=True, is_duvenaud=False)
+    spec, theta, _ = model._flow_inputs(X, with_grad=False)      # (advances the counter once more: not used below)
+    lvn = model.likelihood.log_var_noise.detach().reshape(-1)[:1].contiguous()
+    _, _, lp = ops.predict(mq.reshape(-1).contiguous(), cq.reshape(-1).contiguous(), lvn, spec,
+                           theta.detach() if theta is not None else None, model.quad_points, rowp_ref.to(DEV),
+                           Y=Y, Y_std=1.0)
+    import numpy
+    want = (lp + 0.5 * float(numpy.log(numpy.pi))).sum() - 200 * float(numpy.float32(0.5) * numpy.log(numpy.float32(numpy.pi)))
+    assert rel_err(one.cpu(), want.reshape(1).cpu()) < 1e-9
+
+
 def test_cholesky_failure_protocol():
     """status word -> the reference's jitter ladder (dsp/utils.py:256-269) and NanError (:241-254)."""
     from tgp.pytorch_amd import ops

@@ -150,7 +150,11 @@ class sparse_MF_SP(nn.Module):
                     # one for this call's backward (the counter moves before the forward, not after it)
                     self._cfg["mlp_step"][0] += 1
                     W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
-                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(nets[0].training), self._cfg["mlp_step"])
+                    # dropout is on when the nets' Dropout layers are in train mode: in training, and in the fully
+                    # Bayesian evaluation, where enable_eval_dropout() re-enables ONLY those layers after eval()
+                    # (models/utils_models.py:358-364) -- the container's own .training flag is False there
+                    drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
+                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(drop_on), self._cfg["mlp_step"])
                 else:
                     rowp = torch.cat([net(X2d) for net in nets], dim=-1)
         return spec, theta, rowp
