@@ -40,6 +40,9 @@ positive_transform = "exp"
 strict_flag = True
 constant_jitter = None
 global_jitter = None
+# like the reference, importing the configuration seeds torch and numpy (dsp/config.py:66): runs of main.py are
+# reproducible (flow initialisers, dropout of the torch-side nets, predictive samples draw from these generators)
+set_seed(config_seed)
 device = check_device()
 
 # The reference creates this tensor while the default dtype is float32 (dsp/config.py:71) and every log-Gaussian
