@@ -98,8 +98,12 @@ def main(argv=None):
     trainer.train(epochs=args.epochs, lr_ALL=lr, opt="adam", keep_parameter_groups=True,
                   optimisation_schedule=([1.0], specs), lr_groups=None)
     res = trainer.compute_metrics()
-    print("Dataset {}, num inducing points {}, model {}, Test Negative LOGL {:.3f}, Test RMSE {:.3f}".format(
-        args.dataset, args.num_inducing, args.model, -res[6], res[7]))
+    if args.model == "ID_TGP":       # the reference's result lines (main.py:309-324)
+        print("Dataset {}, num inducing points {}, POINT ESTIMATE FLOW , Test Negative LOGL {:.3f}, Test RMSE {:.3f}".format(
+            args.dataset, args.num_inducing, -res[6], res[7]))
+    else:
+        print("Dataset {}, num inducing points {}, model {}, Test Negative LOGL {:.3f}, Test RMSE {:.3f}".format(
+            args.dataset, args.num_inducing, args.model, -res[6], res[7]))
     if args.model == "ID_TGP":
         model.be_fully_bayesian(True)
         res = trainer.compute_metrics()
