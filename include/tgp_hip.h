@@ -117,6 +117,9 @@ typedef struct tgp_grads {
 
 int tgp_version(void);
 const char* tgp_last_error(void);
+/* sha256 (first 16 hex digits) of the kernel sources this library was compiled from (csrc Makefile SRC_HASH): the
+   Python binding recomputes it from the tree and refuses a stale binary. */
+const char* tgp_source_hash(void);
 
 /* Bytes of workspace the calls below need for a problem of this shape (training is the maximum). */
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP);

@@ -214,7 +214,162 @@ def matern_fixtures():
         reference_step0(prob, kw["flow"], name, kernel="scale_matern32")
 
 
+# ---------------------------------------------------------------------------------------------------
+# real data (the reference's own CSV + split pickle) and full-size (N=8611, M=100) fixtures
+# ---------------------------------------------------------------------------------------------------
+def real_dataset_fixture(name):
+    """The reference's loader, called as code/main.py:134 does -> tests/golden/<name>_seed1.npz
+    (split indices, z-scored tensors, Y_std, KMeans centres of the reference's KMEANS).  Data, not source."""
+    import pickle
+    from dsp.data import return_dataset
+    from dsp.utils import KMEANS
+    opts = {"shuffle_train": True, "split_from_disk": True, "use_generator": True, "n_workers": 0}
+    loaders, dc = return_dataset(name, 10000, use_validation=None, seed=1, options=opts)
+    with open("/root/reference/code/datasets/regression/uci/splits_idx_%s.pkl" % name, "rb") as fh:
+        sp = pickle.load(fh)["seed_1"]
+    M = {"power": 100, "boston": 5}[name]
+    Z1 = KMEANS(dc["X_tr"], M, n_init=1, seed=0)
+    out = {"train_idx": np.asarray(sp["train"]), "test_idx": np.asarray(sp["test"]), "X_tr": dc["X_tr"], "Y_tr": dc["Y_tr"],
+           "X_te": dc["X_te"], "Y_te": dc["Y_te"], "Y_std": np.asarray(dc["Y_std"], dtype=np.float64).reshape(-1),
+           "Z_kmeans_n1_seed0": Z1, "N_tr": np.int64(dc["N_tr"]), "N_te": np.int64(dc["N_te"])}
+    # validation split as the reference draws it (uci_datasets.py:54-56): only the indices, to pin random_split_validation
+    # (datasets.py:179 raises NameError('toy_list') for use_validation != None, so the dataset class is called directly)
+    from dsp.data.uci_datasets import Power, Boston
+    ds = {"power": Power, "boston": Boston}[name](1, use_validation=[3, 50], split_from_disk=True)
+    out["val_X_va_head"], out["val_Y_std"] = ds.X_va[:8], np.asarray(ds.Y_std).reshape(-1)
+    save(name + "_seed1", out)
+    return dc, Z1
+
+
+def problem_on(dc, Z, flow, S, perturb, seed=0):
+    """orc.synthetic_problem's parameter recipe on real rows: same generators, X/Y/Z replaced."""
+    N, D = dc["X_tr"].shape
+    prob = orc.synthetic_problem(N, D, Z.shape[0], seed=seed, flow=flow, S=S, perturb=perturb)
+    prob["X"], prob["Y"] = dc["X_tr"].clone(), dc["Y_tr"].clone()
+    prob["params"]["Z"] = Z.clone()
+    prob["N_total"] = float(N)
+    return prob
+
+
+def id_model_with_weights(prob, seed=0):
+    """ID_TGP (SAL x 3, MLPs 4->50->50->1, code/exp_config.py:31-55) with seeded network weights whose output
+    layers are shrunk around the identity flow (a_n ~ 0, b_n ~ 1) -- the state find_forward_params_input_dependent_flow
+    leaves them in -- so the flow is well conditioned.  Eval mode: dropout off, deterministic."""
+    torch.manual_seed(seed)
+    model = build_reference_model(prob, "idsal3")
+    with torch.no_grad():
+        for blk in model.G_matrix[0].flow_arr:
+            if hasattr(blk, "NNets_a"):
+                for nm, bias in (("a", 0.0), ("b", 1.0)):
+                    last = list(getattr(blk, "NNets_" + nm))[-1].w
+                    last.weight.mul_(0.3)
+                    last.bias.fill_(bias)
+    model.set_is_training(True)
+    model.eval()
+    return model
+
+
+def nn_params(model):
+    """The MLP parameters in the packed order of the product (tgp/pytorch_amd/flow.py compile_flow: block by block,
+    NNets_a then NNets_b; per layer weight then bias)."""
+    out = []
+    for blk in model.G_matrix[0].flow_arr:
+        if hasattr(blk, "NNets_a"):
+            out += list(blk.NNets_a.parameters()) + list(blk.NNets_b.parameters())
+    return out
+
+
+def full_size_fixture(dc, dte, Z, flow, name, perturb=True, steps=5):
+    """Reference step 0 (values, every gradient), the evaluation path on the TEST split, and `steps` Adam steps, at
+    the full training-split size.  X/Y are not stored again: 'data' names the <dataset>_seed1 fixture."""
+    S = 32
+    prob = problem_on(dc, Z, flow, S, perturb)
+    is_id = flow is not None and flow.startswith("idsal")
+    model = id_model_with_weights(prob) if is_id else build_reference_model(prob, flow)
+    model.set_is_training(True)
+    X, Y = prob["X"], prob["Y"]
+    elbo, ell, kld = model.ELBO(X, Y)
+    elbo.backward()
+    out = {"data": np.array(dte), "xs": prob["xs"], "ws": prob["ws"], "N_total": np.float64(prob["N_total"]),
+           "ELBO": elbo.detach(), "ELL": ell.detach(), "KLD": kld.detach(),
+           "g_Z": model.Z.grad[0], "g_m": model.q_U.variational_mean.grad[0],
+           "g_Lam": model.q_U.chol_variational_covar.grad[0],
+           "g_raw_outputscale": model.covariance_function.raw_outputscale.grad,
+           "g_raw_lengthscale": model.covariance_function.base_kernel.raw_lengthscale.grad.reshape(-1),
+           "g_log_var_noise": model.likelihood.log_var_noise.grad.reshape(-1)}
+    for k, v in prob["params"].items():
+        out["p_" + k] = v
+    if flow is not None:
+        out["program"] = np.array(prob["program"], dtype=np.int32)
+        th = flow_scalar_params(model, prob["program"])
+        if th:
+            out["g_theta"] = torch.stack([q.grad.reshape(()) for q in th])
+    if is_id:
+        out["nn_W"] = torch.cat([q.detach().reshape(-1) for q in nn_params(model)])
+        out["g_nn_W"] = torch.cat([q.grad.reshape(-1) for q in nn_params(model)])
+        with torch.no_grad():
+            cols = []
+            for blk in model.G_matrix[0].flow_arr:
+                if hasattr(blk, "NNets_a"):
+                    cols += [blk.NNets_a(X[:256]).reshape(-1), blk.NNets_b(X[:256]).reshape(-1)]
+            out["rowp_head"] = torch.stack(cols, 1)
+    with torch.no_grad():
+        if name.endswith("svgp"):
+            mu, v = model.marginal_variational_qf_parameters(X, diagonal=True, is_duvenaud=False, init_Z=None)
+            out["mu"], out["v"] = mu.reshape(-1), v.reshape(-1)
+        # evaluation path on the test split (sparse_MF_SP.py:637-825), as Trainer.compute_metrics calls it
+        model.set_is_training(False)
+        Y_std = torch.tensor(np.asarray(dc["Y_std"], dtype=np.float64).reshape(-1))
+        logp, (m1, m2) = model.test_log_likelihood(dc["X_te"], dc["Y_te"], return_moments=True, Y_std=Y_std, S_MC_NNet=None)
+        out["test_logp_sum"], out["pred_m1"], out["pred_m2"] = logp.reshape(-1), m1.reshape(-1), m2.reshape(-1)
+        model.set_is_training(True)
+        if is_id:
+            model.eval()
+    # Adam steps continue from the same state (gradients are recomputed; trainer_base.py:337-342)
+    if is_id:
+        nn_ids = {id(q) for q in nn_params(model)}
+        groups = [{"params": [q for q in model.parameters() if id(q) not in nn_ids], "lr": 0.01},
+                  {"params": nn_params(model), "lr": 0.01, "weight_decay": 1e-5}]       # main.py:276-288
+        opt = torch.optim.Adam(groups, lr=0.01)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    hist = []
+    for _ in range(steps):
+        e, l, k = model.ELBO(X, Y)
+        opt.zero_grad()
+        (-e).backward()
+        opt.step()
+        hist.append([e.item(), l.item(), k.item()])
+    out["history"] = np.array(hist)
+    out["final_Z"], out["final_m"] = model.Z.detach()[0], model.q_U.variational_mean.detach()[0]
+    out["final_log_var_noise"] = model.likelihood.log_var_noise.detach().reshape(-1)
+    if flow is not None and flow_scalar_params(model, prob["program"]):
+        out["final_theta"] = torch.stack([q.detach().reshape(()) for q in flow_scalar_params(model, prob["program"])])
+    if is_id:
+        out["final_nn_W_head"] = torch.cat([q.detach().reshape(-1) for q in nn_params(model)])[:512]
+    save(name, out)
+
+
+def real_data_fixtures():
+    dc, Z = real_dataset_fixture("power")
+    # known answers at initialisation (SURVEY.md 8c: ELBO -81723.694286, KLD 525.646773 for SVGP and identity TGP)
+    full_size_fixture(dc, "power_seed1", Z, None, "power_init_svgp", perturb=False)
+    full_size_fixture(dc, "power_seed1", Z, "sal2", "power_init_sal2", perturb=False, steps=2)
+    for flow, name in ((None, "power_svgp"), ("sal2", "power_sal2"), ("tanh3x2", "power_tanh3x2"), ("idsal3", "power_idsal3")):
+        full_size_fixture(dc, "power_seed1", Z, flow, name)
+    dcb, Zb = real_dataset_fixture("boston")
+    full_size_fixture(dcb, "boston_seed1", Zb, None, "boston_init_svgp", perturb=False)
+    full_size_fixture(dcb, "boston_seed1", Zb, None, "boston_svgp")
+    # medium ID fixture (SURVEY 8c: N=1024, M=100, D=4, S=32, ID-SAL x 3) on the first 1024 Power rows
+    dcm = dict(dc)
+    dcm["X_tr"], dcm["Y_tr"] = dc["X_tr"][:1024].clone(), dc["Y_tr"][:1024].clone()
+    full_size_fixture(dcm, "power_seed1[:1024]", Z, "idsal3", "med_idsal3")
+
+
 def main():
+    if "--real-only" in sys.argv:
+        real_data_fixtures()
+        return
     if "--matern-only" in sys.argv:
         matern_fixtures()
         return
@@ -243,6 +398,7 @@ def main():
         prob = orc.synthetic_problem(64, 3, 8, seed=0, flow=flow, S=8)
         reference_adam_steps(prob, flow, name)
     cholesky_ladder_fixture()
+    real_data_fixtures()
 
 
 if __name__ == "__main__":

@@ -351,6 +351,30 @@ def steptanh_program(num_blocks, num_steps, rng):
     return prog, torch.tensor(theta, dtype=torch.float64)
 
 
+def mlp_rowp(X, W, D, H, L, nnets, act="relu", masks=None, drop_p=0.0):
+    """Per-row flow parameters of the input-dependent SAL blocks (models/flow.py:853-871, 949-965): `nnets` MLPs
+    D -> H x L -> 1, each hidden layer Linear -> activation -> Dropout (the assumed pytorchlib.apply_linear order,
+    unpinned), evaluated from the packed weights W (per net, per layer: weight (out, in) then bias).  Eval mode unless
+    `masks[k][l]` (N, H) keep-masks are given.  Returns (N, nnets): columns a_0, b_0, a_1, b_1, ..."""
+    actf = {"relu": torch.relu, "tanh": torch.tanh}[act]
+    pw = D * H + H + (L - 1) * (H * H + H) + H + 1
+    outs = []
+    for k in range(nnets):
+        w = W[k * pw:(k + 1) * pw]
+        o, h, nin = 0, X, D
+        for l in range(L):
+            Wl = w[o:o + H * nin].reshape(H, nin)
+            o += H * nin
+            bl = w[o:o + H]
+            o += H
+            h = actf(h @ Wl.T + bl)
+            if masks is not None:
+                h = h * masks[k][l] / (1.0 - drop_p)
+            nin = H
+        outs.append(h @ w[o:o + H] + w[o + H])
+    return torch.stack(outs, 1)
+
+
 def synthetic_problem(N, D, M, seed=0, flow="sal2", S=32, perturb=True, dtype=torch.float64):
     """Seeded inputs per SURVEY.md 8(d): X~N(0,1); Y = zscore(sin(Xw)+0.1 x0^2+0.05 eps);
     Z = first M rows of a seeded permutation; l=2, s2=2; m ~ 0.5 N(0,1); Lq = sqrt(1e-5) I +

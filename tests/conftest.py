@@ -24,13 +24,20 @@ def load_golden(name):
         a = z[k]
         if k == "program":
             out[k] = [tuple(int(t) for t in row) for row in a]
-        elif k == "kernel":
+        elif k in ("kernel", "data"):
             out[k] = str(a)
         elif a.dtype.kind == "f":
             out[k] = torch.from_numpy(np.array(a, dtype=np.float64))
         else:
             out[k] = torch.from_numpy(np.array(a))
     out["params"] = {k[2:]: out[k] for k in out if k.startswith("p_")}
+    if "data" in out and "X" not in out:
+        # full-size fixtures name the dataset fixture that holds their rows: "power_seed1" or "power_seed1[:1024]"
+        base, _, cut = out["data"].partition("[:")
+        d = load_golden(base)
+        n = int(cut[:-1]) if cut else d["X_tr"].shape[0]
+        out["X"], out["Y"] = d["X_tr"][:n], d["Y_tr"][:n]
+        out["X_te"], out["Y_te"], out["Y_std"] = d["X_te"], d["Y_te"], d["Y_std"]
     out.setdefault("program", None)
     out.setdefault("kernel", "scale_rbf")
     return out

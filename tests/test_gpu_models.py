@@ -129,6 +129,22 @@ def test_trainer_first_steps_match_reference(name, flow, resident):
     assert rel_err(model.Z.detach().cpu()[0], g["final_Z"]) < 1e-8
 
 
+def test_frozen_parameters_are_not_trained():
+    """optimisation_schedule entries with lr = 0.0 freeze parameters (trainer_base.py:155-179).  The resident engine
+    updates its whole flat buffer, so the trainer must fall back to the torch optimiser for such a run."""
+    from tgp.pytorch_amd.data import DeviceLoader
+    from tgp.pytorch_amd.trainers import Trainer_SP_regression
+    g = load_golden("adam5_sal2")
+    model = build_model(g, "sal2")
+    Z0 = model.Z.detach().clone()
+    m0 = model.q_U.variational_mean.detach().clone()
+    loader = DeviceLoader(g["X"], g["Y"], 10000, shuffle=False, device=DEV)
+    tr = Trainer_SP_regression(model, [loader], 1e20, False, False, torch.ones(1, device=DEV), -1, 100, True)
+    tr.train(epochs=3, lr_ALL=0.01, opt="adam", keep_parameter_groups=True, optimisation_schedule=([1.0], [[[0.0, "Z"]]]))
+    assert tr._engine is None and tr.optimizer is not None
+    assert torch.equal(model.Z.detach(), Z0) and not torch.equal(model.q_U.variational_mean.detach(), m0)
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_engine_hip_adam_matches_reference_history(graph):
     """The resident step engine (fused ELBO + tgp_adam_dev_f64, optionally replayed from a HIP graph)."""

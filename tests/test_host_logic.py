@@ -81,12 +81,37 @@ def test_optimizer_groups_follow_main_py():
     tr = Trainer_SP_regression(model, [[], None, None], 1e20, False, False, torch.ones(1), -1, 100, True)
     sched = [[0.01, n] for n, _ in model.named_parameters() if "G_matrix" in n and "NNets" not in n]
     sched.append([0.01, 1e-5, "NNets"])
-    groups = tr._param_groups(sched, 0.01)
+    groups, placed = tr._param_groups(sched, 0.01)
     wd = {g["weight_decay"]: len(g["params"]) for g in groups}
     assert wd[1e-5] == 36                                   # 6 MLPs x 3 layers x (weight, bias)
-    assert sum(len(g["params"]) for g in groups) == len(list(model.parameters()))
+    assert sum(len(g["params"]) for g in groups) == len(list(model.parameters())) == len(placed)
     with pytest.raises(ValueError):
         tr._param_groups([[0.01, "NNets"], [0.01, 1e-5, "NNets"]], 0.01)
+    # lr = 0.0 freezes (trainer_base.py:155-179): the parameter joins no group ...
+    groups, placed = tr._param_groups([[0.0, "Z"], [0.02, "variational_mean"]], 0.01)
+    ids = {id(q) for g in groups for q in g["params"]}
+    assert id(model.Z) not in ids and "Z" not in placed
+    assert [g["lr"] for g in groups] == [0.02, 0.01]
+    # ... and a kept optimiser's parameters are skipped by later stages, naming one again is an error
+    groups, placed = tr._param_groups([[0.01, "Z"]], 0.01, already_added=[n for n in placed])
+    assert placed == ["Z"] and len(groups) == 1 and groups[0]["params"][0] is model.Z
+    with pytest.raises(ValueError):
+        tr._param_groups([[0.01, "Z"]], 0.01, already_added=["Z"])
+
+
+def test_frozen_parameters_keep_the_run_off_the_resident_engine(monkeypatch):
+    """optimisation_schedule entries with lr = 0.0 freeze parameters; the resident engine updates its whole
+    flat buffer, so such a stage must not use it (no GPU needed: _engine_for is asked, never built)."""
+    from tgp.pytorch_amd import trainers
+    model = build(None)
+    tr = trainers.Trainer_SP_regression(model, [[], None, None], 1e20, False, False, torch.ones(1), -1, 100, True)
+    asked = []
+    monkeypatch.setattr(tr, "_engine_for", lambda groups, lr, opt: asked.append(groups) or None)
+    monkeypatch.setattr(tr, "_train_eager", lambda n, tot: None)
+    tr.train(epochs=2, lr_ALL=0.01, opt="adam", keep_parameter_groups=True, optimisation_schedule=([0.5, 0.5], [[[0.0, "Z"]], [[0.01, "Z"]]]))
+    assert asked == []                                      # two stages: never eligible
+    assert len(tr.optimizer.param_groups) == 2              # stage 2 ADDED Z's group to the kept optimiser
+    assert tr.optimizer.param_groups[1]["params"][0] is model.Z
 
 
 def test_device_loader_protocol_and_normalisation():
@@ -95,7 +120,7 @@ def test_device_loader_protocol_and_normalisation():
     assert dc["N_tr"] == 8611 and dc["Dx"] == 4 and dc["X_te"].shape[0] == 957
     (x, y), = list(loaders[0])                              # full batch: one step per epoch (main.py:74)
     assert x.shape == (8611, 4) and y.shape == (8611, 1) and len(loaders[0]) == 1
-    assert abs(float(x.mean())) < 1e-12 and abs(float(y.std()) - 1.0) < 1e-9
+    assert abs(float(x.mean())) < 1e-12 and abs(float(y.std(unbiased=False)) - 1.0) < 1e-9     # numpy.std, ddof=0 (data.py:262-268)
     small, _ = return_dataset("synthetic_boston", 100, seed=2)
     assert sum(b[0].shape[0] for b in small[0]) == 455 and len(small[0]) == 5
 

@@ -62,6 +62,11 @@ int tgp_version(void) { return TGP_VERSION; }
 
 const char* tgp_last_error(void) { return g_err; }
 
+#ifndef TGP_SRC_HASH
+#define TGP_SRC_HASH "unstamped"
+#endif
+const char* tgp_source_hash(void) { return TGP_SRC_HASH; }
+
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP) {
   return tgp_workspace_bytes_kernel(N, D, M, S, nblk, P, RP, TGP_KERNEL_SCALE_RBF);
 }

@@ -1,11 +1,12 @@
-"""Data path: UCI-style regression splits, z-scored with the train statistics
-(code/dsp/data/data.py:260-299), served by a loader with the torch DataLoader iteration protocol whose
-tensors are resident on the GPU -- the reference re-collates 8611 rows item by item and copies them H2D
-every step (code/dsp/data/data.py:86-88, trainers/trainer_base.py:330).
+"""Data path: UCI regression splits, z-scored with the train statistics, served by a loader with
+the torch DataLoader iteration protocol whose tensors are resident on the GPU -- the reference re-collates 8611
+rows item by item and copies them H2D every step (code/dsp/data/data.py:86-88, trainers/trainer_base.py:330).
 
-`return_dataset(name, batch_size, use_validation, seed, options)` keeps the reference's call signature
-(code/dsp/data/datasets.py:81-221).  'power' / 'boston' read <root>/<name>.csv + splits_idx_<name>.pkl
-(the reference's own data files, located through options['root'] or $TGP_DATA_ROOT); 'synthetic_power' /
+`return_dataset(name, batch_size, use_validation, seed, options)` keeps the reference's call signature and return
+value (code/dsp/data/datasets.py:81-221): `data_loaders` = [train, test] or [train, valid, test], `data_config` with
+the reference's keys.  'power' / 'boston' read <root>/<name>.csv (no header row, target = last column) and the row
+indices `splits_idx_<name>.pkl['seed_k']['train'|'test']` exactly as code/dsp/data/uci_datasets.py:62-107 does --
+these are the reference's data files, found through options['root'] or $TGP_DATA_ROOT.  'synthetic_power' /
 'synthetic_boston' generate seeded data of the same shape (no network in the build environment).
 """
 import os
@@ -20,7 +21,12 @@ SHAPES = {"power": (9568, 4, 8611), "boston": (506, 13, 455)}
 
 
 class DeviceLoader:
-    """Iterates (x, y) minibatches already resident on `device`; len() = number of batches."""
+    """Iterates (x, y) minibatches already resident on `device`; len() = number of batches.
+
+    Shuffling follows torch's RandomSampler (what the reference's DataLoader(shuffle=True, generator=gen) uses,
+    code/dsp/data/data.py:42-60): one `torch.randperm(n, generator)` per epoch from a generator seeded with
+    cg.config_seed, consecutive slices of it are the minibatches, the last one ragged (drop_last=False).
+    `epoch_permutation()` hands the same permutation to the resident minibatch engine."""
 
     def __init__(self, X, Y, batch_size, shuffle=False, device=None, seed=0):
         dev = device or cg.device
@@ -32,23 +38,66 @@ class DeviceLoader:
     def __len__(self):
         return (self.X.shape[0] + self.batch_size - 1) // self.batch_size
 
+    def epoch_permutation(self):
+        """Row order of the next epoch (int64, host), or None when the order is the stored one."""
+        n = self.X.shape[0]
+        if not self.shuffle:
+            return None
+        return torch.randperm(n, generator=self.gen)
+
     def __iter__(self):
         n = self.X.shape[0]
-        if self.shuffle and self.batch_size < n:
-            perm = torch.randperm(n, generator=self.gen).to(self.X.device)
+        perm = self.epoch_permutation()
+        if perm is not None and self.batch_size < n:
+            perm = perm.to(self.X.device)
             for i in range(0, n, self.batch_size):
                 idx = perm[i:i + self.batch_size]
                 yield self.X[idx], self.Y[idx]
+        elif perm is not None:
+            # one full batch: the ELBO is a sum over rows, the order only changes the summation order
+            yield self.X, self.Y
         else:
             for i in range(0, n, self.batch_size):
                 yield self.X[i:i + self.batch_size], self.Y[i:i + self.batch_size]
 
 
-def standard_normalization(X_tr, Y_tr, X_te, Y_te):
-    """z-score by train statistics (+1e-15), code/dsp/data/data.py:262-268."""
-    mx, sx = X_tr.mean(0), X_tr.std(0) + 1e-15
-    my, sy = Y_tr.mean(0), Y_tr.std(0) + 1e-15
-    return (X_tr - mx) / sx, (Y_tr - my) / sy, (X_te - mx) / sx, (Y_te - my) / sy, sy
+def standard_normalization(X_tr, Y_tr, X_va, Y_va, X_te, Y_te):
+    """z-score by the train split's mean and *population* standard deviation (numpy.std, ddof=0) + 1e-15,
+    code/dsp/data/data.py:260-299.  numpy float64 in, numpy out; returns (..., Y_std) with Y_std of shape (Dy,)."""
+    eps = 1e-15
+    X_mean, X_std = numpy.mean(X_tr, 0), numpy.std(X_tr, 0) + eps
+    Y_mean, Y_std = numpy.mean(Y_tr, 0), numpy.std(Y_tr, 0) + eps
+    zx = lambda a: None if a is None else (a - X_mean) / X_std
+    zy = lambda a: None if a is None else (a - Y_mean) / Y_std
+    return zx(X_tr), zy(Y_tr), zx(X_va), zy(Y_va), zx(X_te), zy(Y_te), Y_std
+
+
+def random_split_validation(X, Y, seed, N_val):
+    """code/dsp/data/data.py:216-234: numpy.random.seed(seed) permutation, the last N_val rows validate."""
+    n = X.shape[0]
+    assert N_val <= n, "Got more validation points {} than total training size {}".format(N_val, n)
+    numpy.random.seed(seed)
+    aux = numpy.random.permutation(n)
+    tr, va = aux[0:n - N_val], aux[n - N_val:]
+    return X[tr, :], Y[tr], X[va, :], Y[va]
+
+
+def load_uci_split(base, seed, root):
+    """(X_tr, Y_tr, X_te, Y_te, tr_idx, te_idx) of the split stored on disk (code/dsp/data/uci_datasets.py:73-97)."""
+    import pandas                   # the reference parses the CSV with pandas (data.py:186); numpy.loadtxt rounds
+    csv = os.path.join(root, base + ".csv")         # a few Boston entries differently (1 ulp)
+    if not os.path.exists(csv):
+        raise FileNotFoundError("%s not found: point options['root'] / $TGP_DATA_ROOT at the reference's "
+                                "code/datasets/regression/uci directory" % csv)
+    data = pandas.read_csv(csv, sep=",", header=None).to_numpy()
+    with open(os.path.join(root, "splits_idx_%s.pkl" % base), "rb") as fh:
+        split_dict = pickle.load(fh)
+    key = "seed_" + str(seed)
+    if key not in split_dict:
+        raise KeyError("split %s not in splits_idx_%s.pkl (has %d splits)" % (key, base, len(split_dict)))
+    tr_idx, te_idx = split_dict[key]["train"], split_dict[key]["test"]
+    data_tr, data_te = data[tr_idx], data[te_idx]
+    return data_tr[:, :-1], data_tr[:, -1].reshape(-1, 1), data_te[:, :-1], data_te[:, -1].reshape(-1, 1), tr_idx, te_idx
 
 
 def _synthetic(name, seed):
@@ -60,33 +109,37 @@ def _synthetic(name, seed):
     return X, Y.reshape(-1, 1)
 
 
-def return_dataset(dataset_name, batch_size, use_validation=None, seed=1, options=None):
+def return_dataset(dataset_name, batch_size, use_validation=None, seed=None, options=None):
     options = options or {}
     synth = dataset_name.startswith("synthetic_")
     base = dataset_name.replace("synthetic_", "")
     if base not in SHAPES:
-        raise ValueError("dataset must be power, boston, synthetic_power or synthetic_boston")
+        raise ValueError("Unkown dataset provided {}".format(dataset_name))
+    if not options.get("split_from_disk", True):
+        raise ValueError("only the splits stored on disk are supported (split_from_disk=True, as code/main.py sets it)")
     n, d, n_tr = SHAPES[base]
     if synth:
         X, Y = _synthetic(base, seed)
         perm = numpy.random.default_rng(seed).permutation(n)
-        tr, te = perm[:n_tr], perm[n_tr:]
+        tr_idx, te_idx = perm[:n_tr], perm[n_tr:]
+        X_tr, Y_tr, X_te, Y_te = X[tr_idx], Y[tr_idx], X[te_idx], Y[te_idx]
     else:
         root = options.get("root", os.environ.get("TGP_DATA_ROOT", ""))
-        csv = os.path.join(root, base + ".csv")
-        if not os.path.exists(csv):
-            raise FileNotFoundError("%s not found: point options['root'] / $TGP_DATA_ROOT at the reference's "
-                                    "code/datasets/regression/uci directory" % csv)
-        arr = numpy.loadtxt(csv, delimiter=",", skiprows=1) if base == "power" else numpy.genfromtxt(csv, delimiter=",", skip_header=1)
-        X, Y = arr[:, :d], arr[:, d:d + 1]
-        with open(os.path.join(root, "splits_idx_%s.pkl" % base), "rb") as fh:
-            splits = pickle.load(fh)
-        sp = splits["seed_%d" % seed] if isinstance(splits, dict) else splits[seed]
-        tr, te = numpy.asarray(sp[0]), numpy.asarray(sp[1])
-    t = lambda a: torch.tensor(a, dtype=cg.dtype)
-    X_tr, Y_tr, X_te, Y_te, y_std = standard_normalization(t(X[tr]), t(Y[tr]), t(X[te]), t(Y[te]))
-    loaders = [DeviceLoader(X_tr, Y_tr, batch_size, shuffle=options.get("shuffle_train", True), seed=cg.config_seed),
-               None, DeviceLoader(X_te, Y_te, batch_size)]
-    data_config = {"Dx": d, "Dy": 1, "X_tr": X_tr, "Y_tr": Y_tr, "N_tr": X_tr.shape[0], "Y_std": float(y_std[0]),
-                   "X_te": X_te, "Y_te": Y_te}
+        X_tr, Y_tr, X_te, Y_te, tr_idx, te_idx = load_uci_split(base, seed, root)
+    X_va = Y_va = None
+    if use_validation is not None:          # [seed, N_val], uci_datasets.py:54-56
+        X_tr, Y_tr, X_va, Y_va = random_split_validation(X_tr, Y_tr, use_validation[0], use_validation[1])
+    X_tr, Y_tr, X_va, Y_va, X_te, Y_te, Y_std = standard_normalization(X_tr, Y_tr, X_va, Y_va, X_te, Y_te)
+    t = lambda a: None if a is None else torch.tensor(a, dtype=cg.dtype)
+    X_tr, Y_tr, X_va, Y_va, X_te, Y_te = (t(a) for a in (X_tr, Y_tr, X_va, Y_va, X_te, Y_te))
+    shuffle = options.get("shuffle_train", True)
+    train = DeviceLoader(X_tr, Y_tr, batch_size, shuffle=shuffle, seed=cg.config_seed)
+    test = DeviceLoader(X_te, Y_te, batch_size)
+    loaders = [train, test]
+    if use_validation is not None:
+        loaders = [train, DeviceLoader(X_va, Y_va, batch_size, shuffle=shuffle, seed=cg.config_seed), test]
+    data_config = {"X_tr": X_tr, "Y_tr": Y_tr, "X_va": X_va, "Y_va": Y_va, "X_te": X_te, "Y_te": Y_te,
+                   "N_tr": X_tr.shape[0], "N_va": 0 if X_va is None else X_va.shape[0], "N_te": X_te.shape[0],
+                   "Dx": d, "Dy": 1, "Y_std": Y_std, "X_all": None, "Y_all": None,
+                   "train_idx": numpy.asarray(tr_idx), "test_idx": numpy.asarray(te_idx)}
     return loaders, data_config

@@ -297,8 +297,9 @@ class ElboEngine:
             warnings.warn("A not p.d., added jitter of %g to the diagonal" % (self.md.jitter_ladder * 10 ** (int(st[2]) - 1)),
                           ops.NumericalWarning)
         if int(st[0]):
-            raise ops.NotPSDError("K_MM not positive definite at pivot %d (engine runs without the jitter ladder; "
-                                  "use ops.elbo_step_safe to retry with jitter)" % int(st[0]))
+            raise ops.NotPSDError("K_MM not positive definite at pivot %d even with the largest jitter of the ladder "
+                                  "(%g), like psd_safe_cholesky's final raise (dsp/utils.py:268-269)"
+                                  % (int(st[0]), self.md.jitter_ladder * 100))
 
     def scalars(self):
         o = self.fp.out.cpu()

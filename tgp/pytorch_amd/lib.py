@@ -51,6 +51,7 @@ _lib = None
 _SIGS = {
     "tgp_version": (C.c_int, []),
     "tgp_last_error": (C.c_char_p, []),
+    "tgp_source_hash": (C.c_char_p, []),
     "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
     "tgp_workspace_bytes_kernel": (C.c_size_t, [C.c_int32] * 8),
     "tgp_kernel_matrix_f64": (C.c_int, [C.c_int32, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp]),
@@ -88,8 +89,27 @@ _SIGS = {
 EXPORTS = tuple(_SIGS.keys())
 
 
+def source_hash():
+    """sha256[:16] of the kernel sources in the tree, computed like the csrc Makefile does (sorted *.hip, *.hpp, then
+    include/tgp_hip.h); None when the sources are not next to the library (a binary-only install)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    hdr = os.path.join(_HERE, "..", "..", "include", "tgp_hip.h")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")),
+                   key=lambda f: os.path.basename(f))
+    if not files or not os.path.exists(hdr):
+        return None
+    h = hashlib.sha256()
+    for f in files + [hdr]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load():
-    """Load libtgp_hip.so once; raise (never fall back) when it is absent."""
+    """Load libtgp_hip.so once; raise (never fall back) when it is absent or was built from other sources than the
+    ones in the tree (the binary is git-ignored and travels beside them: a stale one must not pass for the product)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -100,6 +120,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        want, have = source_hash(), lib.tgp_source_hash().decode()
+        if want is not None and have != want and not os.environ.get("TGP_ALLOW_STALE_LIB"):
+            raise TgpError("libtgp_hip.so is stale: built from sources %s, the tree has %s -- rebuild with "
+                           "`make -C tgp/pytorch_amd/csrc`" % (have, want))
         _lib = lib
     return _lib
 

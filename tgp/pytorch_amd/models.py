@@ -154,7 +154,10 @@ class sparse_MF_SP(nn.Module):
                     # Bayesian evaluation, where enable_eval_dropout() re-enables ONLY those layers after eval()
                     # (models/utils_models.py:358-364) -- the container's own .training flag is False there
                     drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
-                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(drop_on), self._cfg["mlp_step"])
+                    # the counter is snapshotted per call: a second forward before this call's backward (loss accumulated
+                    # over minibatches, an evaluation between ELBO() and backward()) must not change the mask the
+                    # backward recomputes
+                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(drop_on), self._cfg["mlp_step"].clone())
                 else:
                     rowp = torch.cat([net(X2d) for net in nets], dim=-1)
         return spec, theta, rowp

@@ -32,7 +32,13 @@ class Trainer_SP_regression:
     def __init__(self, model, data_loaders, validate_each, plot, track, Y_std, plot_each, S_test,
                  inference_in_cpu=False):
         self.model = model
-        self.train_loader, self.valid_loader, self.test_loader = (list(data_loaders) + [None, None])[:3]
+        # [train], [train, test] or [train, valid, test] (trainer_base.py:50-59)
+        dl = list(data_loaders)
+        self.train_loader, self.valid_loader, self.test_loader = dl[0], None, None
+        if len(dl) == 3:
+            self.valid_loader, self.test_loader = dl[1], dl[2]
+        elif len(dl) == 2:
+            self.test_loader = dl[1]
         self.is_valid, self.is_test = self.valid_loader is not None, self.test_loader is not None
         self.num_outputs = model.out_dim
         self.validate_each = validate_each
@@ -42,36 +48,55 @@ class Trainer_SP_regression:
         self.Y_std = Y_std
         self.optimizer = None
         self._engine = None
+        self._names_added = []
         self.loss_arr, self.ELL_arr, self.KLD_arr = [], [], []
         self.total_trainer_epochs = 0
 
     # ---- optimiser groups (trainer_base.py:106-248) ---------------------------------------------------
-    def _param_groups(self, specs, lr_all):
+    def _param_groups(self, specs, lr_all, already_added=()):
+        """Parameter groups of one schedule stage.  `specs` entries are [lr, name_substring] or [lr, weight_decay,
+        name_substring]; parameters no entry names take (lr_all, 0).  lr == 0.0 freezes: the parameter joins no group
+        (and, with a kept optimiser, stays free to be added by a later stage).  `already_added`: names a kept optimiser
+        holds already (keep_parameter_groups=True) -- skipped, and naming one again is an error like in the reference.
+        Returns (groups, names placed in them)."""
         named = OrderedDict(self.model.named_parameters())
-        taken, groups = set(), []
+        taken, frozen, groups, placed = set(), set(), [], []
+        seen_keys = set()
         for sp in (specs or []):
             if len(sp) == 3:
                 lr, wd, key = sp
             elif len(sp) == 2:
                 (lr, key), wd = sp, 0.0
             else:
-                raise ValueError("Parameters should be specified as [lr, param] or [lr, weight_decay, param]")
+                raise ValueError("Unvalid argument optimisation_schedule. Parameters should be specified as lr, param or "
+                                 "lr, weight_decay, param")
+            if key in seen_keys:
+                raise ValueError("Parameter {} already added to the parameter list".format(key))
+            seen_keys.add(key)
             names = [n for n in named if key in n]
             for n in names:
-                if n in taken:
+                if n in taken and lr != 0.0:
                     raise ValueError("Got repeated parameter {}".format(n))
+                if n in already_added:
+                    raise ValueError("Got repeated parameter {} with root {}. This parameter already belongs to a "
+                                     "parameter group".format(n, key))
+            if lr == 0.0:
+                frozen.update(names)
+                continue
             taken.update(names)
-            if lr != 0.0 and names:
+            if names:
                 for g in groups:
                     if g["lr"] == lr and g["weight_decay"] == wd:
                         g["params"] += [named[n] for n in names]
                         break
                 else:
                     groups.append({"params": [named[n] for n in names], "lr": lr, "weight_decay": wd})
-        rest = [p for n, p in named.items() if n not in taken]
+                placed += names
+        rest = [n for n in named if n not in taken and n not in frozen and n not in already_added]
         if rest:
-            groups.append({"params": rest, "lr": lr_all, "weight_decay": 0.0})
-        return groups
+            groups.append({"params": [named[n] for n in rest], "lr": lr_all, "weight_decay": 0.0})
+            placed += rest
+        return groups, placed
 
     # ---- resident fast path ---------------------------------------------------------------------------
     def _engine_for(self, groups, lr_ALL, opt):
@@ -91,6 +116,10 @@ class Trainer_SP_regression:
             return None
         model = self.model
         if not hasattr(model, "_gp_params") or any(g["lr"] != lr_ALL for g in groups):
+            return None
+        # the engine updates EVERY parameter of its flat buffer: a stage that freezes some (lr = 0.0 entries,
+        # trainer_base.py:155-179) or leaves some to a later stage must take the torch optimiser
+        if {id(q) for g in groups for q in g["params"]} != {id(q) for q in model.parameters()}:
             return None
         nets, theta_list, blocks = [], [], None
         if not isinstance(model.likelihood, GaussianLinearMean):
@@ -162,48 +191,87 @@ class Trainer_SP_regression:
         return loss
 
     def train(self, epochs, lr_ALL, opt, keep_parameter_groups, lr_groups=None, optimisation_schedule=None):
+        """trainer_base.py:250-361.  keep_parameter_groups=True keeps the optimiser (its groups and moments) across
+        stages and calls: later stages ADD the groups of parameters not yet held, earlier groups take `lr_groups` (or
+        lr_ALL).  keep_parameter_groups=False starts from a fresh optimiser and re-creates it at every stage."""
         if optimisation_schedule is None:
             optimisation_schedule = ([1.0], [None])
         percentages, specifications = optimisation_schedule
         if abs(sum(percentages) - 1.0) > 1e-12:
             raise ValueError("percentages must sum 1, got {}".format(sum(percentages)))
+        if len(percentages) != len(specifications):
+            raise ValueError("Percentages and specifications must have same length")
+        if keep_parameter_groups:
+            if self.optimizer is None and self._engine is None:
+                self._names_added = []
+            elif self.optimizer is not None:
+                if lr_groups is not None and len(lr_groups) != len(self.optimizer.param_groups):
+                    raise ValueError("The provided `lr_groups` {} does not match the number of parameter groups in the "
+                                     "optimizer {}".format(lr_groups, len(self.optimizer.param_groups)))
+                for g, lr_i in zip(self.optimizer.param_groups, lr_groups or [lr_ALL] * len(self.optimizer.param_groups)):
+                    g["lr"] = lr_i
+            elif lr_groups is not None and any(v != lr_ALL for v in lr_groups):
+                raise ValueError("the resident step engine holds one learning rate: pass lr_groups=None (or all equal to "
+                                 "lr_ALL), or set config.use_step_engine = False")
+        else:
+            self.optimizer, self._engine, self._names_added = None, None, []
+        single = len(percentages) == 1
         for per, specs in zip(percentages, specifications):
-            groups = self._param_groups(specs, lr_ALL)
-            if getattr(self, "_engine", None) is None or not keep_parameter_groups:
-                self._engine = self._engine_for(groups, lr_ALL, opt)
-            if self._engine is not None:
-                self._train_resident(self._engine, int(epochs * per), epochs)
+            fresh = not keep_parameter_groups or (self.optimizer is None and self._engine is None)
+            groups, placed = self._param_groups(specs, lr_ALL, () if fresh else self._names_added)
+            n_ep = int(epochs * per)
+            if self._engine is not None and not fresh:
+                if groups:
+                    raise ValueError("the resident step engine already trains every parameter; new groups cannot be added")
+                if self._engine.lr != float(lr_ALL):       # the learning rate is a launch argument of the captured step
+                    self._engine.lr = float(lr_ALL)
+                    self._engine.capture()
+                self._train_resident(self._engine, n_ep, epochs)
                 continue
-            if self.optimizer is None or not keep_parameter_groups:
+            if fresh:
+                self._engine = self._engine_for(groups, lr_ALL, opt) if single else None
+                self._names_added = list(placed) if keep_parameter_groups else []
+                if self._engine is not None:
+                    self._train_resident(self._engine, n_ep, epochs)
+                    continue
                 self.optimizer = return_optimizer(opt, groups, lr_ALL)
-            for ep in range(int(epochs * per)):
-                t0 = time.time()
-                acc = [0.0, 0.0, 0.0]
-                nb = 0
-                for x, y in self.train_loader:
-                    x, y = x.to(cg.device), y.to(cg.device)
-                    assert x.dim() == 2 and y.dim() == 2, "x and y must be (MB,D) and (MB,D')"
-                    self.model.set_is_training(True)
-                    loss = self.ELBO_call(x, y)
-                    self.optimizer.zero_grad()
-                    loss.backward()
-                    self.optimizer.step()
-                    self.model.set_is_training(False)
-                    lv = loss.item()
-                    self.loss_arr.append(lv)
-                    self.ELL_arr.append(self.param_elbo[1].item())
-                    self.KLD_arr.append(self.param_elbo[2].item())
-                    acc[0] += -lv
-                    acc[1] += self.ELL_arr[-1]
-                    acc[2] += self.KLD_arr[-1]
-                    nb += 1
-                self.total_trainer_epochs += 1
-                if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
-                    print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
-                        ep + 1, epochs, acc[0] / nb, acc[1] / nb, acc[2] / nb, time.time() - t0))
+            else:
+                for g in groups:
+                    self.optimizer.add_param_group(g)
+                self._names_added += placed
+            self._train_eager(n_ep, epochs)
         if not keep_parameter_groups:
             self.optimizer = None
             self._engine = None
+
+    def _train_eager(self, n_epochs, epochs_total):
+        """The reference's loop as is: per minibatch ELBO -> zero_grad -> backward -> optimizer.step
+        (trainer_base.py:329-349), autograd through ops.ElboFunction."""
+        for ep in range(n_epochs):
+            t0 = time.time()
+            acc = [0.0, 0.0, 0.0]
+            nb = 0
+            for x, y in self.train_loader:
+                x, y = x.to(cg.device), y.to(cg.device)
+                assert x.dim() == 2 and y.dim() == 2, "x and y must be (MB,D) and (MB,D')"
+                self.model.set_is_training(True)
+                loss = self.ELBO_call(x, y)
+                self.optimizer.zero_grad()
+                loss.backward()
+                self.optimizer.step()
+                self.model.set_is_training(False)
+                lv = loss.item()
+                self.loss_arr.append(lv)
+                self.ELL_arr.append(self.param_elbo[1].item())
+                self.KLD_arr.append(self.param_elbo[2].item())
+                acc[0] += -lv
+                acc[1] += self.ELL_arr[-1]
+                acc[2] += self.KLD_arr[-1]
+                nb += 1
+            self.total_trainer_epochs += 1
+            if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
+                print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
+                    ep + 1, epochs_total, acc[0] / nb, acc[1] / nb, acc[2] / nb, time.time() - t0))
 
     # ---- metrics (trainers_regression.py:108-224, 317-338) ----------------------------------------------
     def performance_metrics(self, X, Y):

@@ -1,7 +1,8 @@
 # diagnostic build of the whole library with -DTGP_STAMPS into tools/probes/stamp/ (see README.md)
-mkdir -p /root/repo/tools/probes/stamp
 set -e
-cd /root/repo/tgp/pytorch_amd/csrc
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)"
+mkdir -p "$ROOT/tools/probes/stamp"
+cd "$ROOT/tgp/pytorch_amd/csrc"
 O=../../../tools/probes/stamp
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DTGP_STAMPS"
 for f in tgp_api tgp_mm tgp_lik tgp_rows tgp_big tgp_kmeans tgp_mlp; do /opt/rocm/bin/hipcc $F -c $f.hip -o $O/$f.o & done
