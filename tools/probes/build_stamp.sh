@@ -9,5 +9,7 @@ for f in tgp_api tgp_mm tgp_lik tgp_rows tgp_big tgp_kmeans tgp_mlp; do /opt/roc
 wait
 for n in 1 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc $F -DTGP_MT=$n -c tgp_rows_inst.hip -o $O/mt$n.o & done
 wait
+for n in 1 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc $F -DTGP_MT=$n -c tgp_rows2_inst.hip -o $O/r2mt$n.o & done
+wait
 cd ../../..
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/probes/stamp/libtgp_hip.so tools/probes/stamp/*.o
