@@ -9,9 +9,19 @@ One "step" = forward ELBO + backward + Adam update on one full Power-sized minib
 code/dsp/trainers/trainer_base.py:337-342), float64 like the reference's main.py.  Default workload =
 BASELINE.json configs[2]: TGP on Power (N=8611 training rows, D=4), M=100, 3-block tanh flow (StepTanhL 3x2),
 S=32 Gauss-Hermite nodes; synthetic seeded data of that shape, data resident in HBM.
-Multi-GPU is weak scaling: every rank owns a Power-sized row shard of a W-times larger minibatch, one RCCL
-all-reduce of the flat [gradient | ELL | KL] buffer per step; `value` counts Power-sized shard-steps per second
-over the whole job.
+Multi-GPU (one process per GPU, torch.distributed over RCCL): rows are sharded, ONE all-reduce of the flat
+[gradient | ELBO, ELL, KL] buffer per step, replicated Adam.  `--scaling weak` (default): every rank owns a
+workload-sized row shard of a W-times larger minibatch, `value` counts workload-sized shard-steps per second over the
+whole job.  `--scaling strong`: the SAME workload's rows are split W ways (north_star's "Power at 1/2/4/8 GPUs"; at
+Power size this cannot scale -- the replicated M x M work and the collective do not shrink -- and the line says what
+it measures), `value` = steps of the whole problem per second.  The documented BASELINE configs[4] line is
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --workload tgp_airline_tanh5x6 --steps 20 --warmup 3        (N = 2 M rows, 250 k per GPU)
+`--capture-allreduce` records the collective inside the HIP graph instead of between two graphs.
+
+Timing: after W warm-up steps the K steps are timed `--repeats` times (default 5), each repeat bracketed by a barrier +
+synchronize and reduced with MAX over ranks; the line reports the MEDIAN repeat (`ms_per_step`, `value`) and the
+spread (`ms_per_step_min`, `ms_per_step_max`).
 
 Extra objects on the JSON line (rank 0):
   roofline      dominant kernel = the fused row kernel k_rows; achieved = algorithmic FLOP per launch
@@ -157,6 +167,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps; the median is reported")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--capture-allreduce", action="store_true", help="capture the collective inside the HIP graph")
+    ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
+                    "--pmc pass of THIS build (tools/probes/pmc_summary.py); without it roofline.traffic is null")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,12 +198,21 @@ def main():
 
     from tgp.pytorch_amd.engine import ElboEngine
 
+    from tgp.pytorch_amd.engine import shard_rows
+
     w = WORKLOADS[args.workload]
-    prob = make_problem(w, seed=rank)              # every rank: its own Power-sized shard, same parameters (seed 0)
-    params = make_problem(w, seed=0)["params"] if rank else prob["params"]
     mlp = make_mlp(w, seed=0) if "mlp" in w else None       # same networks on every rank
-    eng = ElboEngine(prob["X"], prob["Y"], params, N_total=float(w["N"] * world), flow_blocks=prob["program"],
-                     S=w["S"], device=dev, world_size=world, rank=rank, mb_global=w["N"] * world,
+    if args.scaling == "weak":
+        prob = make_problem(w, seed=rank)          # every rank: its own workload-sized shard, same parameters (seed 0)
+        params = make_problem(w, seed=0)["params"] if rank else prob["params"]
+        Xr, Yr, n_global = prob["X"], prob["Y"], w["N"] * world
+    else:
+        prob = make_problem(w, seed=0)             # one problem, rows split W ways
+        params = prob["params"]
+        lo, hi = shard_rows(w["N"], world, rank)
+        Xr, Yr, n_global = prob["X"][lo:hi], prob["Y"][lo:hi], w["N"]
+    eng = ElboEngine(Xr, Yr, params, N_total=float(n_global), flow_blocks=prob["program"],
+                     S=w["S"], device=dev, world_size=world, rank=rank, mb_global=n_global,
                      mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None)
 
     def barrier():
@@ -202,20 +226,25 @@ def main():
         eng.step()
     eng.check_status()
     if not args.no_graph:
-        eng.capture()
+        eng.capture(with_allreduce=True if (args.capture_allreduce and world > 1) else None)
         run = eng.replay
     for _ in range(args.warmup):
         run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t[0])
+    dts = []
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t[0])
+        dts.append(dt)
+    dts.sort()
+    dt = dts[len(dts) // 2]                       # median repeat: the reported K steps
     eng.check_status()
     elbo, ell, kl = eng.scalars()
     if not (elbo == elbo):
@@ -235,29 +264,35 @@ def main():
         torch.cuda.synchronize()
         ks = sorted(a.elapsed_time(b) for a, b in evs)
         k_ms = sum(ks) / len(ks)
-        flop = rows_kernel_flops(w)
+        flop = rows_kernel_flops(dict(w, N=int(Xr.shape[0])))      # this rank's rows
         big = w["M"] > 128
         kname = ("rows phase of the general-M path: per 16k-row chunk K_NM tile kernel + 6 k_gemm launches (4 triangular, "
                  "SYRK, statistics) + flow quadrature" if big else
                  "k_rows (fused K_NM + 4 triangular GEMMs + flow quadrature + SYRK)")
         achieved = flop / (k_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_rows_traffic.json")
-        if os.path.exists(tpath):
+        traffic = None                     # measured by a separate --pmc pass of the same build, never a committed constant
+        if args.traffic_json and os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                traffic = json.load(open(args.traffic_json)).get(args.workload)
             except Exception:
                 traffic = None
+        units = world if args.scaling == "weak" else 1
+        pg = {"world_size": torch.distributed.get_world_size() if world > 1 else 1,
+              "backend": torch.distributed.get_backend() if world > 1 else None,
+              "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+              "allreduce": ("none" if world == 1 else ("in-graph" if eng.graph == "full" else "between two graphs")),
+              "allreduce_doubles": eng.fp.n + eng.fp.extra}
         result = {
             # BASELINE.json's metric string for the configuration it is quoted on; other workloads say what they are
             "metric": ("ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32" if args.workload == "tgp_power_tanh3x2"
                        else "ELBO-steps/sec (N x M kernel + chol + flow), workload %s" % args.workload),
-            "value": world * args.steps / dt, "unit": "ELBO-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": units * args.steps / dt, "unit": "ELBO-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "rows_per_gpu": w["N"], "D": w["D"], "M": w["M"], "S": w["S"],
-                       "flow": w["flow"], "global_rows_per_step": w["N"] * world, "parallelism": "row-shard x%d" % world,
-                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo},
+            "repeats": len(dts), "ms_per_step_min": 1e3 * dts[0] / args.steps, "ms_per_step_max": 1e3 * dts[-1] / args.steps,
+            "config": {"workload": args.workload, "rows_per_gpu": int(Xr.shape[0]), "D": w["D"], "M": w["M"], "S": w["S"],
+                       "flow": w["flow"], "global_rows_per_step": n_global, "parallelism": "row-shard x%d" % world,
+                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo, "process_group": pg},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
