@@ -252,6 +252,15 @@ int tgp_mlp_forward_f64(const tgp_mlp* mlp, const double* X, const double* W, co
 int tgp_mlp_backward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev,
                          const double* g_out, double* g_W, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Minibatch rows of a data set resident in HBM -- replaces the per-step host collation + H2D copy of the reference's
+ * DataLoader (dsp/data/data.py:86-88, trainers/trainer_base.py:330): Xb[r] = X[index[cursor + offset + r]] and Yb
+ * likewise for r < nrows (index NULL: the stored order; entries are row numbers < N).  `cursor_dev` = int32[2]
+ * {position in the epoch, ticket}, both 0 at the start of an epoch; the launch advances the position by `advance`
+ * and wraps it to 0 when it reaches `wrap`, so a captured launch serves batch after batch under hipGraph replay.
+ * `offset` selects a rank's shard inside the batch. */
+int tgp_gather_rows_f64(const double* X, const double* Y, int32_t N, int32_t D, const int32_t* index, int32_t* cursor_dev,
+                        int32_t offset, int32_t nrows, int32_t advance, int32_t wrap, double* Xb, double* Yb, void* stream);
+
 /* Adam on a flat parameter buffer (torch.optim.Adam semantics, dsp/trainers/optimizers.py:12; L2 weight decay
  * added to the gradient as torch does).  `maximize` != 0 ascends (gradients here are of +ELBO). */
 int tgp_adam_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,

@@ -362,6 +362,20 @@ int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, doubl
                          static_cast<hipStream_t>(stream));
 }
 
+int tgp_gather_rows_f64(const double* X, const double* Y, int32_t N, int32_t D, const int32_t* index, int32_t* cursor_dev,
+                        int32_t offset, int32_t nrows, int32_t advance, int32_t wrap, double* Xb, double* Yb, void* stream) {
+  if (!X) return -1;
+  if (!Y) return -2;
+  if (N < 1 || D < 1) return -3;
+  if (!cursor_dev) return -6;
+  if (offset < 0 || nrows < 1 || nrows > N) return -8;
+  if (advance < 0 || wrap < 1) return -9;
+  if (!Xb) return -11;
+  if (!Yb) return -12;
+  return launch_gather_rows(X, Y, N, D, index, cursor_dev, offset, nrows, advance, wrap, Xb, Yb,
+                            static_cast<hipStream_t>(stream));
+}
+
 int tgp_adam_dev_groups_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n,
                             double lr, double beta1, double beta2, double eps, int64_t n_plain, double weight_decay_tail,
                             int32_t* step_dev, int32_t maximize, void* stream) {

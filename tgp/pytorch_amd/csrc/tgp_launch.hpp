@@ -77,5 +77,7 @@ int launch_adam_dev(double* params, const double* grads, double* exp_avg, double
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
                     hipStream_t st, int64_t n_plain = 0);
 size_t lik_workspace_doubles(int N, int P, int RP);
+int launch_gather_rows(const double* X, const double* Y, int N, int D, const int32_t* index, int32_t* cursor, int offset,
+                       int nrows, int advance, int wrap, double* Xb, double* Yb, hipStream_t st);
 
 }  // namespace tgp

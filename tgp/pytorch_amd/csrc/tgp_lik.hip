@@ -296,6 +296,49 @@ __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Minibatch rows of a data set that stays resident in HBM (the reference's DataLoader re-collates the rows on the host
+// and copies them every step, dsp/data/data.py:86-88, trainers/trainer_base.py:330):
+//   Xb[r] = X[index[cursor + offset + r]],  Yb[r] = Y[...]     r < nrows   (index == NULL: the stored order)
+// `cursor` = int32[2] {position in the epoch, ticket} on the device: every workgroup reads the position before it
+// takes a ticket, the last one advances it (wrapping to 0 at `wrap`), so a captured launch walks through the epoch
+// replay after replay without the host touching it.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ X, const double* __restrict__ Y, int N, int D,
+                                                      const int32_t* __restrict__ index, int32_t* __restrict__ cursor,
+                                                      int offset, int nrows, int advance, int wrap,
+                                                      double* __restrict__ Xb, double* __restrict__ Yb) {
+  const int c0 = cursor[0];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < (long long)nrows * (D + 1)) {
+    const int r = (int)(i / (D + 1)), d = (int)(i % (D + 1));
+    int src = c0 + offset + r;
+    src = src < N ? src : N - 1;
+    if (index != nullptr) src = index[src];
+    src = src < 0 ? 0 : (src < N ? src : N - 1);
+    if (d < D) Xb[(size_t)r * D + d] = X[(size_t)src * D + d];
+    else Yb[r] = Y[src];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = atomicAdd(&cursor[1], 1);
+    if (t == (int)gridDim.x - 1) {
+      cursor[1] = 0;
+      const int nx = c0 + advance;
+      cursor[0] = nx >= wrap ? 0 : nx;
+    }
+  }
+}
+
+int launch_gather_rows(const double* X, const double* Y, int N, int D, const int32_t* index, int32_t* cursor, int offset,
+                       int nrows, int advance, int wrap, double* Xb, double* Yb, hipStream_t st) {
+  const long long n = (long long)nrows * (D + 1);
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, Y, N, D, index, cursor, offset,
+                     nrows, advance, wrap, Xb, Yb);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* lvn, double scale,

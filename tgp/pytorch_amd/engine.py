@@ -87,10 +87,11 @@ class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
                  eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
                  kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True,
-                 jitter_ladder=1e-8):
+                 jitter_ladder=1e-8, share=None):
         """`mlp` (ops.MlpSpec) + `mlp_weights` (packed, nnets * weights_per_net): input-dependent flow (ID_TGP) whose
         per-row parameters come from the HIP MLP kernels inside the step; `nn_weight_decay` is the reference's Adam
-        group for the 'NNets' parameters (main.py:276-288)."""
+        group for the 'NNets' parameters (main.py:276-288).  `share` = another ElboEngine of the same model whose flat
+        parameter / gradient / Adam buffers and step counter this one uses (two batch sizes of one training run)."""
         self.lib = L.load()
         self.device = torch.device(device)
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
@@ -109,7 +110,7 @@ class ElboEngine:
         tensors["raw_ls"] = tensors["raw_ls"].reshape(-1)
         tensors["raw_os"] = tensors["raw_os"].reshape(-1)
         tensors["lvn"] = tensors["lvn"].reshape(-1)
-        self.fp = FlatParams(tensors, self.device)
+        self.fp = FlatParams(tensors, self.device) if share is None else share.fp
         self.M = self.fp.sizes["m"]
         self.flow = None
         self.S = int(S) if S else 1
@@ -120,8 +121,10 @@ class ElboEngine:
             self.flow = ops.FlowSpec(flow_blocks, P, RP, self.device)
         self.g_rowp = torch.zeros_like(self.rowp) if self.rowp is not None else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
-        self.step_dev = torch.zeros(2, dtype=torch.int32, device=self.device)
-        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=self.device) if share is None else share.step_dev
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device) if share is None else share.status
+        self.pre_step = None        # callables launched (and captured) before / after the step: the minibatch gather
+        self.post_step = None
         mbg = mb_global if mb_global is not None else self.N
         scale = float(N_total) / float(mbg)
         fp = self.fp
@@ -219,9 +222,13 @@ class ElboEngine:
     def step(self):
         if self.graph == "rotated":      # the captured unit straddles two steps: eager steps would repeat half of one
             return self.replay()
+        if self.pre_step is not None:
+            self.pre_step()
         self.forward_backward()
         self.allreduce()
         self.adam()
+        if self.post_step is not None:
+            self.post_step()
 
     # ---- HIP graph ----------------------------------------------------------------------------------
     def capture(self, with_allreduce=None):
@@ -230,7 +237,9 @@ class ElboEngine:
         if not self._warm:
             self.forward_backward()          # first launch sets kernel attributes; must happen outside capture
         torch.cuda.synchronize()
-        if self.mlp is not None and self.world_size == 1 and self.pipeline_steps:
+        pre = self.pre_step if self.pre_step is not None else (lambda: None)
+        post = self.post_step if self.post_step is not None else (lambda: None)
+        if self.mlp is not None and self.world_size == 1 and self.pipeline_steps and self.pre_step is None:
             # Rotated unit.  The long pole of an ID_TGP step is the MLP backward (97 us), and nothing of step t depends on it
             # except the network weights' own Adam update and the NEXT step's MLP forward.  So the captured unit starts
             # at the row kernel:   main: rows(t) -> M x M adjoint(t) -> Adam(GP params) -> prepare(t+1)
@@ -263,18 +272,22 @@ class ElboEngine:
             # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1):
+                pre()
                 self.forward_backward()
                 pre_reduce(self.fp.grad, self.fp.n, self.world_size)
             with torch.cuda.graph(self.g2):
                 post_reduce(self.fp.grad, self.fp.n)
                 self.adam()
+                post()
             self.graph = "split"
         else:
             self.g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1):
+                pre()
                 self.forward_backward()
                 self.allreduce()
                 self.adam()
+                post()
             self.graph = "full"
 
     def replay(self):
@@ -304,3 +317,97 @@ class ElboEngine:
     def scalars(self):
         o = self.fp.out.cpu()
         return float(o[0]), float(o[1]), float(o[2])
+
+    def set_lr(self, lr):
+        self.lr = float(lr)          # a launch argument: re-capture afterwards
+
+
+class MinibatchEngine:
+    """The reference's minibatch loop (trainers/trainer_base.py:322-349 over a DataLoader(batch_size, shuffle,
+    drop_last=False), code/main.py:74) with the data set resident in HBM and every step replayed from a HIP graph.
+
+    * X, Y stay on the device; one epoch's row order is an int32 index buffer written once per epoch (`set_order`);
+    * a captured step = [tgp_gather_rows_f64: batch rows -> fixed batch buffers, device cursor advanced by the launch]
+      -> the ElboEngine step (ELBO + backward + Adam) on those buffers;
+    * the ragged last batch of an epoch (N mod B rows) has its own engine + graph on the same flat parameter / Adam
+      buffers (the ELL scale N_total / MB follows the batch's own size, sparse_MF_SP.py:623-626);
+    * the three logged scalars of every step are copied device-to-device into a history buffer; nothing syncs.
+    With world_size > 1 each rank gathers and processes its row shard of every batch (one all-reduce per step)."""
+
+    def __init__(self, X, Y, params, N_total, batch_size, device="cuda:0", world_size=1, rank=0, **engine_kw):
+        self.device = torch.device(device)
+        self.lib = L.load()
+        self.X = X.to(self.device, torch.float64).contiguous()
+        self.Y = Y.reshape(-1).to(self.device, torch.float64).contiguous()
+        self.N, self.D = self.X.shape
+        self.B = int(min(batch_size, self.N))
+        self.nfull, self.rest = divmod(self.N, self.B)
+        self.steps_per_epoch = self.nfull + (1 if self.rest else 0)
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.index = torch.arange(self.N, dtype=torch.int32, device=self.device)
+        self.cursor = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.has_order = False
+        lo, hi = shard_rows(self.B, world_size, rank)
+        self.Xb = torch.zeros(hi - lo, self.D, dtype=torch.float64, device=self.device)
+        self.Yb = torch.zeros(hi - lo, dtype=torch.float64, device=self.device)
+        self.full = ElboEngine(self.Xb, self.Yb, params, N_total, device=self.device, world_size=world_size, rank=rank,
+                               mb_global=self.B, **engine_kw)
+        self.full.pipeline_steps = False
+        self.full.pre_step = self._gather(lo, hi - lo, self.B)
+        self.last = None
+        if self.rest:
+            lo2, hi2 = shard_rows(self.rest, world_size, rank)
+            kw = dict(engine_kw)
+            kw.pop("mlp_weights", None)
+            self.last = ElboEngine(self.Xb[:hi2 - lo2], self.Yb[:hi2 - lo2], params, N_total, device=self.device,
+                                   world_size=world_size, rank=rank, mb_global=self.rest, share=self.full,
+                                   mlp_weights=(self.full.fp.view("nn") if self.full.mlp is not None else None), **kw)
+            self.last.pipeline_steps = False
+            self.last.pre_step = self._gather(lo2, hi2 - lo2, self.rest)
+        self.fp = self.full.fp
+
+    def _gather(self, offset, nrows, advance):
+        def run():
+            rc = self.lib.tgp_gather_rows_f64(L.ptr(self.X), L.ptr(self.Y), self.N, self.D,
+                                              L.ptr(self.index) if self.has_order else None, L.ptr(self.cursor), offset, nrows,
+                                              advance, self.N, L.ptr(self.Xb), L.ptr(self.Yb), L.stream_ptr())
+            L.check(rc, "tgp_gather_rows_f64")
+        return run
+
+    def set_order(self, perm=None):
+        """Row order of the coming epoch (a permutation of range(N), host or device; None = stored order).  Must be
+        called before capture() with the kind of order (permuted or not) the run will use: the index pointer is a launch
+        argument of the captured gather."""
+        if perm is None:
+            if self.has_order:
+                self.index.copy_(torch.arange(self.N, dtype=torch.int32, device=self.device))
+        else:
+            self.has_order = True
+            self.index.copy_(perm.to(torch.int32), non_blocking=True)
+        self.cursor.zero_()
+
+    def capture(self):
+        self.full.capture()
+        if self.last is not None:
+            self.last.capture()
+
+    def run_epoch(self, hist=None, row0=0, replay=True):
+        """One pass over the data: nfull full batches + the ragged one.  hist[row0 + i] <- (ELBO, ELL, KL) of step i."""
+        for i in range(self.steps_per_epoch):
+            eng = self.full if i < self.nfull else self.last
+            (eng.replay if (replay and eng.graph is not None) else eng.step)()
+            if hist is not None:
+                hist[row0 + i].copy_(eng.fp.out[:3])
+        return self.steps_per_epoch
+
+    def check_status(self):
+        self.full.check_status()
+
+    @property
+    def lr(self):
+        return self.full.lr
+
+    def set_lr(self, lr):
+        self.full.set_lr(lr)
+        if self.last is not None:
+            self.last.set_lr(lr)

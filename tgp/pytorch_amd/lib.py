@@ -79,6 +79,8 @@ _SIGS = {
     "tgp_mlp_workspace_bytes": (C.c_size_t, [C.POINTER(TgpMlp)]),
     "tgp_mlp_forward_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp]),
     "tgp_mlp_backward_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_gather_rows_f64": (C.c_int, [_dp, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp,
+                                      _dp, _dp]),
     "tgp_adam_dev_groups_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_int64, C.c_double, _dp, C.c_int32, _dp]),
     "tgp_adam_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -106,13 +106,13 @@ class Trainer_SP_regression:
         The model's nn.Parameters are re-pointed at the engine's flat buffer, so the modules stay the parameter holders
         and everything downstream (metrics, prediction, state_dict) sees the trained values.  Returns None otherwise."""
         from .data import DeviceLoader
-        from .engine import ElboEngine
+        from .engine import ElboEngine, MinibatchEngine
         from .flow import compile_flow, mlp_spec
         from .likelihoods import GaussianLinearMean
         if not getattr(cg, "use_step_engine", True) or opt != "adam":
             return None
         ld = self.train_loader
-        if not isinstance(ld, DeviceLoader) or len(ld) != 1 or not ld.X.is_cuda or ld.Y.shape[1] != 1:
+        if not isinstance(ld, DeviceLoader) or not ld.X.is_cuda or ld.Y.shape[1] != 1:
             return None
         model = self.model
         if not hasattr(model, "_gp_params") or any(g["lr"] != lr_ALL for g in groups):
@@ -142,10 +142,16 @@ class Trainer_SP_regression:
         if theta_list:
             params["theta"] = torch.stack([p.detach().reshape(()) for p in theta_list])
         W = torch.cat([p.detach().reshape(-1) for p in nn_params]) if nn_params else None
-        eng = ElboEngine(ld.X, ld.Y, params, float(model.N), flow_blocks=blocks, S=getattr(model, "quad_points", None),
-                         lr=lr_ALL, device=ld.X.device, kernel=model.covariance_function.hip_kernel, mlp=mspec,
-                         mlp_weights=W, nn_weight_decay=wd, mlp_training=True,
-                         jitter_ladder=cg.global_jitter if cg.global_jitter is not None else 1e-8)
+        kw = dict(flow_blocks=blocks, S=getattr(model, "quad_points", None), lr=lr_ALL,
+                  kernel=model.covariance_function.hip_kernel, mlp=mspec, mlp_weights=W, nn_weight_decay=wd, mlp_training=True,
+                  jitter_ladder=cg.global_jitter if cg.global_jitter is not None else 1e-8)
+        if len(ld) == 1:
+            eng = ElboEngine(ld.X, ld.Y, params, float(model.N), device=ld.X.device, **kw)
+        else:
+            # several minibatches per epoch (the Airline recipe, main.py:74): rows gathered on the device by index,
+            # one captured step per batch size (full batches + the ragged last one), see engine.MinibatchEngine
+            eng = MinibatchEngine(ld.X, ld.Y, params, float(model.N), ld.batch_size, device=ld.X.device, **kw)
+            eng.has_order = bool(ld.shuffle)
         # the modules' parameters become views of the engine's flat buffer
         fp, k = eng.fp, model.covariance_function
         with torch.no_grad():
@@ -165,21 +171,30 @@ class Trainer_SP_regression:
         return eng
 
     def _train_resident(self, eng, n_epochs, epochs_total):
-        hist = torch.empty(max(n_epochs, 1), 3, dtype=torch.float64, device=eng.device)
+        from .engine import MinibatchEngine
+        mb = isinstance(eng, MinibatchEngine)
+        spe = eng.steps_per_epoch if mb else 1          # optimiser steps per epoch
+        hist = torch.empty(max(n_epochs * spe, 1), 3, dtype=torch.float64, device=eng.device)
         t0 = time.time()
         last = 0
         for ep in range(n_epochs):
-            eng.replay()
-            hist[ep].copy_(eng.fp.out[:3])          # device-to-device, no synchronisation
+            if mb:
+                # the loader's own permutation stream (torch RandomSampler semantics), written to the device once per
+                # epoch; the batches are then gathered by index inside the captured steps
+                eng.set_order(self.train_loader.epoch_permutation())
+                eng.run_epoch(hist, ep * spe)
+            else:
+                eng.replay()
+                hist[ep].copy_(eng.fp.out[:3])          # device-to-device, no synchronisation
             self.total_trainer_epochs += 1
             if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
-                h = hist[last:ep + 1].mean(0).cpu()     # the only host sync: once per `validate_each` epochs
+                h = hist[last * spe:(ep + 1) * spe].mean(0).cpu()     # the only host sync: once per `validate_each` epochs
                 eng.check_status()                      # a failed Cholesky surfaces here, not thousands of epochs later
                 print("| Epoch [{}/{}] ELBO {:.5f} ELL {:.5f} KLD {:.5f} ({:.3f}s)".format(
                     ep + 1, epochs_total, float(h[0]), float(h[1]), float(h[2]), time.time() - t0))
                 t0, last = time.time(), ep + 1
         eng.check_status()
-        h = hist[:n_epochs].cpu()
+        h = hist[:n_epochs * spe].cpu()
         self.loss_arr += (-h[:, 0]).tolist()
         self.ELL_arr += h[:, 1].tolist()
         self.KLD_arr += h[:, 2].tolist()
@@ -224,7 +239,7 @@ class Trainer_SP_regression:
                 if groups:
                     raise ValueError("the resident step engine already trains every parameter; new groups cannot be added")
                 if self._engine.lr != float(lr_ALL):       # the learning rate is a launch argument of the captured step
-                    self._engine.lr = float(lr_ALL)
+                    self._engine.set_lr(float(lr_ALL))
                     self._engine.capture()
                 self._train_resident(self._engine, n_ep, epochs)
                 continue
