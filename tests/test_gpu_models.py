@@ -365,7 +365,7 @@ def test_adam_kernel_matches_torch_adam():
     assert rel_err(p.cpu(), ref.detach()) < 1e-14
 
 
-@pytest.mark.parametrize("flow", ["tanh3x2", "sal2", None])
+@pytest.mark.parametrize("flow", ["tanh3x2", "sal2", None, "idsal3"])
 def test_full_size_properties(flow):
     """At the BASELINE size (8611 x 4, M = 100, S = 32) the oracle is too slow to be the checker for every run, so
     check size-independent properties: row-shard additivity (the multi-GPU contract), run-to-run bit
@@ -374,21 +374,27 @@ def test_full_size_properties(flow):
     prob = orc.synthetic_problem(8611, 4, 100, seed=0, flow=flow, S=32)
     p = {k: v.to(DEV) for k, v in prob["params"].items()}
     X, Y = prob["X"].to(DEV), prob["Y"].to(DEV)
-    spec = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, DEV) if flow else None
+    rowp = prob["rowp"].to(DEV) if prob.get("rowp") is not None else None      # ID flow: per-row (a_n, b_n) columns
+    RP = rowp.shape[1] if rowp is not None else 0
+    spec = ops.FlowSpec(prob["program"], p["theta"].numel(), RP, DEV) if flow else None
     th = p.get("theta")
 
-    def run(Xs, Ys, kl_scale=1.0, mbg=None):
-        out, g, st, _ = ops.elbo_step(Xs, Ys, p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"],
+    def run(lo, hi, kl_scale=1.0, mbg=None):
+        out, g, st, _ = ops.elbo_step(X[lo:hi], Y[lo:hi], p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"],
                                       p["log_var_noise"], 8611.0, flow=spec, theta=th, S=32, kl_scale=kl_scale,
-                                      mb_global=mbg)
+                                      mb_global=mbg, rowp=rowp[lo:hi].contiguous() if rowp is not None else None)
         assert int(st[0]) == 0
         return out.clone(), {k: t.clone() for k, t in g.items()}
-    full, gfull = run(X, Y)
-    again, gagain = run(X, Y)
+    full, gfull = run(0, 8611)
+    again, gagain = run(0, 8611)
     assert torch.equal(full, again) and all(torch.equal(gfull[k], gagain[k]) for k in gfull)      # bit reproducible
-    parts = [run(X[lo:hi], Y[lo:hi], kl_scale=0.25, mbg=8611) for lo, hi in ((0, 2000), (2000, 4311), (4311, 6000), (6000, 8611))]
+    spans = ((0, 2000), (2000, 4311), (4311, 6000), (6000, 8611))
+    parts = [run(lo, hi, kl_scale=0.25, mbg=8611) for lo, hi in spans]
     assert rel_err(sum(o[1] for o, _ in parts).cpu(), full[1].cpu()) < 1e-12                      # ELL additive
     for k in gfull:
+        if k == "rowp":       # per-row gradients: each shard produces its own rows
+            assert rel_err(torch.cat([g[k] for _, g in parts]).cpu(), gfull[k].cpu()) < 1e-9
+            continue
         assert rel_err(sum(g[k] for _, g in parts).cpu(), gfull[k].cpu()) < 1e-9, k                # gradients additive
     assert abs(float(full[0] - (full[1] - full[2]))) < 1e-9 * abs(float(full[0]))
     if flow == "sal2":
@@ -569,3 +575,56 @@ def test_device_jitter_ladder_inside_the_captured_step():
                                            p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], 128.0, jitter=1e-8)
     assert torch.equal(e1.fp.out[:3].cpu(), out[:3].cpu())
     assert torch.equal(e1.fp.gview("Z").cpu(), grads["Z"].cpu())
+
+
+def test_input_dependent_initialiser_runs_on_the_hip_mlp_kernels():
+    """initializers.find_forward_params_input_dependent_flow (code/dsp/initializers/initializers.py:111-182): the epoch
+    (MLP forward -> d loss -> MLP backward -> Adam) on the HIP kernels.  One epoch with dropout off against torch autograd
+    of FLOW.forward_initializer + torch.optim.Adam; then the captured loop drives the nets to the scalars (dropout on)."""
+    from tgp.pytorch_amd.data import DeviceLoader
+    from tgp.pytorch_amd.flow import instance_flow, mlp_spec
+    from tgp.pytorch_amd.flows import SAL
+    from tgp.pytorch_amd.initializers import IdInitEngine, find_forward_params_input_dependent_flow, id_nets_and_targets
+
+    def make():
+        torch.manual_seed(3)
+        f = instance_flow(SAL(3, input_dependent=True, input_dim=4, num_hidden_layers=2, batch_norm=0, dropout=0.25,
+                              hidden_dim=50, hidden_activation="relu", inference="MC_dropout"))
+        with torch.no_grad():                      # distinct targets per block so that a mix-up of columns shows
+            for k, fl in enumerate(f.flow_arr):
+                if hasattr(fl, "NNets_a"):
+                    fl.a.fill_(0.1 * k)
+                    fl.b.fill_(1.0 + 0.05 * k)
+        return f.to(DEV)
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(2000, 4, generator=g, dtype=torch.float64).to(DEV)
+    # (a) one epoch, dropout off: loss, and the weights after one Adam step, against torch
+    ref = make()
+    ref.eval()
+    opt = torch.optim.Adam([p for p in ref.parameters()], lr=0.01)
+    loss = ref.forward_initializer(X)
+    loss.backward()
+    opt.step()
+    hipf = make()
+    nets, targets = id_nets_and_targets(hipf)
+    assert len(nets) == 6
+    spec = mlp_spec(nets, seed=0)
+    eng = IdInitEngine(X, nets, targets, spec, lr=0.01)
+    eng.d = spec.struct(X.shape[0], False)          # dropout off for the comparison
+    got = eng.run(1)
+    assert abs(got - float(loss)) < 1e-10 * abs(float(loss))
+    eng.write_back()
+    for a, b in zip(hipf.parameters(), ref.parameters()):
+        assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-9
+    # (b) the entry point: 400 epochs with dropout, captured; the nets end near their targets, the scalars are switched off
+    f2 = make()
+    loader = DeviceLoader(X, torch.zeros(2000, 1, dtype=torch.float64), 10000, shuffle=True, device=DEV)
+    f2, last = find_forward_params_input_dependent_flow(loader, FLOW=f2, num_epochs=400, noise_var=0.0)
+    assert all(fl.parameters_are_turn_off for fl in f2.flow_arr if hasattr(fl, "NNets_a"))
+    f2.eval()
+    with torch.no_grad():
+        for k, fl in enumerate(f2.flow_arr):
+            if hasattr(fl, "NNets_a"):
+                assert float((fl.NNets_a(X) - 0.1 * k).abs().mean()) < 0.05
+                assert float((fl.NNets_b(X) - (1.0 + 0.05 * k)).abs().mean()) < 0.05
+    assert last < 0.2
