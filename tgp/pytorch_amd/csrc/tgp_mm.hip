@@ -139,6 +139,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #define PSTAMP(i) do { } while (0)
 #define WSTAMP(i) do { } while (0)
 #endif
+  // Wave 0 runs the critical chain (issue-bound: potrf_trtri16) and shares its SIMD with wave 4 (a workgroup's waves
+  // go to the SIMDs cyclically): wave 4 stays idle in this block so that the chain has the SIMD to itself; the six
+  // waves on the other three SIMDs are the helpers (hw = 0..5).
+  constexpr int NH = PREP_THREADS / 64 - 2;
+  const int hw = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
   const int LD = MP + 1;
   double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
   double* Dt = sm + (size_t)MP * LD;         // MT x 256: inverses of the diagonal tiles (row-major, zero above diag)
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // critical chain, instead of all of K_MM before the first pivot.
   auto fill_block = [&](int c, int r0, int r1) {
     const int n = (r1 - r0) * 16;
-    for (int e = tid - 64; e < n; e += PREP_THREADS - 64) {
+    if (hw < 0) return;
+    for (int e = hw * 64 + lane; e < n; e += NH * 64) {
       const int rr = r0 + (e >> 4), cc = 16 * c + (e & 15);
       if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
     }
@@ -316,20 +322,22 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         WSTAMP(4);
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
       }
+    } else if (hw < 0) {
+      // wave 4: idle (see above)
     } else if (j == 0) {
       fill_block(0, 16, MP);  // tile (0,0) is wave 0's
       if (MT > 1) fill_block(1, 16, 32);
     } else {
       // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2  (at most MT-2 <= 6 tiles for 7 waves)
       const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
-      for (int t = wave - 1; t < npanel + (j - 1); t += PREP_THREADS / 64 - 1) {
+      for (int t = hw; t < npanel + (j - 1); t += NH) {
         if (t < npanel) panel_tile(j + 1 + t, j - 1);
         else inv_tile(j - 1, t - npanel);
       }
       if (j < MT) fill_block(j, 16 * (j + 1), MP);                      // rest of block j: read from iteration j+1 on
       if (j + 1 < MT) fill_block(j + 1, 16 * (j + 1), 16 * (j + 2));     // diagonal tile (j+1, j+1): wave 0, iteration j+1
       if (j >= 2)
-        for (int tj = wave - 1; tj <= j - 2; tj += PREP_THREADS / 64 - 1) write_tile(j - 2, tj);
+        for (int tj = hw; tj <= j - 2; tj += NH) write_tile(j - 2, tj);
     }
     __syncthreads();
     PSTAMP(j < 4 ? j : 3);
