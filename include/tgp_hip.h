@@ -90,7 +90,8 @@ typedef struct tgp_model {
   double jitter_ladder; /* > 0: psd_safe_cholesky's retry ladder (dsp/utils.py:256-269) runs ON THE DEVICE -- a failed
                       factorisation is repeated with jitter_ladder * 10^i, i = 0..2, added to diag(K_MM); status[2] = the
                       level that succeeded (1..3) or 0.  0: no retry, status[0] reports the pivot (host ladder:
-                      ops.elbo_step_safe).  Fused path (M <= 128, scale_rbf) only; ignored elsewhere.  */
+                      ops.elbo_step_safe).  Fused path: inside k_prep_a; general-M path: one extra launch that returns
+                      at once unless the blocked factorisation failed (then a single-workgroup refactorisation).  */
   /* parameters (reference nn.Parameter names in brackets) */
   const double* Z;             /* (M,D)   [Z]                                               */
   const double* raw_ls;        /* (D)     [covariance_function.base_kernel.raw_lengthscale] */

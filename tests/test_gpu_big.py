@@ -285,3 +285,38 @@ def test_big_jitter_ladder_recovers():
     assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(t).all()) for t in grads.values())
     out2, grads2, status2, _ = ops.elbo_step(*args, jitter=1e-8)
     assert int(status2[0]) == 0 and torch.equal(out.cpu(), out2.cpu())
+
+
+def test_device_jitter_ladder_on_the_general_path():
+    """M = 200 with duplicated inducing points: the blocked factorisation reports the pivot; with md.jitter_ladder > 0
+    (what the resident engine sets) the step repeats the factorisation on the device with 1e-8 * 10^i on the diagonal
+    (dsp/utils.py:256-269), status[2] names the level, the engine warns lazily, and the result agrees with the step
+    launched with that jitter up front -- eagerly and replayed from a HIP graph."""
+    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd import ops
+    from tgp.pytorch_amd.engine import ElboEngine
+    dev = _dev()
+    prob = orc.synthetic_problem(700, 4, 200, seed=1, flow="sal2", S=8)
+    prob["params"]["Z"][1] = prob["params"]["Z"][0]
+    e0 = ElboEngine(prob["X"], prob["Y"], prob["params"], 700.0, flow_blocks=prob["program"], S=8, device=dev, jitter_ladder=0.0)
+    e0.elbo()
+    torch.cuda.synchronize()
+    assert int(e0.status[0]) > 0                              # no ladder: LAPACK-style info of the failing pivot
+    p = {k: v.to(dev) for k, v in prob["params"].items()}
+    flow = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, dev)
+    ref, _, st, _ = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"], p["raw_outputscale"],
+                                  p["m"], p["Lam"], p["log_var_noise"], 700.0, flow=flow, theta=p["theta"], S=8, jitter=1e-8)
+    assert int(st[0]) == 0
+    for graph in (False, True):
+        e1 = ElboEngine(prob["X"], prob["Y"], prob["params"], 700.0, flow_blocks=prob["program"], S=8, device=dev,
+                        jitter_ladder=1e-8)
+        if graph:
+            e1.capture()
+            e1.fp.data.copy_(e0.fp.data)                      # capture() ran one forward/backward; parameters unchanged
+        e1.elbo()
+        with pytest.warns(ops.NumericalWarning):
+            e1.check_status()
+        assert int(e1.status[0]) == 0 and int(e1.status[2]) == 1
+        assert bool(torch.isfinite(e1.fp.grad).all())
+        # K_MM + 1e-8 I has condition ~1e8: two correct factorisations agree to ~1e-8 on the ELBO, not bitwise
+        assert rel_err(e1.fp.out[:3].cpu(), ref[:3].cpu()) < 1e-6

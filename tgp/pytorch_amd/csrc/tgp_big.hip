@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void k_big_hdr(BigPlan p, tgp_model md, double
     hdr[H_SIG_OS] = sigmoid_d(md.raw_os[0]);
     status[0] = 0;
     status[1] = 0;
+    status[2] = 0;
   }
   // zero the adjoints of the padding rows of the last chunk
   for (int i = p.N + tid; i < p.NP; i += 256) { ws[p.mub + i] = 0.0; ws[p.vb + i] = 0.0; }
@@ -730,6 +731,78 @@ static int gemm_mm(bool ta, bool tb, GemmArgs g, const BigPlan& p, double* ws, h
   LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// psd_safe_cholesky's retry ladder (dsp/utils.py:256-269) for the general-M path, ON THE DEVICE: a captured step
+// cannot ask the host to retry.  One launch after the blocked factorisation; it returns at once unless that
+// factorisation reported a non-positive pivot (status[0] != 0) -- the rare case, served by a plain single-workgroup
+// code path: K_MM + jitter_ladder * 10^i (i = 0..2) is refactorised column by column in global memory (right-looking,
+// one barrier pair per column) and inverted by forward substitution (thread c owns column c of J = L^-1), tens of
+// milliseconds at M = 1000.  status[2] = ladder level that succeeded, status[0] = 0 then; otherwise the last failing
+// pivot stays in status[0] (the reference raises after its third retry).
+// ---------------------------------------------------------------------------------------------------
+#define LADDER_THREADS 1024
+__global__ __launch_bounds__(LADDER_THREADS) void k_big_ladder(BigPlan p, tgp_model md, double* __restrict__ ws,
+                                                               int32_t* __restrict__ status) {
+  if (status[0] == 0 || status[1] != 0 || !(md.jitter_ladder > 0.0)) return;
+  const int tid = threadIdx.x, MP = p.MP, M = p.M;
+  const int ty = tid >> 6, tx = tid & 63;
+  double* Lm = ws + p.Lm;
+  double* J = ws + p.J;
+  const double* __restrict__ K = ws + p.Kmm;
+  __shared__ int s_bad;
+  int level = 0, bad = 0;
+  for (int attempt = 1; attempt <= 3 && level == 0; ++attempt) {
+    const double add = md.jitter_ladder * (attempt == 1 ? 1.0 : (attempt == 2 ? 10.0 : 100.0));
+    // working copy: lower triangle of K_MM (md.jitter is in it already) + the ladder's jitter on the diagonal
+    for (int row = ty; row < MP; row += LADDER_THREADS / 64)
+      for (int col = tx; col < MP; col += 64)
+        Lm[(size_t)row * MP + col] = col <= row ? K[(size_t)row * MP + col] + ((row == col && row < M) ? add : 0.0) : 0.0;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int j = 0; j < MP; ++j) {
+      const double d = Lm[(size_t)j * MP + j];           // the same value in every thread
+      if (!(d > 0.0)) {
+        if (tid == 0) s_bad = j + 1;
+        break;
+      }
+      const double dj = sqrt(d), inv = 1.0 / dj;
+      __syncthreads();                                    // everybody has read the pivot
+      for (int i = j + tid; i < MP; i += LADDER_THREADS) Lm[(size_t)i * MP + j] = (i == j) ? dj : Lm[(size_t)i * MP + j] * inv;
+      __syncthreads();
+      for (int i = j + 1 + ty; i < MP; i += LADDER_THREADS / 64) {
+        const double lij = Lm[(size_t)i * MP + j];
+        for (int k = j + 1 + tx; k <= i; k += 64) Lm[(size_t)i * MP + k] -= lij * Lm[(size_t)k * MP + j];
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    bad = s_bad;
+    __syncthreads();
+    if (bad == 0) level = attempt;
+  }
+  if (level != 0) {
+    // J = L^-1 by forward substitution: thread c owns column c (it only re-reads what it wrote itself)
+    for (int c = tid; c < MP; c += LADDER_THREADS) {
+      J[(size_t)c * MP + c] = 1.0 / Lm[(size_t)c * MP + c];
+      for (int i = c + 1; i < MP; ++i) {
+        double s0 = 0.0, s1 = 0.0;
+        int k = c;
+        for (; k + 1 < i; k += 2) {
+          s0 += Lm[(size_t)i * MP + k] * J[(size_t)k * MP + c];
+          s1 += Lm[(size_t)i * MP + k + 1] * J[(size_t)(k + 1) * MP + c];
+        }
+        if (k < i) s0 += Lm[(size_t)i * MP + k] * J[(size_t)k * MP + c];
+        J[(size_t)i * MP + c] = -(s0 + s1) / Lm[(size_t)i * MP + i];
+      }
+    }
+  }
+  if (tid == 0) {
+    status[0] = level != 0 ? 0 : bad;
+    status[2] = level;
+  }
+}
+
 #define GEMM_MM(ta, tb, args)                                          \
   do {                                                                 \
     if (int rc_ = gemm_mm((ta), (tb), (args), p, ws, st)) return rc_;  \
@@ -778,6 +851,10 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
   LAUNCH_CHECK();
   if (int rc = big_factorise(p, ws, status, true, st)) return rc;
+  if (md.jitter_ladder > 0.0) {  // the device-side retry ladder: returns at once unless the factorisation failed
+    hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
+    LAUNCH_CHECK();
+  }
   if (!train) return 0;
   hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, st, p, md, ws);
   LAUNCH_CHECK();

@@ -1,7 +1,9 @@
 #!/bin/bash
-# The command sequence behind profiles/r01_v6_* (run on the GPU box through gpurun; outputs under gpurun_out/v6).
-R=$GRAFT_REPO_ROOT
-O=gpurun_out/v6
+# The command sequence behind profiles/<tag>_* (run on the GPU box through gpurun; raw outputs under gpurun_out/<tag>,
+# summaries are copied into profiles/ by hand).   tools/probes/profile_round.sh r02
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}
+O=gpurun_out/$TAG
 cd $R; mkdir -p $O
 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/tests.log
 cat $O/tests.log
@@ -9,20 +11,60 @@ python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tai
 for w in tgp_power_tanh3x2 tgp_power_sal2 svgp_power svgp_boston idtgp_power_sal3; do
   python bench.py --workload $w --cpu-seconds 8 > $O/bench_$w.json 2> $O/bench_$w.err
   cut -c1-230 $O/bench_$w.json
+  TGP_ROWS2=1 python bench.py --workload $w --no-cpu-baseline > $O/bench_rows2_$w.json 2> $O/bench_rows2_$w.err
+  cut -c1-230 $O/bench_rows2_$w.json
 done
 python bench.py --workload tgp_airline_tanh5x6 --steps 20 --warmup 3 --cpu-seconds 8 > $O/bench_tgp_airline_tanh5x6.json 2> $O/bench_airline.err
 cut -c1-230 $O/bench_tgp_airline_tanh5x6.json
 python bench.py --workload tgp_airline_mb10k --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_tgp_airline_mb10k.json 2> $O/bench_mb10k.err
 cut -c1-230 $O/bench_tgp_airline_mb10k.json
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/$O/prof_graph $R/$O/prof_eager $R/$O/pmc_f $R/$O/pmc_w $R/$O/prof_big
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_graph -- python3 $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/$O/prof_graph.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_eager -- python3 $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-graph > $R/$O/prof_eager.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_f -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-graph > $R/$O/pmc_f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_w -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-graph > $R/$O/pmc_w.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_big -- python3 $R/bench.py --workload tgp_airline_tanh5x6 --steps 5 --warmup 1 --no-cpu-baseline > $R/$O/prof_big.log 2>&1
+rm -rf $R/$O/prof_graph $R/$O/prof_graph_rows2 $R/$O/prof_eager $R/$O/pmc_f $R/$O/pmc_w $R/$O/prof_big $R/$O/pmc_big
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_graph -- python3 $R/bench.py --steps 500 --warmup 50 --repeats 1 --no-cpu-baseline > $R/$O/prof_graph.log 2>&1
+export TGP_ROWS2=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_graph_rows2 -- python3 $R/bench.py --steps 500 --warmup 50 --repeats 1 --no-cpu-baseline > $R/$O/prof_graph_rows2.log 2>&1
+unset TGP_ROWS2
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_eager -- python3 $R/bench.py --steps 300 --warmup 30 --repeats 1 --no-cpu-baseline --no-graph > $R/$O/prof_eager.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_f -- python3 $R/bench.py --steps 100 --warmup 10 --repeats 1 --no-cpu-baseline --no-graph > $R/$O/pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_w -- python3 $R/bench.py --steps 100 --warmup 10 --repeats 1 --no-cpu-baseline --no-graph > $R/$O/pmc_w.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_big -- python3 $R/bench.py --workload tgp_airline_tanh5x6 --steps 5 --warmup 1 --repeats 1 --no-cpu-baseline > $R/$O/prof_big.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES --output-format csv -d $R/$O/pmc_big -- python3 $R/bench.py --workload tgp_airline_tanh5x6 --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-graph > $R/$O/pmc_big.log 2>&1
 cd $R
-for d in prof_graph prof_eager prof_big; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; head -12 "$f" | cut -c1-150; done
+for d in prof_graph prof_graph_rows2 prof_eager prof_big; do f=$(find $O/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; head -12 "$f" | cut -c1-150; cp "$f" $O/${d}_kernel_stats.csv; done
+FC=$(find $O/pmc_f -name "*counter_collection.csv" | head -1); WC=$(find $O/pmc_w -name "*counter_collection.csv" | head -1)
+python tools/probes/pmc_summary.py FETCH_SIZE=$FC WRITE_SIZE=$WC > $O/pmc_hbm_traffic_per_kernel.csv; head -20 $O/pmc_hbm_traffic_per_kernel.csv | cut -c1-150
+# per-launch HBM bytes of the dominant kernel from THIS build's PMC passes -> bench --traffic-json (same session)
+python - <<PY
+import csv, json
+f = {}; w = {}
+for line in open("$O/pmc_hbm_traffic_per_kernel.csv"):
+    if line.startswith("#") or line.startswith("counter"): continue
+    r = next(csv.reader([line]))
+    (f if r[0] == "FETCH_SIZE" else w)[r[1]] = float(r[3])
+k = [n for n in f if "k_rows<" in n][0]
+json.dump({"tgp_power_tanh3x2": (2 * f[k] + w[k]) * 1024.0}, open("$O/rows_traffic.json", "w"))
+print("k_rows HBM bytes per launch:", (2 * f[k] + w[k]) * 1024.0)
+PY
+python bench.py --steps 2000 --warmup 100 --cpu-seconds 8 --traffic-json $O/rows_traffic.json > $O/bench_tgp_power_tanh3x2_with_traffic.json 2> /dev/null; cut -c1-300 $O/bench_tgp_power_tanh3x2_with_traffic.json
+BC=$(find $O/pmc_big -name "*counter_collection.csv" | head -1)
+python - <<PY
+import csv
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(list))
+for r in csv.DictReader(open("$BC")):
+    if "tgp::" in r["Kernel_Name"]: acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = open("$O/big_pmc_mfma_util_per_kernel.csv", "w")
+out.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES, bench.py --workload tgp_airline_tanh5x6 --no-graph; mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs)\n")
+out.write("kernel,dispatches,mean_SQ_VALU_MFMA_BUSY_CYCLES,mean_GRBM_GUI_ACTIVE,mean_MFMA_MOPS_F64,mfma_busy_frac\n")
+for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
+    n = len(c.get("GRBM_GUI_ACTIVE", []))
+    if not n: continue
+    m = lambda name: sum(c.get(name, [0])) / max(len(c.get(name, [0])), 1)
+    busy, gui = m("SQ_VALU_MFMA_BUSY_CYCLES"), m("GRBM_GUI_ACTIVE")
+    out.write('"%s",%d,%.0f,%.0f,%.0f,%.3f\n' % (k[:110], n, busy, gui, m("SQ_INSTS_VALU_MFMA_MOPS_F64"), busy / (gui / 8 * 1024) if gui else 0))
+out.close()
+print(open("$O/big_pmc_mfma_util_per_kernel.csv").read()[:1500])
+PY
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*counter_collection.csv" -size +30M -delete
-ls -la $O/pmc_f/*/ | head
+python tools/probes/stamp_rows2.py 8611 > $O/stamp_rows2.txt 2>&1; cat $O/stamp_rows2.txt | tail -3
