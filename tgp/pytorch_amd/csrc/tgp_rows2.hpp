@@ -34,7 +34,7 @@ namespace tgp {
 #endif
 
 #ifndef TGP_R2_CHAIN_PRIO
-#define TGP_R2_CHAIN_PRIO 2
+#define TGP_R2_CHAIN_PRIO 0
 #endif
 #ifndef TGP_R2_PREFETCH
 #define TGP_R2_PREFETCH 16 /* A fragments requested one product ahead */
@@ -127,10 +127,10 @@ __host__ __device__ inline Row2Lds row2_lds(const Plan& p, int T, int nslots) {
 template <int NSTEPS>
 __device__ __forceinline__ d4 chain_r(const double* av, const double* bp) {
   d4 c = {0, 0, 0, 0};
-  // Three waves share this SIMD's matrix pipe.  Back-to-back f64 MFMAs on ONE accumulator are forwarded (64 cycles
-  // apart); MFMAs of different waves interleaved by the arbiter are not (80-100 cycles measured).  A raised priority
-  // keeps the pipe on this wave's chain until it ends; the co-resident waves run their chains one after the other.
-  __builtin_amdgcn_s_setprio(TGP_R2_CHAIN_PRIO);
+  // Three waves share this SIMD's matrix pipe: their MFMAs interleave and issue 80-100 cycles apart (measured), against
+  // 64 for one wave's chain alone.  Raising the wave's priority for the length of its chain (s_setprio 2 here, 0 after
+  // it) changed nothing: TGP_R2_CHAIN_PRIO is left at 0 and the instruction is not emitted.
+  if (TGP_R2_CHAIN_PRIO) __builtin_amdgcn_s_setprio(TGP_R2_CHAIN_PRIO);
 #pragma unroll
   for (int s0 = 0; s0 < NSTEPS; s0 += 8) {
     double bv[8];
@@ -141,7 +141,7 @@ __device__ __forceinline__ d4 chain_r(const double* av, const double* bp) {
     for (int u = 0; u < 8; ++u)
       if (s0 + u < NSTEPS) c = TGP_MFMA(av[s0 + u], bv[u], c);
   }
-  __builtin_amdgcn_s_setprio(0);
+  if (TGP_R2_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0);
   return c;
 }
 
