@@ -134,7 +134,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #define PSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tph[i] += (double)(tn_ - tlast); tlast = tn_; } while (0)
   double twv[5] = {0, 0, 0, 0, 0};
   unsigned long long twl = 0;
-#define WSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memtime(); if ((i) > 0) twv[i] += (double)(tn_ - twl); twl = tn_; } while (0)
+#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long tn_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) twv[i] += (double)(tn_ - twl); twl = tn_; } while (0)
 #else
 #define PSTAMP(i) do { } while (0)
 #define WSTAMP(i) do { } while (0)
@@ -190,16 +190,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     }
     return k;
   };
-  // left-looking tile: acc = sum_{k < kend} L[i-tile rows, k] * L[j-tile rows, k]   (both operands in LDS)
-  auto ll_sum = [&](int i0, int j0, int kend) {
+  // left-looking tile: acc = sum_{kbeg <= k < kend} L[i-tile rows, k] * L[j-tile rows, k]   (both operands in LDS)
+  auto ll_sum = [&](int i0, int j0, int kbeg, int kend) {
     d4 acc = {0, 0, 0, 0};
-    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, 0,
+    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
                      kend, acc);
   };
+  // tile (i, c) -= sum_{kbeg <= k < kend} L[i rows, k] L[c rows, k]^T in place (one wave; C/D layout read-modify-write)
+  auto sub_sum = [&](int i, int c, int kbeg, int kend) {
+    if (kend <= kbeg) return;
+    const d4 upd = ll_sum(16 * i, 16 * c, kbeg, kend);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] -= upd[rr];
+  };
   // panel tile (i, c): L_ic = (A_ic - sum_{k<c} L_ik L_ck^T) Dinv_c^T ; own tile, read fully before it is rewritten
-  auto panel_tile = [&](int i, int c) {
+  // (kbeg > 0: the part of the left-looking sum below kbeg was subtracted from the tile beforehand, see the schedule)
+  auto panel_tile = [&](int i, int c, int kbeg) {
     const int i0 = 16 * i, c0 = 16 * c;
-    const d4 upd = ll_sum(i0, c0, c0);
+    const d4 upd = ll_sum(i0, c0, kbeg, c0);
     double av[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];   // updated A_ic, C/D layout
@@ -297,10 +305,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
           __builtin_amdgcn_wave_barrier();
         } else {
           WSTAMP(0);
-          panel_tile(j, j - 1);
+          // the sums over the block columns before j-2 (panel tile) / before j-1 (diagonal tile) were subtracted by a
+          // helper during iteration j-1: only the newest block column is left on the critical chain
+          panel_tile(j, j - 1, j >= 2 ? 16 * (j - 2) : 0);
           __builtin_amdgcn_wave_barrier();
           WSTAMP(1);
-          const d4 upd = ll_sum(j0, j0, j0);
+          const d4 upd = ll_sum(j0, j0, 16 * (j - 1), j0);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
           __builtin_amdgcn_wave_barrier();
@@ -311,12 +321,21 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
         const int bad = potrf_trtri16(a, x, li);
+#ifdef TGP_STAMPS
+        asm volatile("" ::"v"(x[15]), "v"(a[15]), "v"(x[0]));
+#endif
         WSTAMP(3);
-        if (lane < 16) {
+        // Store L_jj (row li) and Dinv_j (column li).  The four 16-lane rows of the wave hold the same a[], x[]: row q
+        // stores the columns c = 4 u + q, so all 64 lanes store and every lane issues 4 + 4 plain ds_write_b64 instead
+        // of 16 lanes issuing 16 + 16 under 16 different exec masks (that was 2.0 k of the 9.6 k cycles of an iteration).
+        // The strict upper part of the diagonal tile is never read (potrf reads the lower part, write_tile masks it).
+        {
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
-            Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
+          for (int u = 0; u < 4; ++u) {
+            const double av4 = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
+            const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+            A[(j0 + li) * LD + j0 + 4 * u + q] = av4;
+            Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
           }
         }
         WSTAMP(4);
@@ -325,21 +344,42 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     } else if (hw < 0) {
       // wave 4: idle (see above)
     } else if (j == 0) {
+      // K_MM is filled TWO iterations ahead of its first reader (block column c below its diagonal tile at iteration
+      // c-1, tile (c,c) at iteration c-2): the helper that pre-subtracts row j+1's sums at iteration j finds tiles
+      // (j+1, j) and (j+1, j+1) complete
       fill_block(0, 16, MP);  // tile (0,0) is wave 0's
-      if (MT > 1) fill_block(1, 16, 32);
+      if (MT > 1) { fill_block(1, 16, 32); fill_block(1, 32, MP); }
+      if (MT > 2) fill_block(2, 32, 48);
     } else {
       // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2  (at most MT-2 <= 6 tiles for 7 waves)
       const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
+      if (MT - 2 < NH && hw == NH - 1 && j + 1 < MT) sub_sum(j + 1, j, 0, 16 * (j - 1));   // see t == 0 below
       for (int t = hw; t < npanel + (j - 1); t += NH) {
-        if (t < npanel) panel_tile(j + 1 + t, j - 1);
-        else inv_tile(j - 1, t - npanel);
+        if (t < npanel) {
+          panel_tile(j + 1 + t, j - 1, 0);
+          if (t == 0) {
+            // row j+1 is wave 0's at the next iteration: take everything that is already final off its chain --
+            //   tile (j+1, j+1) -= sum over block columns 0 .. j-1 (the last one is the panel tile just formed): here;
+            //   tile (j+1, j)   -= sum over block columns 0 .. j-2 (column j-1 needs L(j, j-1), wave 0's tile of THIS
+            //                      iteration, and stays on the chain): by the helper that has no tile this iteration
+            //                      (there are MT-2 tiles for NH helpers), else here as well.  One wave per tile: no race.
+            __builtin_amdgcn_wave_barrier();
+            sub_sum(j + 1, j + 1, 0, 16 * j);
+            if (MT - 2 >= NH) sub_sum(j + 1, j, 0, 16 * (j - 1));
+          }
+        } else {
+          inv_tile(j - 1, t - npanel);
+        }
       }
-      if (j < MT) fill_block(j, 16 * (j + 1), MP);                      // rest of block j: read from iteration j+1 on
-      if (j + 1 < MT) fill_block(j + 1, 16 * (j + 1), 16 * (j + 2));     // diagonal tile (j+1, j+1): wave 0, iteration j+1
+      if (j + 1 < MT) fill_block(j + 1, 16 * (j + 2), MP);               // rest of block j+1: first read at iteration j+1
+      if (j + 2 < MT) fill_block(j + 2, 16 * (j + 2), 16 * (j + 3));     // diagonal tile (j+2, j+2)
       if (j >= 2)
         for (int tj = hw; tj <= j - 2; tj += NH) write_tile(j - 2, tj);
     }
-    __syncthreads();
+    // The iteration barrier orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it made every iteration
+    // wait for the global stores of write_tile (a store's acknowledgement takes 1-2 us): those stores are read by no
+    // wave of this kernel and may stay in flight across the barrier.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     PSTAMP(j < 4 ? j : 3);
   }
   if (has_nan) s_nan = 1;
