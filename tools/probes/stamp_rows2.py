@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ["TGP_ALLOW_STALE_LIB"] = "1"
 import tgp.pytorch_amd.lib as L
 L.LIB_PATH = os.path.join(ROOT, "tools/probes/stamp/libtgp_hip.so")
+L.load().tgp_set_rows_kernel(1)
 from tgp.pytorch_amd.engine import ElboEngine
 from tgp.pytorch_amd import synthetic as orc
 names = ["stage", "K", "gemm1", "gemm2", "mu,v+flow", "Bvb", "gemm3", "gemm4", "E+T", "A-tile", "G,s", "tail"]
