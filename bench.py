@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps; the median is reported")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--capture-allreduce", action="store_true", help="capture the collective inside the HIP graph")
+    ap.add_argument("--replicas", type=int, default=1, help="(1 GPU only) K independent training runs of the workload on K "
+                    "streams, value = their aggregate steps/s: how the chip is filled when several UCI splits train at once")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
                     "--pmc pass of THIS build (tools/probes/pmc_summary.py); without it roofline.traffic is null")
     args = ap.parse_args()
@@ -220,6 +222,24 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # independent replicas (other seeds, own parameters / workspaces / graphs / streams); replica 0 is `eng`
+    extra = []
+    if args.replicas > 1 and world == 1:
+        from tgp.pytorch_amd import ops
+        for k in range(1, args.replicas):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                pk = make_problem(w, seed=k)
+                ops._ws_cache.clear()
+                ek = ElboEngine(pk["X"], pk["Y"], pk["params"], N_total=float(w["N"]), flow_blocks=pk["program"], S=w["S"],
+                                device=dev, mlp=mlp[0] if mlp else None, mlp_weights=mlp[1].clone() if mlp else None)
+                for _ in range(3):
+                    ek.step()
+                if not args.no_graph:
+                    ek.capture()
+            extra.append((ek, st))
+        torch.cuda.synchronize()
+
     # ---- warm-up (eager), capture, then the timed region --------------------------------------------------------
     run = eng.step
     for _ in range(min(args.warmup, 10)):
@@ -228,6 +248,14 @@ def main():
     if not args.no_graph:
         eng.capture(with_allreduce=True if (args.capture_allreduce and world > 1) else None)
         run = eng.replay
+    if extra:
+        run0 = run
+
+        def run():
+            run0()
+            for ek, st in extra:
+                with torch.cuda.stream(st):
+                    (ek.step if args.no_graph else ek.replay)()
     for _ in range(args.warmup):
         run()
     dts = []
@@ -276,7 +304,7 @@ def main():
                 traffic = json.load(open(args.traffic_json)).get(args.workload)
             except Exception:
                 traffic = None
-        units = world if args.scaling == "weak" else 1
+        units = (world if args.scaling == "weak" else 1) * (1 + len(extra))
         pg = {"world_size": torch.distributed.get_world_size() if world > 1 else 1,
               "backend": torch.distributed.get_backend() if world > 1 else None,
               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
@@ -292,7 +320,8 @@ def main():
             "repeats": len(dts), "ms_per_step_min": 1e3 * dts[0] / args.steps, "ms_per_step_max": 1e3 * dts[-1] / args.steps,
             "config": {"workload": args.workload, "rows_per_gpu": int(Xr.shape[0]), "D": w["D"], "M": w["M"], "S": w["S"],
                        "flow": w["flow"], "global_rows_per_step": n_global, "parallelism": "row-shard x%d" % world,
-                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo, "process_group": pg},
+                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo, "process_group": pg,
+                       "replicas": 1 + len(extra)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,

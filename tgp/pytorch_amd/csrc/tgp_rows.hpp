@@ -20,6 +20,12 @@ namespace tgp {
 
 #define TGP_NODES_IN_FLIGHT 4
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads() also drains vmcnt:
+// the operand panels requested two ahead (global loads meant to land under the MFMA chain of the current panel) were
+// waited for AT every barrier, and so were the slab stores of the epilogue.  Everything the waves of a row kernel
+// exchange goes through LDS; what they store to global memory is read by no wave of the same launch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct RowArgs {
   Plan p;
   const double* X;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nacc = P * 64 + RP * 256;
     for (int i = tid; i < nacc; i += 256) acc[i] = 0.0;
   }
-  __syncthreads();
+  lds_barrier();
 
   TGP_STAMP(a.ws, p, 1);
   double x[DP];
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + (i & 1) * (MP * 16);
     commit(i, stg[i & 1]);
-    __syncthreads();
+    lds_barrier();
     if (i + 2 < 2 * MT) issue(JT, Lq, i + 2, stg[i & 1]);
     Aa[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Kr[st]; });
   }
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + ((MT + i) & 1) * (MP * 16);
     commit(MT + i, stg[(MT + i) & 1]);
-    __syncthreads();
+    lds_barrier();
     if (MT + i + 2 < 2 * MT) issue(JT, Lq, MT + i + 2, stg[(MT + i) & 1]);
     Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Aa[i + st / 4][st % 4]; });
   }
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       double* accq = acc + wave * 16 + nl;
       double* accr = acc + (size_t)P * 64 + tid;
       const int ntrip = (p.S + 4 * NB - 1) / (4 * NB);
-      __syncthreads();  // the stack aliases the operand panels: all waves must be done with GEMM 2
+      lds_barrier();  // the stack aliases the operand panels: all waves must be done with GEMM 2
       for (int it = 0; it < ntrip; ++it) {
         double xn[NB], wq[NB], f[NB], c[NB];
 #pragma unroll
@@ -372,14 +378,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int i = 0; i < MT; ++i) Ba[i] *= vb;
   d4 Ca[MT];
-  __syncthreads();  // every wave is done with the flow stack / forward panels before the region is overwritten
+  lds_barrier();  // every wave is done with the flow stack / forward panels before the region is overwritten
   issue(LqT, Jm, 0, stg[0]);
   issue(LqT, Jm, 1, stg[1]);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + (i & 1) * (MP * 16);
     commit(i, stg[i & 1]);
-    __syncthreads();
+    lds_barrier();
     if (i + 2 < 2 * MT) issue(LqT, Jm, i + 2, stg[i & 1]);
     Ca[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Ba[st / 4][st % 4]; });
   }
@@ -391,11 +397,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + ((MT + i) & 1) * (MP * 16);
     commit(MT + i, stg[(MT + i) & 1]);
-    __syncthreads();
+    lds_barrier();
     if (MT + i + 2 < 2 * MT) issue(LqT, Jm, MT + i + 2, stg[(MT + i) & 1]);
     Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Ca[i + st / 4][st % 4]; });  // Kbar
   }
-  __syncthreads();  // panels dead: the region becomes the transposition tile
+  lds_barrier();  // panels dead: the region becomes the transposition tile
 
   TGP_STAMP(a.ws, p, 7);
   double* slab = a.ws + p.slabs + (size_t)blockIdx.x * p.slab_len;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       xt[col * CT16 + c] = val;
     }
   }
-  __syncthreads();
+  lds_barrier();
   for (int t = wave; t < MT * CT; t += 4) {
     const int ti = t / CT, tc = t % CT;
     d4 c = {0, 0, 0, 0};
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
   }
-  __syncthreads();
+  lds_barrier();
 
   TGP_STAMP(a.ws, p, 8);
   // ---- phase 2: A through LDS, G = A diag(vbar) A^T (lower tiles), s = A mubar ----
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
   if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
-  __syncthreads();
+  lds_barrier();
   TGP_STAMP(a.ws, p, 17);
   // Row-blocks of G are dealt to the waves in balanced groups -- MT odd: {MT-1}, {MT-2, 0}, {MT-3, 1}, ...; MT even:
   // {MT-1, 0}, {MT-2, 1}, ... (every group holds MT or MT+1 of the MT(MT+1)/2 lower tiles) -- so that the 16 A-operand
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // ---- scalars, flow parameter gradients ----
   const double e1 = wave_sum(ellp), e2 = wave_sum(etap), e3 = wave_sum(q == 0 ? vb : 0.0);
   if (lane == 0) { red[wave * 4] = e1; red[wave * 4 + 1] = e2; red[wave * 4 + 2] = e3; }
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) {
     slab[p.slab_C + C_ELL] = a.scale * (red[0] + red[4] + red[8] + red[12]);
     slab[p.slab_C + C_ETAB] = a.scale * (red[1] + red[5] + red[9] + red[13]);

@@ -44,6 +44,10 @@ class Trainer_SP_regression:
         self.validate_each = validate_each
         self.S_test = S_test
         self.inference_in_cpu = inference_in_cpu
+        if inference_in_cpu:
+            # the reference moves the model to the CPU for compute_metrics (trainers_regression.py:321-338); the product has
+            # no CPU implementation, so the flag is accepted and metrics stay on the GPU -- said once, not silently
+            print("[tgp.pytorch_amd] inference_in_cpu=True ignored: metrics are computed on the GPU (no CPU path in this package)")
         assert len(Y_std.shape) == 1 and Y_std.shape[0] == self.num_outputs
         self.Y_std = Y_std
         self.optimizer = None
