@@ -139,9 +139,11 @@ def cpu_baseline(prob, budget_s=15.0, max_steps=400, mlp=None):
     for nt in sorted(cand):
         torch.set_num_threads(nt)
         one()
-        t0 = time.perf_counter()
-        one()
-        t = time.perf_counter() - t0
+        t = float("inf")
+        for _ in range(1 if big else 3):          # best of three: one noisy step used to flip the choice between runs
+            t0 = time.perf_counter()
+            one()
+            t = min(t, time.perf_counter() - t0)
         if t < best_t:
             best, best_t = nt, t
         if t > 3.0:
