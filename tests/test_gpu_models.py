@@ -628,3 +628,50 @@ def test_input_dependent_initialiser_runs_on_the_hip_mlp_kernels():
                 assert float((fl.NNets_a(X) - 0.1 * k).abs().mean()) < 0.05
                 assert float((fl.NNets_b(X) - (1.0 + 0.05 * k)).abs().mean()) < 0.05
     assert last < 0.2
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_engine_id_tgp_training_mode_dropout_matches_host_restated_masks(graph):
+    """ID_TGP in TRAINING mode (dropout on, set_is_training(True): models/sparse_MF_SP.py:133-134, flow.py:949-965) through the
+    resident engine: the keep masks are a counter-based hash of (seed, Adam step, net, layer, row, unit group), so the run
+    is reproducible on the host -- oracle + the same nets as torch ops with ops.mlp_keep_mask(step) + torch Adam with
+    the two parameter groups, 3 steps.  `graph`: the rotated captured unit (rows -> adjoint -> Adam -> prepare | MLP
+    backward -> Adam(nets) -> MLP forward), whose mask counter is the network group's own."""
+    from tgp.pytorch_amd import ops
+    from tgp.pytorch_amd.engine import ElboEngine
+    N, D, M, S = 320, 4, 24, 12
+    prob = orc.synthetic_problem(N, D, M, seed=6, flow="idsal3", S=S)
+    spec = ops.MlpSpec(D, 50, 2, 6, act="relu", drop_p=0.25, seed=77)
+    g = torch.Generator().manual_seed(5)
+    W0 = 0.25 * (2 * torch.rand(6 * spec.weights_per_net, generator=g, dtype=torch.float64) - 1)
+    pw = spec.weights_per_net
+    for k in range(6):                                   # a nets near 0, b nets near 1: a well-conditioned flow
+        W0[(k + 1) * pw - 1] = float(k % 2)
+    leaves = {k: t.clone().requires_grad_(True) for k, t in prob["params"].items()}
+    Wn = W0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": list(leaves.values())}, {"params": [Wn], "weight_decay": 1e-5}], lr=0.01)
+    ref = []
+    for step in range(3):
+        masks = [[torch.from_numpy(ops.mlp_keep_mask(spec.seed, step, k, l, N, spec.H, spec.drop_p)).to(torch.float64)
+                  for l in range(spec.L)] for k in range(spec.nnets)]
+        rowp = orc.mlp_rowp(prob["X"], Wn, D, 50, 2, 6, "relu", masks=masks, drop_p=0.25)
+        e, l, k = orc.elbo(prob["X"], prob["Y"], leaves["Z"], leaves["raw_lengthscale"], leaves["raw_outputscale"], leaves["m"],
+                           leaves["Lam"], leaves["log_var_noise"], prob["N_total"], prob["program"], leaves.get("theta"),
+                           prob["xs"], prob["ws"], rowp)
+        ref.append([float(e.detach()), float(l.detach()), float(k.detach())])
+        opt.zero_grad()
+        (-e).backward()
+        opt.step()
+    eng = ElboEngine(prob["X"], prob["Y"], prob["params"], float(prob["N_total"]), flow_blocks=prob["program"], S=S, device=DEV,
+                     mlp=spec, mlp_weights=W0, mlp_training=True)
+    hist = []
+    if graph:
+        eng.capture()
+        assert eng.graph == "rotated"
+    for _ in range(3):
+        (eng.replay if graph else eng.step)()
+        hist.append(list(eng.scalars()))
+    eng.check_status()
+    assert rel_err(torch.tensor(hist, dtype=torch.float64), torch.tensor(ref, dtype=torch.float64)) < 1e-8
+    assert rel_err(eng.fp.view("nn").cpu(), Wn.detach()) < 1e-7
+    assert rel_err(eng.fp.view("Z").cpu(), leaves["Z"].detach()) < 1e-7
