@@ -19,7 +19,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define TGP_ROWS_PER_BLOCK 64 /* 4 waves x 16 rows */
 #define TGP_TILE_LD 66        /* LDS row stride (f64) of the [m][64 rows] transposition tile: conflict-free ds_read_b64 */
 #define TGP_MAX_MT 8
+#ifndef TGP_RSPLIT
 #define TGP_RSPLIT 4 /* the slab reduction is split in this many independent partial sums */
+#endif
 #define TGP_LOG_2PI_REF 1.8378770942368803 /* log(2*float32(pi)): the reference's cg.pi is a float32 tensor (dsp/config.py:71) */
 
 // Diagnostic build only (-DTGP_STAMPS): thread 0 of block 0 writes the 100 MHz s_memrealtime counter into the

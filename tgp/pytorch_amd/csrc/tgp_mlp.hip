@@ -355,18 +355,34 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
   }
 }
 
-// g_W[net][k] = sum over row blocks of the partials (fixed order)
+// g_W[net][k] = sum over row blocks of the partials (fixed order).  One workgroup = 64 consecutive elements x 4 quarters
+// of the row blocks (a wave per quarter); 16 partials are requested before the first add -- with two loads in flight per
+// thread the 135 partials of a Power-sized step were 67 dependent L2 round trips (21 us on the critical path of the
+// ID_TGP step); the four quarter sums meet in LDS and are added in a fixed order.
 __global__ __launch_bounds__(256) void k_mlp_reduce(const double* __restrict__ part, int nblk, size_t len, double* __restrict__ g_W) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= len) return;
-  double s0 = 0.0, s1 = 0.0;
-  int b = 0;
-  for (; b + 2 <= nblk; b += 2) {
-    s0 += part[(size_t)b * len + e];
-    s1 += part[(size_t)(b + 1) * len + e];
+  __shared__ double q4[4][64];
+  const int el = threadIdx.x & 63, qt = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + el;
+  const int b0 = (int)((long long)nblk * qt / 4), b1 = (int)((long long)nblk * (qt + 1) / 4);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < len) {
+    const double* pe = part + e;
+    for (int b = b0; b < b1; b += 16) {
+      double t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int bu = b + u < b1 ? b + u : b1 - 1;
+        t[u] = pe[(size_t)bu * len];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? t[u] : 0.0;
+      s0 += (t[0] + t[4]) + (t[8] + t[12]); s1 += (t[1] + t[5]) + (t[9] + t[13]);
+      s2 += (t[2] + t[6]) + (t[10] + t[14]); s3 += (t[3] + t[7]) + (t[11] + t[15]);
+    }
   }
-  if (b < nblk) s0 += part[(size_t)b * len + e];
-  g_W[e] = s0 + s1;
+  q4[qt][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (qt == 0 && e < len) g_W[e] = (q4[0][el] + q4[1][el]) + (q4[2][el] + q4[3][el]);
 }
 
 static size_t mlp_lds_bytes(int D, int H, int L, bool bwd) { return (size_t)mlp_lds(D, H, L, bwd).total * sizeof(double); }
@@ -412,7 +428,7 @@ int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, cons
   hipLaunchKernelGGL(k_mlp_bwd, dim3(nblk, d.nnets), dim3(MLP_NT), lds, st, mlp_args(d, X, W, step_dev), g_out, ws);
   LAUNCH_CHECK();
   const size_t len = (size_t)d.nnets * mlp_weights_per_net(d.D, d.H, d.L);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, st, ws, nblk, len, g_W);
+  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((len + 63) / 64)), dim3(256), 0, st, ws, nblk, len, g_W);
   LAUNCH_CHECK();
   return 0;
 }
