@@ -268,13 +268,14 @@ __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const 
                                                    double b1, double b2, double eps, double wd,
                                                    int32_t* __restrict__ step_dev, double sign, int64_t n_plain,
                                                    double ln_b1, double ln_b2) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const double step = (double)(step_dev[0] + 1);
-  if (i < n) {
-    // beta^step = exp(step ln beta), ln beta from the host: the library pow() is ~300 dependent f64 instructions per
-    // call and every thread made two of them -- 3 of this kernel's 4.3 us (relative error of the power <= 1e-14 at
-    // step 1e5, far inside the 1e-8 the parity tests hold the optimiser trajectory to)
-    const double bc1 = 1.0 - exp_fast(step * ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ln_b2));
+  // beta^step = exp(step ln beta), ln beta from the host: the library pow() is ~300 dependent f64 instructions per
+  // call and every thread made two of them -- 3 of this kernel's 4.3 us (relative error of the power <= 1e-14 at
+  // step 1e5, far inside the 1e-8 the parity tests hold the optimiser trajectory to)
+  const double bc1 = 1.0 - exp_fast(step * ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ln_b2));
+  // grid-stride: the launcher caps the grid (the ticket below is one atomic per workgroup on ONE word, ~12 ns each:
+  // the 4 096 workgroups of a 1 M-parameter buffer spent 50 us queueing for it)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double gi = sign * g[i];
     if (wd != 0.0 && i >= n_plain) gi += wd * p[i];  // weight decay only on the tail group
     const double mi = b1 * m[i] + (1.0 - b1) * gi;
@@ -416,7 +417,8 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
 int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
                     hipStream_t st, int64_t n_plain) {
-  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
+  const int64_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
                      n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0, n_plain, log(beta1), log(beta2));
   LAUNCH_CHECK();
   return 0;
