@@ -426,6 +426,8 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
   // weight): the slabs come from the Infinity Cache / HBM at 1-2 us per dependent round trip, and the former scalar
   // tail loop paid one round trip per leftover slab (2 of this kernel's 5 us at Power size)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // (16 slabs per batch; 40 in flight -- all of a Power-sized partial sum in one round trip -- measured no faster: the
+  //  kernel moves 9.8 MB through 144 workgroups and is bound by that, not by its three round trips)
   for (int b = b0; b < b1; b += 16) {
     double t[16];
 #pragma unroll
@@ -473,6 +475,7 @@ __device__ __forceinline__ double red_tail(const Plan& p, const double* __restri
 //   Q(i, c) = [Phi(L^T Lbar) + Phi(L^T Lbar)^T](i, c), i >= c      -> HBM, mirrored
 // ---------------------------------------------------------------------------------------------------
 #define BWD_THREADS 512
+#define TGP_PF2 32 /* >= MP / 4 k-steps */
 
 __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp_grads g, double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -486,20 +489,46 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   const int c = blockIdx.x % MT, c0 = 16 * c;
   const double* __restrict__ Gp = ws + p.Gp;
   const size_t mm = (size_t)MP * MP;
-  for (int i = tid; i < MP * 16; i += BWD_THREADS) {
-    const int row = i >> 4, cc = i & 15;
-    double s = 0.0;
+  {
+    // G(:, c) = sum of the partials: all (<= 4 rows of the loop) x TGP_RSPLIT loads of a thread are requested before the
+    // first add (the rolled loop paid one L2 round trip per trip: its loads depend on nothing but were not hoisted)
+    constexpr int NIT = (16 * TGP_MAX_MT * 16 + BWD_THREADS - 1) / BWD_THREADS;
+    double gv[NIT][TGP_RSPLIT];
 #pragma unroll
-    for (int part = 0; part < TGP_RSPLIT; ++part) s += Gp[part * mm + (size_t)row * MP + c0 + cc];
-    Gs[i] = s;
-    LbL[i] = 0.0;
+    for (int u = 0; u < NIT; ++u) {
+      const int i = tid + u * BWD_THREADS;
+      const int ic = i < MP * 16 ? i : 0;
+#pragma unroll
+      for (int part = 0; part < TGP_RSPLIT; ++part) gv[u][part] = Gp[part * mm + (size_t)(ic >> 4) * MP + c0 + (ic & 15)];
+    }
+    const double sv0 = tid < 16 ? red_tail(p, ws, p.slab_S + c0 + tid) : 0.0;
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int i = tid + u * BWD_THREADS;
+      if (i < MP * 16) {
+        double s = 0.0;
+#pragma unroll
+        for (int part = 0; part < TGP_RSPLIT; ++part) s += gv[u][part];
+        Gs[i] = s;
+        LbL[i] = 0.0;
+      }
+    }
+    if (tid < 16) svL[tid] = sv0;
   }
-  if (tid < 16) svL[tid] = red_tail(p, ws, p.slab_S + c0 + tid);
   __syncthreads();
   const double* __restrict__ HpT = ws + p.HpT;
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ Lm = ws + p.L;
   const double* __restrict__ w = ws + p.w;
+  // A fragments of this wave's Q tile (second phase, rows of L from its diagonal block down): requested now, so that
+  // they land under the first phase's MFMAs instead of costing a round trip of their own after the second barrier
+  // (requesting them -- and the first phase's -- before the staging loads above was slower: the workgroup is bound by what
+  //  one CU pulls from L2, and the staging loads then queue behind 96 fragment loads per wave)
+  double pq[TGP_PF2];
+  const bool has2 = !lam_block && wave < MT - c;
+  const int i2 = 16 * (c + wave), n2 = has2 ? (MP - i2) / 4 : 0;
+#pragma unroll
+  for (int s_ = 0; s_ < TGP_PF2; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
   // ---- Lbar tiles (i >= c) / Lam-gradient tiles (all j) ----
   const int t_lo = lam_block ? MT - c : 0, t_hi = lam_block ? (MT - c) + MT : MT - c;
   for (int t = t_lo + wave; t < t_hi; t += BWD_THREADS / 64) {
@@ -541,8 +570,17 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
     const int i = c + t, i0 = 16 * i;
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
-                    [&](int k) { return LbL[(k + q) * 16 + r]; }, i0, MP, acc);
+#pragma unroll
+    for (int s0 = 0; s0 < TGP_PF2; s0 += 8) {
+      if (s0 < n2) {
+        double o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
+      }
+    }
     if (i != c) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -577,6 +615,16 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restric
   const int i = blockIdx.x, i0 = 16 * i;
   const double* __restrict__ J = ws + p.J;
   const double* __restrict__ Q = ws + p.Q;
+  // operands of the epilogue (K_MM entries of this wave's second-phase tile, the 16 Zs rows of the block): requested with
+  // the first phase's loads instead of after the second phase's MFMAs (one L2 round trip less on the chain)
+  double* zsL = Yl + (size_t)MT * 256;                       // 16 x DP
+  double kmv[4];
+  {
+    const int jbw = wave < MT ? wave : 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) kmv[rr] = (ws + p.Kmm)[(size_t)(i0 + q + 4 * rr) * MP + 16 * jbw + r];
+    if (tid < 16 * DP) zsL[tid] = (ws + p.Zs)[(size_t)i0 * DP + tid];
+  }
   for (int kb = wave; kb < MT; kb += BWD_THREADS / 64) {
     d4 acc = {0, 0, 0, 0};
     acc = tile_mm_f<TGP_GBATCH>([&](int k) { return J[(size_t)(k + q) * MP + i0 + r]; },
@@ -594,14 +642,14 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restric
                     [&](int k) { return J[(size_t)(k + q) * MP + j0 + r]; }, j0, MP, acc);  // J[k,j] = 0 for k < j
     double ep[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) ep[rr] = 0.5 * acc[rr] * Kmm[(size_t)(i0 + q + 4 * rr) * MP + j0 + r];
+    for (int rr = 0; rr < 4; ++rr) ep[rr] = 0.5 * acc[rr] * kmv[rr];
     double cs = quad_sum((ep[0] + ep[1]) + (ep[2] + ep[3]));
     double* out = ws + p.PP + ((size_t)i * MP + j0 + r) * PPW;
     if (q == 0) out[DP] = cs;
     for (int d = 0; d < DP; ++d) {
       double s = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) s += ep[rr] * Zs[(i0 + q + 4 * rr) * DP + d];
+      for (int rr = 0; rr < 4; ++rr) s += ep[rr] * zsL[(q + 4 * rr) * DP + d];
       s = quad_sum(s);
       if (q == 0) out[d] = s;
     }
@@ -851,7 +899,7 @@ int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, d
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bwd12, dim3(2 * p.MT), dim3(BWD_THREADS), (size_t)(2 * p.MP * 16 + 16) * sizeof(double), st, p, md, g, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), (size_t)p.MT * 256 * sizeof(double), st, p, ws);
+  hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), ((size_t)p.MT * 256 + 16 * p.DP) * sizeof(double), st, p, ws);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), (size_t)p.M * (p.D + 1) * sizeof(double), st, p, md, g, out, ws);
   LAUNCH_CHECK();
