@@ -477,6 +477,12 @@ __device__ __forceinline__ double red_tail(const Plan& p, const double* __restri
 #define BWD_THREADS 512
 #define TGP_PF2 32 /* >= MP / 4 k-steps */
 
+// PF = number of second-phase L fragments a wave requests early (TGP_PF2: all of them; 0: none).  The early request buys
+// 0.6 us when the kernel has the chip to itself but costs 58 VGPRs (222 instead of 164), and at 2 waves per SIMD a
+// workgroup above 168 VGPRs no longer fits a CU beside two k_mlp_bwd workgroups (2 x 88): under ID_TGP, where the
+// per-row networks' backward runs on the second stream at the same time, the 222-register form waited for whole CUs
+// to drain (26 -> 50 us).  launch_backward_mm picks PF = 0 for models with per-row flow parameters.
+template <int PF>
 __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp_grads g, double* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
@@ -524,11 +530,13 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   // they land under the first phase's MFMAs instead of costing a round trip of their own after the second barrier
   // (requesting them -- and the first phase's -- before the staging loads above was slower: the workgroup is bound by what
   //  one CU pulls from L2, and the staging loads then queue behind 96 fragment loads per wave)
-  double pq[TGP_PF2];
+  double pq[PF > 0 ? PF : 1];
   const bool has2 = !lam_block && wave < MT - c;
   const int i2 = 16 * (c + wave), n2 = has2 ? (MP - i2) / 4 : 0;
+  if constexpr (PF > 0) {
 #pragma unroll
-  for (int s_ = 0; s_ < TGP_PF2; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
+    for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
+  }
   // ---- Lbar tiles (i >= c) / Lam-gradient tiles (all j) ----
   const int t_lo = lam_block ? MT - c : 0, t_hi = lam_block ? (MT - c) + MT : MT - c;
   for (int t = t_lo + wave; t < t_hi; t += BWD_THREADS / 64) {
@@ -570,16 +578,21 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
     const int i = c + t, i0 = 16 * i;
     d4 acc = {0, 0, 0, 0};
+    if constexpr (PF > 0) {
 #pragma unroll
-    for (int s0 = 0; s0 < TGP_PF2; s0 += 8) {
-      if (s0 < n2) {
-        double o[8];
+      for (int s0 = 0; s0 < PF; s0 += 8) {
+        if (s0 < n2) {
+          double o[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
+          for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
+          for (int u = 0; u < 8; ++u)
+            if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
+        }
       }
+    } else {
+      acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
+                      [&](int k) { return LbL[(k + q) * 16 + r]; }, i0, MP, acc);
     }
     if (i != c) {
 #pragma unroll
@@ -897,7 +910,9 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st) {
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd12, dim3(2 * p.MT), dim3(BWD_THREADS), (size_t)(2 * p.MP * 16 + 16) * sizeof(double), st, p, md, g, ws);
+  const size_t lds12 = (size_t)(2 * p.MP * 16 + 16) * sizeof(double);
+  if (md.RP > 0) hipLaunchKernelGGL(k_bwd12<0>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
+  else hipLaunchKernelGGL(k_bwd12<TGP_PF2>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), ((size_t)p.MT * 256 + 16 * p.DP) * sizeof(double), st, p, ws);
   LAUNCH_CHECK();
