@@ -13,9 +13,11 @@ for _ in range(3):
     eng.forward_backward()
 torch.cuda.synchronize()
 st = eng.mlp_ws[-16:].cpu().tolist()
-nblk = (eng.N + 63) // 64
-PW = spec.weights_per_net
-off = nblk * spec.nnets * PW
+nch = (eng.N + 63) // 64
+per = (nch * spec.nnets + 511) // 512
+G = (nch + per - 1) // per                       # mlp_groups(N, nnets, MLP_SLOTS_BWD)
+off = G * spec.nnets * spec.weights_per_net      # the 16 spare doubles behind the partials
 st = eng.mlp_ws[off:off + 10].cpu().tolist()
-names = ["stage", "fwd recompute", "out layer", "delta_L", "dW2+db2", "delta-prop", "dW1+db1"]
-print("k_mlp_bwd block 0:", "  ".join("%s %.1f" % (names[i], (st[i + 1] - st[i]) * 0.01) for i in range(7)), " total %.1f us" % ((st[7] - st[0]) * 0.01))
+names = ["weights", "inputs+sync", "fwd chain", "dwo + delta_L + put + sync", "dwo out", "delta-prop + dW2", "put + syncs", "dW1"]
+print("k_mlp_bwd block 0 (its last chunk; stamp 0 = kernel start):",
+      "  ".join("%s %.1f" % (names[i], (st[i + 1] - st[i]) * 0.01) for i in range(7)), " total %.1f us" % ((st[7] - st[0]) * 0.01))
