@@ -486,7 +486,11 @@ def _torch_mlps(X, W, spec, masks=None):
 
 
 @pytest.mark.parametrize("N,D,H,Lh,nnets,act,p", [(1000, 4, 50, 2, 6, "relu", 0.25), (333, 7, 17, 1, 2, "tanh", 0.1),
-                                                   (129, 3, 32, 3, 3, "relu", 0.0)])
+                                                   (129, 3, 32, 3, 3, "relu", 0.0),
+                                                   # several 64-row chunks per workgroup, inputs and units of more than one tile
+                                                   (40000, 20, 64, 2, 6, "relu", 0.1),
+                                                   # H a multiple of 4 but not of 16: the last unit tile reads past the image
+                                                   (500, 5, 52, 2, 2, "tanh", 0.2), (700, 33, 40, 3, 2, "tanh", 0.0)])
 def test_mlp_kernels_match_torch(N, D, H, Lh, nnets, act, p):
     """tgp_mlp_forward/backward_f64 (the NNets of the input-dependent flows, flow.py:836-897) against torch autograd:
     eval mode, and training mode with the dropout mask restated on the host (ops.mlp_keep_mask)."""

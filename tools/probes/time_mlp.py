@@ -20,4 +20,4 @@ for N in (8611, 128 * 256):
         tf = timeit(lambda: ops.mlp_forward(spec, X, W, True, step))
         tb = timeit(lambda: ops.mlp_backward(spec, X, W, G, True, step))
         tf0 = timeit(lambda: ops.mlp_forward(spec, X, W, False, step))
-        print("N=%6d nets=%d blocks=%4d  fwd %.1f us (no dropout %.1f)  bwd+reduce %.1f us" % (N, nn, (N + 127) // 128 * nn, tf, tf0, tb))
+        print("N=%6d nets=%d chunks=%4d  fwd %.1f us (no dropout %.1f)  bwd+reduce %.1f us" % (N, nn, (N + 63) // 64 * nn, tf, tf0, tb))
