@@ -18,6 +18,8 @@ per = (nch * spec.nnets + 511) // 512
 G = (nch + per - 1) // per                       # mlp_groups(N, nnets, MLP_SLOTS_BWD)
 off = G * spec.nnets * spec.weights_per_net      # the 16 spare doubles behind the partials
 st = eng.mlp_ws[off:off + 10].cpu().tolist()
-names = ["weights", "inputs+sync", "fwd chain", "dwo + delta_L + put + sync", "dwo out", "delta-prop + dW2", "put + syncs", "dW1"]
-print("k_mlp_bwd block 0 (its last chunk; stamp 0 = kernel start):",
-      "  ".join("%s %.1f" % (names[i], (st[i + 1] - st[i]) * 0.01) for i in range(7)), " total %.1f us" % ((st[7] - st[0]) * 0.01))
+# stamps: 0 kernel start; 1 after the LAST chunk's input staging + barrier; then the phases of that chunk
+names = ["weights + earlier chunks + inputs", "forward chain", "output layer + delta_L + strip + barrier", "dwo out",
+         "delta-prop + dW2", "barrier + strip + barrier", "dW1"]
+print("k_mlp_bwd workgroup 0:", "  ".join("%s %.1f" % (names[i], (st[i + 1] - st[i]) * 0.01) for i in range(7)),
+      " total %.1f us" % ((st[7] - st[0]) * 0.01))
