@@ -197,8 +197,8 @@ static int launch_gemm_l(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
   return launch_gemm_t<false, false, MOD, EPI>(g, st);
 }
 
-int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
-  GemmArgs g = g_in;
+// argument checks and the launcher-set fields (pair, xcd); 0 or -1
+static int gemm_normalise(GemmArgs& g) {
   if (g.m % GT || g.n % GT || g.k % GK || g.m < 1 || g.n < 1 || g.ksplit < 1) return -1;
   if ((g.lda | g.ldb) & 1) return -1;  // 16-byte operand loads
   if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B) | reinterpret_cast<uintptr_t>(g.a_mul) |
@@ -210,10 +210,53 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
             g.n / GT > 1) ? 1 : 0;
   if ((g.tri & TRI_C_LOWER) && g.ksplit > 1 && g.m == g.n && !(g.tri & ~TRI_C_LOWER)) g.xcd = 3;
   else if (g.xcd == 3) g.xcd = 0;
+  return 0;
+}
+static bool gemm_has_mod(const GemmArgs& g) { return g.a_mul != nullptr || g.k_scale != nullptr; }
+static bool gemm_has_epi(const GemmArgs& g) {
+  return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
+}
+
+int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
+  GemmArgs g = g_in;
+  if (gemm_normalise(g)) return -1;
   const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
   const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
   if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
   return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
+}
+
+// a (op(B) transposed) and b (no transposition) in one launch, both plain or both with the C epilogue -- the shapes the
+// blocked factorisation pairs up; anything else: two launches
+static int launch_gemm_pair_ft_ff(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t st) {
+  GemmArgs a = a_in, b = b_in;
+  if (gemm_normalise(a) || gemm_normalise(b)) return -1;
+  const bool epi = gemm_has_epi(a);
+  const bool ok = !gemm_has_mod(a) && !gemm_has_mod(b) && gemm_has_epi(b) == epi && a.ksplit == 1 && b.ksplit == 1;
+  if (!ok) {
+    if (int rc = launch_gemm(false, true, a_in, st)) return rc;
+    return launch_gemm(false, false, b_in, st);
+  }
+  a.xcd = 0; b.xcd = 0;
+  const int gxa = a.pair ? (a.n / GT + 1) / 2 : a.n / GT, gya = a.m / GT;
+  const int gxb = b.pair ? (b.n / GT + 1) / 2 : b.n / GT, gyb = b.m / GT;
+  const int na = gxa * gya, nbk = gxb * gyb;
+  static bool attr_done[2] = {false, false};
+  const void* f = epi ? reinterpret_cast<const void*>(k_gemm_pair<false, true, false, true, false, false, false, true>)
+                      : reinterpret_cast<const void*>(k_gemm_pair<false, true, false, false, false, false, false, false>);
+  if (!attr_done[epi]) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    attr_done[epi] = true;
+  }
+  if (epi)
+    hipLaunchKernelGGL((k_gemm_pair<false, true, false, true, false, false, false, true>), dim3(na + nbk), dim3(256), GEMM_LDS_BYTES, st,
+                       a, b, na, gxa, gya, gxb, gyb);
+  else
+    hipLaunchKernelGGL((k_gemm_pair<false, true, false, false, false, false, false, false>), dim3(na + nbk), dim3(256), GEMM_LDS_BYTES, st,
+                       a, b, na, gxa, gya, gxb, gyb);
+  LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -734,23 +777,25 @@ __global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_
 // An M x M product has at most (MP/128)^2 <= 64 output tiles at M = 1000 -- a quarter of the CUs, each running the
 // whole k loop.  Split k so that about 256 workgroups run, partial sums into compact slabs, then one fixed-order
 // reduction into C (150 us -> ~50 us per product at MP = 1024).
-static int gemm_mm(bool ta, bool tb, GemmArgs g, const BigPlan& p, double* ws, hipStream_t st) {
+static int gemm_mm_on(bool ta, bool tb, GemmArgs g, double* scratch, size_t cap, hipStream_t st) {
   const int tiles = (g.m / 128) * (g.n / 128);
   int ks = 256 / (tiles > 0 ? tiles : 1);
   if (ks > 8) ks = 8;
   if (ks > g.k / 64) ks = g.k / 64;  // at least four k stages per slab
   const size_t slab = (size_t)g.m * g.n;
-  const size_t cap = (size_t)8 * ((p.MP / 128) <= 4 ? (size_t)p.MP * p.MP : (size_t)p.MP * p.MP / 2);
   if (ks <= 1 || (size_t)ks * slab > cap || g.add || g.row_scale || g.col_scale || g.rowv) return launch_gemm(ta, tb, g, st);
   double* C = g.C;
   const int ldc = g.ldc;
   const double beta = g.beta;
-  g.C = ws + p.Sk; g.ldc = g.n; g.beta = 0.0; g.ksplit = ks; g.cz = slab;
+  g.C = scratch; g.ldc = g.n; g.beta = 0.0; g.ksplit = ks; g.cz = slab;
   if (int rc = launch_gemm(ta, tb, g, st)) return rc;
-  hipLaunchKernelGGL(k_big_sum_slabs2d, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, ws + p.Sk, ks, g.m, g.n, C, ldc,
-                     beta);
+  hipLaunchKernelGGL(k_big_sum_slabs2d, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, scratch, ks, g.m, g.n, C, ldc, beta);
   LAUNCH_CHECK();
   return 0;
+}
+static int gemm_mm(bool ta, bool tb, const GemmArgs& g, const BigPlan& p, double* ws, hipStream_t st) {
+  const size_t cap = (size_t)8 * ((p.MP / 128) <= 4 ? (size_t)p.MP * p.MP : (size_t)p.MP * p.MP / 2);
+  return gemm_mm_on(ta, tb, g, ws + p.Sk, cap, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -829,9 +874,41 @@ __global__ __launch_bounds__(LADDER_THREADS) void k_big_ladder(BigPlan p, tgp_mo
     if (int rc_ = gemm_mm((ta), (tb), (args), p, ws, st)) return rc_;  \
   } while (0)
 
+// A second stream inside one C-ABI call.  The M x M phases of this path are chains of small launches (one workgroup
+// factorising a 128-column block, products with 8-64 output tiles) that leave most of the chip idle, and several of the
+// chains do not depend on each other; they are forked onto an auxiliary stream by event record / wait -- valid in eager
+// mode and under stream capture of the caller's stream (the auxiliary stream joins the capture through the event and is
+// joined back before the call returns) -- so a captured step replays them as parallel branches of the graph.
+struct BigFork {
+  hipStream_t aux = nullptr;
+  hipEvent_t ev[2] = {};    // 0: fork, 1: join
+  int init() {
+    if (aux != nullptr) return 0;
+    if (hipError_t e = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    for (auto& x : ev)
+      if (hipError_t e = hipEventCreateWithFlags(&x, hipEventDisableTiming); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    return 0;
+  }
+  // `to` continues after everything issued on `from` so far
+  int after(int i, hipStream_t from, hipStream_t to) {
+    if (hipError_t e = hipEventRecord(ev[i], from); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    if (hipError_t e = hipStreamWaitEvent(to, ev[i], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    return 0;
+  }
+};
+static BigFork& big_fork() {
+  static BigFork f;
+  return f;
+}
+
 // Blocked right-looking Cholesky of the padded matrix in p.Lm (lower block triangle filled, J zeroed) and, if wanted, the
-// block-row inverse J = L^-1 (torch.cholesky, dsp/utils.py:239).  Diagonal blocks of J are always produced (the panel
-// solve multiplies by them).
+// inverse J = L^-1 (torch.cholesky, dsp/utils.py:239).  Diagonal blocks of J are always produced (the panel solve
+// multiplies by them).  The inverse is right-looking too, J[i,j] = -J_ii sum_{j <= k < i} L[i,k] J[k,j]:
+//   after k_big_potrf(k):  J[k, 0:k]  = -J_kk Acc[k, 0:k]                       (row k is final)
+//   after the panel of k:  Acc[i, 0:k+1] += L[i,k] J[k, 0:k+1]  for all i > k    (Acc lives in J's own blocks below row k)
+// so every product has k = 128 (no split-k, no scratch) and each rides in a launch the factorisation makes anyway
+// (launch_gemm_pair_ft_ff: the row product beside the panel product, the push beside the trailing update): the inverse
+// costs ONE launch at the very end instead of 3 (nb - 1) launches after the factorisation (330 us at M = 1000).
 static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool want_inverse, hipStream_t st) {
   const int MP = p.MP, nb = MP / 128;
   double* Lm = ws + p.Lm;
@@ -840,50 +917,70 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
     hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
     LAUNCH_CHECK();
     const int rem = MP - (kb + 1) * 128;
+    double* Jk = J + (size_t)kb * 128 * MP;                          // block row kb of J
+    const double* Jkk = Jk + (size_t)kb * 128;
+    // in place: each workgroup reads exactly the tile it overwrites
+    const GemmArgs inv_row = gemm_args(Jkk, MP, Jk, MP, Jk, MP, 128, 128 * kb, 128, -1.0, 0.0);
+    const bool row = want_inverse && kb >= 1;
     if (rem > 0) {
       double* panel = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)kb * 128;
-      const double* Jkk = J + (size_t)kb * 128 * MP + (size_t)kb * 128;
-      // L[i,kb] = K[i,kb] J_kk^T   (in place: each workgroup reads exactly the tile it overwrites)
-      GEMM(false, true, gemm_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 128));
+      // L[i,kb] = K[i,kb] J_kk^T   (in place as well)
+      const GemmArgs pan = gemm_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 128);
       // trailing update K[i,j] -= L[i,kb] L[j,kb]^T, lower block triangle
       double* trail = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)(kb + 1) * 128;
-      GEMM(false, true, gemm_args(panel, MP, panel, MP, trail, MP, rem, rem, 128, -1.0, 1.0, TRI_C_LOWER));
+      const GemmArgs upd = gemm_args(panel, MP, panel, MP, trail, MP, rem, rem, 128, -1.0, 1.0, TRI_C_LOWER);
+      const GemmArgs push = gemm_args(panel, MP, Jk, MP, J + (size_t)(kb + 1) * 128 * MP, MP, rem, 128 * (kb + 1), 128, 1.0, 1.0);
+      if (row) {
+        if (int rc = launch_gemm_pair_ft_ff(pan, inv_row, st)) return rc;
+      } else {
+        GEMM(false, true, pan);
+      }
+      if (want_inverse) {
+        if (int rc = launch_gemm_pair_ft_ff(upd, push, st)) return rc;
+      } else {
+        GEMM(false, true, upd);
+      }
+    } else if (row) {
+      GEMM(false, false, inv_row);
     }
-  }
-  if (!want_inverse) return 0;
-  // block-row inverse: J[i, 0:i] = -J_ii (L[i, 0:i] J[0:i, 0:i])
-  for (int i = 1; i < nb; ++i) {
-    const double* Li = Lm + (size_t)i * 128 * MP;
-    double* tmp = ws + p.tmp;
-    GEMM_MM(false, false, gemm_args(Li, MP, J, MP, tmp, MP, 128, 128 * i, 128 * i, 1.0, 0.0, TRI_B_LOWER));
-    const double* Jii = J + (size_t)i * 128 * MP + (size_t)i * 128;
-    GEMM(false, false, gemm_args(Jii, MP, tmp, MP, J + (size_t)i * 128 * MP, MP, 128, 128 * i, 128, -1.0, 0.0));
   }
   return 0;
 }
 
 static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
-  const int MP = p.MP, nb = MP / 128;
+  const int MP = p.MP;
   const size_t mm = (size_t)MP * MP;
+  BigFork& fk = big_fork();
+  if (int rc = fk.init()) return rc;
+  hipStream_t sx = fk.aux;
   hipLaunchKernelGGL(k_big_hdr, dim3(1), dim3(256), 0, st, p, md, ws, status);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_big_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
   LAUNCH_CHECK();
+  // ---- fork: what needs only the variational parameters (KL, S = Lq Lq^T - I) runs beside the factorisation ----
+  if (int rc = fk.after(0, st, sx)) return rc;
+  if (train) {
+    hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, sx, p, md, ws);
+    LAUNCH_CHECK();
+    const double* Lq = ws + p.Lq;
+    // (split-k through the row phase's G partials, idle until the first chunk: the scratch of gemm_mm belongs to the main
+    //  stream; split, the product fits under the first diagonal block's factorisation instead of slowing the first panel)
+    if (int rc = gemm_mm_on(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER),
+                            ws + p.Gpart, (size_t)p.ksg * mm, sx))
+      return rc;
+    hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, sx, ws + p.S_, MP);
+    LAUNCH_CHECK();
+  }
   if (int rc = big_factorise(p, ws, status, true, st)) return rc;
+  if (int rc = fk.after(1, sx, st)) return rc;   // join
   if (md.jitter_ladder > 0.0) {  // the device-side retry ladder: returns at once unless the factorisation failed
     hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
     LAUNCH_CHECK();
   }
   if (!train) return 0;
-  hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, st, p, md, ws);
-  LAUNCH_CHECK();
-  // S = Lq Lq^T - I ; H' = J^T S
-  const double* Lq = ws + p.Lq;
-  GEMM_MM(false, true, gemm_args(Lq, MP, Lq, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_A_LOWER | TRI_B_UPPER));
-  hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, st, ws + p.S_, MP);
-  LAUNCH_CHECK();
+  // H' = J^T S (after the ladder: a retry rewrites J)
   GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
   hipLaunchKernelGGL(k_big_wvec, dim3(MP / 64), dim3(WVEC_THREADS), 0, st, p, ws);
   LAUNCH_CHECK();

@@ -309,6 +309,41 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   }
 }
 
+// Two independent products in ONE launch (the first `na` workgroups run product a, the rest product b; natural tile
+// order, no split-K): the blocked factorisation's chain of small launches leaves most CUs idle, and the block-row inverse
+// that does not depend on the current step rides in the same launches instead of costing launches -- or cross-queue
+// graph dependencies, ~10 us each under replay -- of its own.  The second GemmArgs sits behind the first in the kernel
+// argument segment (gemm_tile reads its arguments through scalar loads from that segment).
+template <bool TA1, bool TB1, bool MOD1, bool EPI1, bool TA2, bool TB2, bool MOD2, bool EPI2>
+__global__ __launch_bounds__(256, 2) void k_gemm_pair(GemmArgs a, GemmArgs b, int na, int gxa, int gya, int gxb, int gyb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  double* As = reinterpret_cast<double*>(gemm_smem);
+  double* Bs = As + 2 * GSTAGE;
+  const uint64_t kernarg = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  int L = blockIdx.x;
+  if (L < na) {
+    int bx = L % gxa, by = L / gxa;
+    if (a.tri & TRI_A_LOWER) by = gya - 1 - by;
+    const int nj = a.n / GT;
+    gemm_tile<TA1, TB1, MOD1, EPI1>(kernarg, by * GT, bx * GT, 0, As, Bs);
+    if (a.pair && nj - 1 - bx > bx) {
+      __syncthreads();
+      gemm_tile<TA1, TB1, MOD1, EPI1>(kernarg, by * GT, (nj - 1 - bx) * GT, 0, As, Bs);
+    }
+  } else {
+    L -= na;
+    int bx = L % gxb, by = L / gxb;
+    if (b.tri & TRI_A_LOWER) by = gyb - 1 - by;
+    const int nj = b.n / GT;
+    const uint64_t kb = kernarg + sizeof(GemmArgs);
+    gemm_tile<TA2, TB2, MOD2, EPI2>(kb, by * GT, bx * GT, 0, As, Bs);
+    if (b.pair && nj - 1 - bx > bx) {
+      __syncthreads();
+      gemm_tile<TA2, TB2, MOD2, EPI2>(kb, by * GT, (nj - 1 - bx) * GT, 0, As, Bs);
+    }
+  }
+}
+
 int launch_gemm(bool ta, bool tb, const GemmArgs& g, hipStream_t st);  // tgp_big.hip
 
 }  // namespace tgp
