@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_big_lbar(BigPlan p, double* __restrict_
 }
 
 // dELBO/dLam = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)); R2 = 2 G Lq is in S_
-__global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, double* __restrict__ gLam, const double* __restrict__ ws) {
+__global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, double* __restrict__ gLam, const double* __restrict__ GL) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int M = p.M;
   if (e >= (size_t)M * M) return;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, doubl
   double x = 0.0;
   if (col <= row) {
     const double lam = md.Lam[e];
-    x = ws[p.S_ + (size_t)row * p.MP + col] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);
+    x = GL[(size_t)row * p.MP + col] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);   // GL = 2 G Lq
   }
   gLam[e] = x;
 }
@@ -947,7 +947,14 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
   return 0;
 }
 
-static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st) {
+// `defer_hw`: H' = J^T S and w = J^T m (used by the backward M x M chain only) are left running on the auxiliary stream;
+// the caller joins it (big_join) before that chain -- they then run beside the first row chunk instead of in front of it.
+static int big_join(hipStream_t st) {
+  BigFork& fk = big_fork();
+  return fk.after(1, fk.aux, st);
+}
+static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st,
+                       bool defer_hw = false) {
   const int MP = p.MP;
   const size_t mm = (size_t)MP * MP;
   BigFork& fk = big_fork();
@@ -981,8 +988,20 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   }
   if (!train) return 0;
   // H' = J^T S (after the ladder: a retry rewrites J)
-  GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
-  hipLaunchKernelGGL(k_big_wvec, dim3(MP / 64), dim3(WVEC_THREADS), 0, st, p, ws);
+  hipStream_t sh = st;
+  if (defer_hw) {
+    if (int rc = fk.after(0, st, sx)) return rc;
+    sh = sx;
+  }
+  // (deferred, the product runs unsplit -- every split-k scratch is in use by the row phase it runs beside; its 64
+  //  workgroups take ~150 us of the 1.8 ms the first chunk's full-chip GEMMs need)
+  if (defer_hw) {
+    if (int rc = launch_gemm(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER), sh))
+      return rc;
+  } else {
+    GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
+  }
+  hipLaunchKernelGGL(k_big_wvec, dim3(MP / 64), dim3(WVEC_THREADS), 0, sh, p, ws);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1031,8 +1050,9 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
   const int MP = p.MP, NC = p.NC;
   const size_t mm = (size_t)MP * MP;
+  const bool defer_hw = (phases & TGP_PHASE_PREPARE) && (phases & TGP_PHASE_ROWS) && (phases & TGP_PHASE_BACKWARD);
   if (phases & TGP_PHASE_PREPARE)
-    if (int rc = big_prepare(p, md, ws, status, true, st)) return rc;
+    if (int rc = big_prepare(p, md, ws, status, true, st, defer_hw)) return rc;
   if (phases & TGP_PHASE_ROWS) {
     // Chunk pipeline.  With a second set of chunk buffers the forward half of chunk c+1 (K' tiles, A', B', moments,
     // likelihood -- a third of it bandwidth/latency-bound kernels that leave the matrix cores idle) runs on a helper
@@ -1112,13 +1132,25 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
   }
   if (phases & TGP_PHASE_BACKWARD) {
     const unsigned gmm = (unsigned)(mm / 256);
+    BigFork& fk = big_fork();
+    if (int rc = fk.init()) return rc;
+    if (defer_hw)
+      if (int rc = big_join(st)) return rc;   // H', w
+    // dLam = tril(2 G Lq) - ... needs G only: on the auxiliary stream, beside the chain Lbar -> Q -> Kbar_MM -> U (product
+    // and split-k slabs in the row phase's G partials, reduced into G by now)
+    if (int rc = fk.after(0, st, fk.aux)) return rc;
+    {
+      double* dl = ws + p.Gpart;
+      const size_t cap = p.ksg > 1 ? (size_t)(p.ksg - 1) * mm : 0;
+      if (int rc = gemm_mm_on(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, dl, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER), dl + mm, cap,
+                              fk.aux))
+        return rc;
+      hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, fk.aux, p, md, g.Lam, dl);
+      LAUNCH_CHECK();
+    }
     // Lbar = -tril(w s^T + 2 H' G)
     GEMM_MM(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0));
     hipLaunchKernelGGL(k_big_lbar, dim3(gmm), dim3(256), 0, st, p, ws);
-    LAUNCH_CHECK();
-    // dLam
-    GEMM_MM(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, ws + p.S_, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER));
-    hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, st, p, md, g.Lam, ws);
     LAUNCH_CHECK();
     // Q = Phi(L^T Lbar) + Phi(.)^T
     GEMM_MM(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER));
@@ -1144,6 +1176,7 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
     hipLaunchKernelGGL(k_big_sum_slabs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, ws + p.Tpart, 8,
                        (size_t)MP * BIG_XW, ws + p.U);
     LAUNCH_CHECK();
+    if (int rc = big_join(st)) return rc;   // dLam
     hipLaunchKernelGGL(k_big_final, dim3(1), dim3(256), 0, st, p, md, g, out, ws);
     LAUNCH_CHECK();
   }
