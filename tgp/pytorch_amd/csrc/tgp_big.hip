@@ -382,14 +382,29 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
     if (cc <= rr) A[rr * LD + cc] = Lb[(size_t)rr * ld + cc];
   }
   __syncthreads();
-  auto ll_sum = [&](int i0, int j0, int kend) {
+  // Wave 0 runs the critical chain and shares its SIMD with wave 4, which stays idle; the six waves on the other three
+  // SIMDs are the helpers (hw = 0..5) -- the schedule of k_prep_a (tgp_mm.hip), round-2 form: at iteration j a helper
+  // takes everything that is already final off the two left-looking sums of row j + 1, so that only the newest block
+  // column (12 MFMAs instead of 8 j + 4) stays on wave 0's chain at iteration j + 1.
+  constexpr int NH = POTRF_THREADS / 64 - 2;
+  const int hw = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  auto ll_sum = [&](int i0, int j0, int kbeg, int kend) {
     d4 acc = {0, 0, 0, 0};
-    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, 0,
+    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
                      kend, acc);
   };
-  auto panel_tile = [&](int i, int c) {
+  // tile (i, c) -= sum_{kbeg <= k < kend} L[i rows, k] L[c rows, k]^T in place (one wave; C/D layout read-modify-write)
+  auto sub_sum = [&](int i, int c, int kbeg, int kend) {
+    if (kend <= kbeg) return;
+    const d4 upd = ll_sum(16 * i, 16 * c, kbeg, kend);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] -= upd[rr];
+  };
+  // panel tile (i, c): L_ic = (A_ic - sum_{kbeg <= k < 16 c} L_ik L_ck^T) Dinv_c^T  (kbeg > 0: the part below kbeg was
+  // subtracted from the tile beforehand)
+  auto panel_tile = [&](int i, int c, int kbeg) {
     const int i0 = 16 * i, c0 = 16 * c;
-    const d4 upd = ll_sum(i0, c0, c0);
+    const d4 upd = ll_sum(i0, c0, kbeg, c0);
     double av[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];
@@ -427,9 +442,9 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
     if (wave == 0) {
       if (j < MT) {
         if (j > 0) {
-          panel_tile(j, j - 1);
+          panel_tile(j, j - 1, j >= 2 ? 16 * (j - 2) : 0);
           __builtin_amdgcn_wave_barrier();
-          const d4 upd = ll_sum(j0, j0, j0);
+          const d4 upd = ll_sum(j0, j0, 16 * (j - 1), j0);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
           __builtin_amdgcn_wave_barrier();
@@ -439,20 +454,34 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
         const int bad = potrf_trtri16(a, x, li);
-        if (lane < 16) {
+        // the four 16-lane rows of the wave hold the same a[], x[]: row q stores the columns 4 u + q (all 64 lanes store,
+        // 4 + 4 plain ds_write_b64 each; the strict upper part of the diagonal tile is never read)
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            if (c <= lane) A[(j0 + lane) * LD + j0 + c] = a[c];
-            Dt[j * 256 + c * 16 + lane] = x[c];  // x[c] = Dinv[c][lane]
-          }
+        for (int u = 0; u < 4; ++u) {
+          const double av4 = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
+          const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+          A[(j0 + li) * LD + j0 + 4 * u + q] = av4;
+          Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
         }
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
       }
-    } else if (j > 0) {
+    } else if (hw >= 0 && j > 0) {
+      // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2
       const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
-      for (int t = wave - 1; t < npanel + (j - 1); t += POTRF_THREADS / 64 - 1) {
-        if (t < npanel) panel_tile(j + 1 + t, j - 1);
-        else inv_tile(j - 1, t - npanel);
+      for (int t = hw; t < npanel + (j - 1); t += NH) {
+        if (t < npanel) {
+          panel_tile(j + 1 + t, j - 1, 0);
+          if (t == 0) {
+            // row j+1 is wave 0's at the next iteration:
+            //   tile (j+1, j+1) -= sum over block columns 0 .. j-1 (the last one is the panel tile just formed);
+            //   tile (j+1, j)   -= sum over block columns 0 .. j-2 (column j-1 needs L(j, j-1), wave 0's tile of THIS iteration)
+            __builtin_amdgcn_wave_barrier();
+            sub_sum(j + 1, j + 1, 0, 16 * j);
+            sub_sum(j + 1, j, 0, 16 * (j - 1));
+          }
+        } else {
+          inv_tile(j - 1, t - npanel);
+        }
       }
     }
     __syncthreads();
