@@ -15,6 +15,7 @@ cp $O/prof_eager_kernel_stats.csv $P/${TAG}_kernel_stats_tanh3x2_eager.csv
 cp $O/prof_big_kernel_stats.csv $P/${TAG}_big_kernel_stats_airline_tanh5x6_hipgraph.csv
 cp $O/pmc_hbm_traffic_per_kernel.csv $P/${TAG}_pmc_hbm_traffic_per_kernel.csv
 cp $O/big_pmc_mfma_util_per_kernel.csv $P/${TAG}_big_pmc_mfma_util_per_kernel.csv
+[ -s $O/pmc_mfma_util_per_kernel.csv ] && cp $O/pmc_mfma_util_per_kernel.csv $P/${TAG}_pmc_mfma_util_per_kernel.csv
 cp $O/tests.log $P/${TAG}_gpu_tests.log
 [ -s $O/stamp_rows2.txt ] && cp $O/stamp_rows2.txt $P/${TAG}_teamsplit_phase_stamps.txt
 [ -s $O/mlp_stamps.txt ] && cp $O/mlp_stamps.txt $P/${TAG}_mlp_phase_stamps.txt

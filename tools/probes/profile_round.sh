@@ -48,24 +48,12 @@ print("k_rows HBM bytes per launch:", (2 * f[k] + w[k]) * 1024.0)
 PY
 python bench.py --steps 2000 --warmup 100 --cpu-seconds 8 --traffic-json $O/rows_traffic.json > $O/bench_tgp_power_tanh3x2_with_traffic.json 2> /dev/null; cut -c1-300 $O/bench_tgp_power_tanh3x2_with_traffic.json
 BC=$(find $O/pmc_big -name "*counter_collection.csv" | head -1)
-python - <<PY
-import csv
-from collections import defaultdict
-acc = defaultdict(lambda: defaultdict(list))
-for r in csv.DictReader(open("$BC")):
-    if "tgp::" in r["Kernel_Name"]: acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = open("$O/big_pmc_mfma_util_per_kernel.csv", "w")
-out.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES, bench.py --workload tgp_airline_tanh5x6 --no-graph; mfma_busy_frac = MFMA_BUSY / (GUI_ACTIVE/8 * 1024 SIMDs)\n")
-out.write("kernel,dispatches,mean_SQ_VALU_MFMA_BUSY_CYCLES,mean_GRBM_GUI_ACTIVE,mean_MFMA_MOPS_F64,mfma_busy_frac\n")
-for k, c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):
-    n = len(c.get("GRBM_GUI_ACTIVE", []))
-    if not n: continue
-    m = lambda name: sum(c.get(name, [0])) / max(len(c.get(name, [0])), 1)
-    busy, gui = m("SQ_VALU_MFMA_BUSY_CYCLES"), m("GRBM_GUI_ACTIVE")
-    out.write('"%s",%d,%.0f,%.0f,%.0f,%.3f\n' % (k[:110], n, busy, gui, m("SQ_INSTS_VALU_MFMA_MOPS_F64"), busy / (gui / 8 * 1024) if gui else 0))
-out.close()
-print(open("$O/big_pmc_mfma_util_per_kernel.csv").read()[:1500])
-PY
+python tools/probes/pmc_mfma_summary.py "$BC" "python3 bench.py --workload tgp_airline_tanh5x6 --steps 3 --warmup 1 --no-graph" > $O/big_pmc_mfma_util_per_kernel.csv; head -14 $O/big_pmc_mfma_util_per_kernel.csv | cut -c1-170
+cd /tmp; rm -rf $R/$O/pmc_m
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES --output-format csv -d $R/$O/pmc_m -- python3 $R/bench.py --steps 100 --warmup 10 --repeats 1 --no-cpu-baseline --no-graph > $R/$O/pmc_m.log 2>&1
+cd $R
+MC=$(find $O/pmc_m -name "*counter_collection.csv" | head -1)
+python tools/probes/pmc_mfma_summary.py "$MC" "python3 bench.py --steps 100 --warmup 10 --no-graph (tgp_power_tanh3x2)" > $O/pmc_mfma_util_per_kernel.csv; head -12 $O/pmc_mfma_util_per_kernel.csv | cut -c1-170
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*counter_collection.csv" -size +30M -delete
 python tools/probes/stamp_rows2.py 8611 > $O/stamp_rows2.txt 2>&1; cat $O/stamp_rows2.txt | tail -3
