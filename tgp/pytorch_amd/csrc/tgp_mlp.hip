@@ -3,9 +3,9 @@
 // layers = pytorchlib apply_linear: Linear -> activation -> Dropout, flow.py:853-871), 6 nets of 4 -> 50 -> 50 -> 1
 // at BASELINE config C4, with dropout active in training (MC dropout, sparse_MF_SP.py:133-134).
 //
-// All nets of a flow have one architecture, so they run as ONE launch: grid = (row blocks, nets), 64 rows per
-// block = 4 waves x 16 rows.  A net's packed weight vector sits in LDS as it is in memory (no padded image: padding is
-// a predicate on the operand read); every product runs on v_mfma_f64_16x16x4_f64.
+// All nets of a flow have one architecture, so they run as ONE launch: grid = (row groups, nets); a workgroup = 4 waves
+// x 16 rows works through one or more 64-row chunks of one net with that net's weights staged once, as zero-padded
+// images in LDS (every fragment address = a per-tile base + a constant); every product runs on v_mfma_f64_16x16x4_f64.
 //   chain   : a wave carries ITS 16 rows through all layers in registers.  The accumulator layout of the 16x16x4
 //             instruction (lane (n, q) holds units q + 4 rr of row n) IS its B-operand layout of k-step rr, so the
 //             four output tiles of a layer are the sixteen k-steps of the next one without leaving the registers:
@@ -16,7 +16,8 @@
 //   backward: recomputes the forward (cheaper than N x H x L activations through HBM) and forms the weight gradients
 //             dW_l = delta_l a_{l-1}^T as [units x 64 rows] x [64 rows x units] contractions: the chain leaves a_l^T,
 //             then delta_l^T, in LDS strips [unit][row]; wave w owns unit tile w of delta_l and walks the tiles of
-//             a_{l-1}; bias gradients are lane-local sums of the same fragments.  Per-block partials are summed in a
+//             a_{l-1}; bias gradients are lane-local sums of the same fragments; the output layer's sums over rows use
+//             the DPP row rotations.  A workgroup adds its chunks' gradients in its own slot; the slots are summed in a
 //             second kernel in a fixed order.
 // Dropout is a counter-based hash of (seed, step, net, layer, row, unit): the same mask in the forward, in the
 // backward recomputation and under hipGraph replay (step is read from device memory), different every step.
@@ -31,7 +32,7 @@ namespace tgp {
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
-#define MLP_T 64       /* rows per block = 4 waves x 16 rows */
+#define MLP_T 64       /* rows per chunk = 4 waves x 16 rows */
 #define MLP_NT 256
 #define MLP_ST 66      /* row stride of a strip [unit][row]: the transposed fragment reads (lane = unit, q = row) of the
                           contractions fall on 32 distinct 8-byte banks per half wave */
