@@ -241,6 +241,29 @@ def real_dataset_fixture(name):
     return dc, Z1
 
 
+def uci_loader_fixtures():
+    """The other regression sets whose CSV + split pickle ship with the reference (uci_datasets.py:186-283), through the
+    reference's own return_dataset -> ONE compact fixture tests/golden/uci_loaders_seed1.npz: split indices (bit-exact
+    check), shapes, Y_std and every 97th z-scored row of each split.  Data, not source."""
+    from dsp.data import return_dataset
+    opts = {"shuffle_train": True, "split_from_disk": True, "use_generator": True, "n_workers": 0}
+    out = {}
+    for name in ("concrete", "kin8nm", "energy", "wine_red", "wine_white", "naval"):
+        loaders, dc = return_dataset(name, 10000, use_validation=None, seed=1, options=opts)
+        ds = loaders[0].dataset
+        stem = {"wine_red": "wine-red", "wine_white": "wine-white"}.get(name, name)
+        import pickle
+        with open("/root/reference/code/datasets/regression/uci/splits_idx_%s.pkl" % stem, "rb") as fh:
+            sp = pickle.load(fh)["seed_1"]
+        out[name + ".train_idx"] = np.asarray(sp["train"]).astype(np.int32)
+        out[name + ".test_idx"] = np.asarray(sp["test"]).astype(np.int32)
+        out[name + ".shape"] = np.asarray([dc["N_tr"], dc["N_te"], dc["X_tr"].shape[1]], dtype=np.int64)
+        out[name + ".Y_std"] = np.asarray(dc["Y_std"], dtype=np.float64).reshape(-1)
+        for k in ("X_tr", "Y_tr", "X_te", "Y_te"):
+            out[name + "." + k + "_every97"] = np.asarray(dc[k])[::97]
+    save("uci_loaders_seed1", out)
+
+
 def problem_on(dc, Z, flow, S, perturb, seed=0):
     """orc.synthetic_problem's parameter recipe on real rows: same generators, X/Y/Z replaced."""
     N, D = dc["X_tr"].shape
@@ -367,6 +390,9 @@ def real_data_fixtures():
 
 
 def main():
+    if "--uci-only" in sys.argv:
+        uci_loader_fixtures()
+        return
     if "--real-only" in sys.argv:
         real_data_fixtures()
         return

@@ -57,6 +57,34 @@ def test_product_loader_equals_reference_loader(name, f64):
 
 
 @needs_data
+@pytest.mark.parametrize("name", ["concrete", "kin8nm", "energy", "wine_red", "wine_white", "naval"])
+def test_other_uci_sets_equal_the_reference_loader(name, f64):
+    """The other regression sets the reference ships with split pickles (uci_datasets.py:186-283: separators ',', ';' and
+    three blanks; energy's target is the second-to-last column and the last is dropped) against a compact fixture of the
+    reference's own return_dataset: indices bit-exact, shapes, Y_std, every 97th z-scored row of each split to 1e-15."""
+    from tgp.pytorch_amd.data import return_dataset
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "uci_loaders_seed1.npz"))
+    loaders, dc = return_dataset(name, 10000, use_validation=None, seed=1,
+                                 options={"shuffle_train": True, "split_from_disk": True, "root": UCI})
+    assert np.array_equal(dc["train_idx"], g[name + ".train_idx"]) and np.array_equal(dc["test_idx"], g[name + ".test_idx"])
+    n_tr, n_te, dx = (int(v) for v in g[name + ".shape"])
+    assert (dc["N_tr"], dc["N_te"], dc["Dx"], dc["Dy"]) == (n_tr, n_te, dx, 1)
+    assert abs(float(dc["Y_std"][0]) - float(g[name + ".Y_std"][0])) <= 1e-15 * max(1.0, float(g[name + ".Y_std"][0]))
+    for k in ("X_tr", "Y_tr", "X_te", "Y_te"):
+        ref = g[name + "." + k + "_every97"]
+        got = dc[k].numpy()[::97]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max()), k
+
+
+def test_unknown_dataset_is_rejected(f64):
+    from tgp.pytorch_amd.data import return_dataset
+    with pytest.raises(ValueError):
+        return_dataset("protein", 100, seed=1, options={"root": UCI})      # no split pickle ships for it
+    with pytest.raises(ValueError):
+        return_dataset("synthetic_concrete", 100, seed=1)
+
+
+@needs_data
 def test_validation_split_follows_the_reference(f64):
     """use_validation = [seed, N_val] (uci_datasets.py:54-56, data.py:216-234): numpy.random.seed permutation, the
     statistics come from the reduced train split."""

@@ -82,22 +82,40 @@ def random_split_validation(X, Y, seed, N_val):
     return X[tr, :], Y[tr], X[va, :], Y[va]
 
 
+# the regression sets of code/dsp/data/uci_datasets.py whose CSV and split pickle ship with the reference
+# (datasets/regression/uci): file, separator, target column (uci_datasets.py:173-283; `index` splits X | Y as
+# data[:, :index], data[:, index] -- energy keeps its second-to-last column as the target and drops the last)
+UCI = {
+    "boston": ("boston.csv", ",", -1),
+    "concrete": ("concrete.csv", ",", -1),
+    "kin8nm": ("kin8nm.csv", ",", -1),
+    "energy": ("energy.csv", ",", -2),
+    "power": ("power.csv", ",", -1),
+    "wine_red": ("wine-red.csv", ",", -1),
+    "wine_white": ("wine-white.csv", ";", -1),
+    "naval": ("naval.tsv", "   ", -1),
+}
+
+
 def load_uci_split(base, seed, root):
     """(X_tr, Y_tr, X_te, Y_te, tr_idx, te_idx) of the split stored on disk (code/dsp/data/uci_datasets.py:73-97)."""
     import pandas                   # the reference parses the CSV with pandas (data.py:186); numpy.loadtxt rounds
-    csv = os.path.join(root, base + ".csv")         # a few Boston entries differently (1 ulp)
+    fname, sep, index = UCI[base]                   # a few Boston entries differently (1 ulp)
+    csv = os.path.join(root, fname)
     if not os.path.exists(csv):
         raise FileNotFoundError("%s not found: point options['root'] / $TGP_DATA_ROOT at the reference's "
                                 "code/datasets/regression/uci directory" % csv)
-    data = pandas.read_csv(csv, sep=",", header=None).to_numpy()
-    with open(os.path.join(root, "splits_idx_%s.pkl" % base), "rb") as fh:
+    data = pandas.read_csv(csv, sep=sep, header=None, engine="python" if len(sep) > 1 else "c").to_numpy()
+    stem = fname.split(".")[0]
+    with open(os.path.join(root, "splits_idx_%s.pkl" % stem), "rb") as fh:
         split_dict = pickle.load(fh)
     key = "seed_" + str(seed)
     if key not in split_dict:
-        raise KeyError("split %s not in splits_idx_%s.pkl (has %d splits)" % (key, base, len(split_dict)))
+        raise KeyError("split %s not in splits_idx_%s.pkl (has %d splits)" % (key, stem, len(split_dict)))
     tr_idx, te_idx = split_dict[key]["train"], split_dict[key]["test"]
     data_tr, data_te = data[tr_idx], data[te_idx]
-    return data_tr[:, :-1], data_tr[:, -1].reshape(-1, 1), data_te[:, :-1], data_te[:, -1].reshape(-1, 1), tr_idx, te_idx
+    return (data_tr[:, :index], data_tr[:, index].reshape(-1, 1), data_te[:, :index], data_te[:, index].reshape(-1, 1),
+            tr_idx, te_idx)
 
 
 def _synthetic(name, seed):
@@ -113,12 +131,12 @@ def return_dataset(dataset_name, batch_size, use_validation=None, seed=None, opt
     options = options or {}
     synth = dataset_name.startswith("synthetic_")
     base = dataset_name.replace("synthetic_", "")
-    if base not in SHAPES:
+    if (synth and base not in SHAPES) or (not synth and base not in UCI):
         raise ValueError("Unkown dataset provided {}".format(dataset_name))
     if not options.get("split_from_disk", True):
         raise ValueError("only the splits stored on disk are supported (split_from_disk=True, as code/main.py sets it)")
-    n, d, n_tr = SHAPES[base]
     if synth:
+        n, d, n_tr = SHAPES[base]
         X, Y = _synthetic(base, seed)
         perm = numpy.random.default_rng(seed).permutation(n)
         tr_idx, te_idx = perm[:n_tr], perm[n_tr:]
@@ -140,6 +158,6 @@ def return_dataset(dataset_name, batch_size, use_validation=None, seed=None, opt
         loaders = [train, DeviceLoader(X_va, Y_va, batch_size, shuffle=shuffle, seed=cg.config_seed), test]
     data_config = {"X_tr": X_tr, "Y_tr": Y_tr, "X_va": X_va, "Y_va": Y_va, "X_te": X_te, "Y_te": Y_te,
                    "N_tr": X_tr.shape[0], "N_va": 0 if X_va is None else X_va.shape[0], "N_te": X_te.shape[0],
-                   "Dx": d, "Dy": 1, "Y_std": Y_std, "X_all": None, "Y_all": None,
+                   "Dx": X_tr.shape[1], "Dy": 1, "Y_std": Y_std, "X_all": None, "Y_all": None,
                    "train_idx": numpy.asarray(tr_idx), "test_idx": numpy.asarray(te_idx)}
     return loaders, data_config
