@@ -47,3 +47,20 @@ def test_sharded_engines_reproduce_the_unsharded_run(tmp_path, world, workload, 
     assert res["ranks_identical"]               # replicated parameters stay bit-identical across ranks
     assert res["hist_rel"] < 1e-9, res          # (ELBO, ELL, KL) of 5 Adam steps == the unsharded engine's
     assert res["param_rel"] < 1e-9, res
+
+
+def test_engine_graphs_with_a_live_rccl_group(tmp_path):
+    """The engine's captures and replays with an NCCL (= RCCL) process group alive in the process (one rank: the most one
+    GPU can host): the two graphs around the collective and the graph that records the collective itself, against eager
+    steps, bit for bit.  With torch's default capture mode this dies in the process group's watchdog thread
+    (hipErrorStreamCaptureUnsupported from its event queries); engine.CAPTURE_MODE = "thread_local" is what makes it run."""
+    out = os.path.join(str(tmp_path), "rccl1.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mp_rccl_worker.py"), out, str(_free_port())], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    with open(out) as fh:
+        res = json.load(fh)
+    assert res["backend"] == "nccl" and res["world"] == 1
+    assert res["graphs"] == [None, "split", "full"], res["graphs"]
+    assert res["split_equals_eager"] and res["full_equals_eager"], res

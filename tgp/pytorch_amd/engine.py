@@ -14,7 +14,16 @@ ELBO -> (-ELBO).backward() -> Adam.step()) with everything resident on the GPU.
 """
 import ctypes as C
 
+import os
+
 import torch
+
+# Stream-capture mode of every graph this package records.  "thread_local", not torch's default "global": with an NCCL
+# (= RCCL) process group alive, its watchdog thread polls the events of earlier collectives with hipEventQuery, which the
+# global mode forbids while ANY stream of the process captures -- measured on this stack (ROCm 7.0 / RCCL 2.26,
+# tools/probes/rccl_smoke.py): the process dies with hipErrorStreamCaptureUnsupported; thread-local capture records the
+# same graph (collective included) and replays it.
+CAPTURE_MODE = os.environ.get("TGP_CAPTURE_MODE", "thread_local")   # the override exists to reproduce the failure
 
 from . import lib as L
 from . import ops
@@ -259,7 +268,7 @@ class ElboEngine:
             self.mlp_forward(self.step_nn)
             torch.cuda.synchronize()
             self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
                 main = torch.cuda.current_stream()
                 side = self._side
                 self.elbo(2)
@@ -282,18 +291,18 @@ class ElboEngine:
         if self.world_size > 1 and not with_allreduce:
             # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
                 pre()
                 self.forward_backward()
                 pre_reduce(self.fp.grad, self.fp.n, self.world_size)
-            with torch.cuda.graph(self.g2):
+            with torch.cuda.graph(self.g2, capture_error_mode=CAPTURE_MODE):
                 post_reduce(self.fp.grad, self.fp.n)
                 self.adam()
                 post()
             self.graph = "split"
         else:
             self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
                 pre()
                 self.forward_backward()
                 self.allreduce()

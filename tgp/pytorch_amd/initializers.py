@@ -16,6 +16,7 @@ import warnings
 
 import numpy
 import torch
+from .engine import CAPTURE_MODE
 from torch import optim
 
 from . import config as cg
@@ -132,7 +133,7 @@ class IdInitEngine:
         torch.cuda.synchronize()
         if num_epochs > 1:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                 self.epoch()
             for _ in range(num_epochs - 1):
                 self.graph.replay()
