@@ -226,6 +226,159 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The k = 128 products of the blocked factorisation (panel, trailing update, inverse row, inverse push) on SMALL tiles.
+// k_gemm's 128 x 128 tile is 14 us of fp64 MFMA on one CU all by itself, and these products have 1-30 such tiles: the
+// launches were bound by tile size while 200+ CUs idled.  Here a workgroup = 4 waves x (32 x 32) computes a 32x128,
+// 128x32 or 64x64 tile (3.6 us of MFMA), so a product spreads over up to 4x the CUs.  The two in-place products keep
+// their safety by tile SHAPE: the panel (C = A J_kk^T over A) takes whole rows (32 x 128), the inverse row (C = -J_kk B
+// over B) whole columns (128 x 32) -- a workgroup reads exactly the operand region it overwrites, all of it before its
+// first store.  K is staged in two halves of 64 through LDS ([x][68]: fragment reads on 32 distinct 8-byte banks per
+// half wave), the second half's global loads in flight under the first half's MFMAs.  Two jobs per launch, as before.
+struct FacJob {
+  const double* A;   // [m][128] row-major, leading dimension lda
+  const double* B;   // tb: [n][128] row-major (op(B) = B^T) ; else [128][n] row-major
+  double* C;
+  int lda, ldb, ldc, m, n, tb, shape, lower;   // shape 0: 32 x 128 tiles, 1: 128 x 32, 2: 64 x 64 ; lower: skip tiles above the diagonal
+  double alpha, beta;
+};
+#define FAC_LD 68
+#define FAC_LDS_BYTES ((size_t)160 * FAC_LD * sizeof(double))
+
+template <int WM, int WN, bool TB>
+__device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double* As, double* Bs) {
+  constexpr int TM = 32 * WM, TN = 32 * WN;
+  constexpr int NA = TM * 32 / 256;                 // d2 loads per thread for a [TM][64] half of A (8 .. 16 .. 4)
+  constexpr int NB = TN * 32 / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wi = (wave / WN) * 32, wj = (wave % WN) * 32;
+  d2 ra[NA], rb[NB];
+  auto load_half = [&](int kh) {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + 256 * u, x = e >> 5, k2 = e & 31;          // 32 d2 per row of 64 k
+      ra[u] = *reinterpret_cast<const d2*>(g.A + (size_t)(i0 + x) * g.lda + 64 * kh + 2 * k2);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = tid + 256 * u;
+      if (TB) {
+        const int x = e >> 5, k2 = e & 31;
+        rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)(j0 + x) * g.ldb + 64 * kh + 2 * k2);
+      } else {
+        const int kk = e / (TN / 2), x2 = e % (TN / 2);                // TN / 2 d2 per k row
+        rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)(64 * kh + kk) * g.ldb + j0 + 2 * x2);
+      }
+    }
+  };
+  auto store_half = [&]() {
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+      const int e = tid + 256 * u, x = e >> 5, k2 = e & 31;
+      *reinterpret_cast<d2*>(As + x * FAC_LD + 2 * k2) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = tid + 256 * u;
+      if (TB) {
+        const int x = e >> 5, k2 = e & 31;
+        *reinterpret_cast<d2*>(Bs + x * FAC_LD + 2 * k2) = rb[u];
+      } else {
+        const int kk = e / (TN / 2), x2 = e % (TN / 2);
+        Bs[(2 * x2) * FAC_LD + kk] = rb[u][0];
+        Bs[(2 * x2 + 1) * FAC_LD + kk] = rb[u][1];
+      }
+    }
+  };
+  // the epilogue's read of C (beta != 0) is requested with the first operands
+  double cold[2][2][4];
+  const bool hb = g.beta != 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        cold[a][b][rr] = hb ? g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] : 0.0;
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = {0, 0, 0, 0};
+  load_half(0);
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) {
+    store_half();
+    __syncthreads();
+    if (kh == 0) load_half(1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = As[(wi + 16 * a + r) * FAC_LD + 4 * s + q];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = Bs[(wj + 16 * b + r) * FAC_LD + 4 * s + q];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = TGP_MFMA(af[a], bf[b], acc[a][b]);
+    }
+    __syncthreads();   // every wave is done with this half before the next one overwrites it
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr];
+}
+
+__device__ __forceinline__ void fac_job(const FacJob& g, int L, double* As, double* Bs) {
+  const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
+  const int gx = g.n / TN, bx = L % gx, by = L / gx;
+  const int i0 = by * TM, j0 = bx * TN;
+  if (g.lower && j0 > i0) return;
+  if (g.shape == 0) { if (g.tb) fac_tile<1, 4, true>(g, i0, j0, As, Bs); else fac_tile<1, 4, false>(g, i0, j0, As, Bs); }
+  else if (g.shape == 1) { if (g.tb) fac_tile<4, 1, true>(g, i0, j0, As, Bs); else fac_tile<4, 1, false>(g, i0, j0, As, Bs); }
+  else { if (g.tb) fac_tile<2, 2, true>(g, i0, j0, As, Bs); else fac_tile<2, 2, false>(g, i0, j0, As, Bs); }
+}
+
+__global__ __launch_bounds__(256) void k_fac_pair(FacJob a, FacJob b, int na) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fac_smem[];
+  double* As = reinterpret_cast<double*>(fac_smem);
+  double* Bs = As + 128 * FAC_LD;                    // A tile: at most 128 rows; B tile: at most 128
+  const int L = blockIdx.x;
+  if (L < na) fac_job(a, L, As, Bs);
+  else fac_job(b, L - na, As, Bs);
+}
+
+static int fac_tiles(const FacJob& g) {
+  const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
+  return (g.m / TM) * (g.n / TN);
+}
+static FacJob fac_job_args(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int n, int tb, int shape,
+                           double alpha, double beta, int lower = 0) {
+  FacJob g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.m = m; g.n = n; g.tb = tb; g.shape = shape; g.lower = lower;
+  g.alpha = alpha; g.beta = beta;
+  return g;
+}
+// one or two jobs in one launch (b.m == 0: only a)
+static int launch_fac_pair(const FacJob& a, const FacJob& b, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fac_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(2 * 128 * FAC_LD * sizeof(double)));
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    attr_done = true;
+  }
+  const int na = fac_tiles(a), nb2 = b.m > 0 ? fac_tiles(b) : 0;
+  hipLaunchKernelGGL(k_fac_pair, dim3(na + nb2), dim3(256), 2 * 128 * FAC_LD * sizeof(double), st, a, b, na);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // a (op(B) transposed) and b (no transposition) in one launch, both plain or both with the C epilogue -- the shapes the
 // blocked factorisation pairs up; anything else: two launches
 static int launch_gemm_pair_ft_ff(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t st) {
@@ -942,35 +1095,30 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
   const int MP = p.MP, nb = MP / 128;
   double* Lm = ws + p.Lm;
   double* J = ws + p.J;
+  FacJob none;
+  none.m = 0; none.n = 0; none.shape = 2;
   for (int kb = 0; kb < nb; ++kb) {
     hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
     LAUNCH_CHECK();
     const int rem = MP - (kb + 1) * 128;
     double* Jk = J + (size_t)kb * 128 * MP;                          // block row kb of J
     const double* Jkk = Jk + (size_t)kb * 128;
-    // in place: each workgroup reads exactly the tile it overwrites
-    const GemmArgs inv_row = gemm_args(Jkk, MP, Jk, MP, Jk, MP, 128, 128 * kb, 128, -1.0, 0.0);
+    // J[kb, 0:kb] = -J_kk Acc[kb, 0:kb]  in place (128 x 32 tiles: a workgroup owns its columns)
+    const FacJob inv_row = fac_job_args(Jkk, MP, Jk, MP, Jk, MP, 128, 128 * kb, 0, 1, -1.0, 0.0);
     const bool row = want_inverse && kb >= 1;
     if (rem > 0) {
       double* panel = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)kb * 128;
-      // L[i,kb] = K[i,kb] J_kk^T   (in place as well)
-      const GemmArgs pan = gemm_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 128);
-      // trailing update K[i,j] -= L[i,kb] L[j,kb]^T, lower block triangle
+      // L[i,kb] = K[i,kb] J_kk^T  in place (32 x 128 tiles: a workgroup owns its rows)
+      const FacJob pan = fac_job_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 1, 0, 1.0, 0.0);
+      // trailing update K[i,j] -= L[i,kb] L[j,kb]^T, lower part (64 x 64 tiles)
       double* trail = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)(kb + 1) * 128;
-      const GemmArgs upd = gemm_args(panel, MP, panel, MP, trail, MP, rem, rem, 128, -1.0, 1.0, TRI_C_LOWER);
-      const GemmArgs push = gemm_args(panel, MP, Jk, MP, J + (size_t)(kb + 1) * 128 * MP, MP, rem, 128 * (kb + 1), 128, 1.0, 1.0);
-      if (row) {
-        if (int rc = launch_gemm_pair_ft_ff(pan, inv_row, st)) return rc;
-      } else {
-        GEMM(false, true, pan);
-      }
-      if (want_inverse) {
-        if (int rc = launch_gemm_pair_ft_ff(upd, push, st)) return rc;
-      } else {
-        GEMM(false, true, upd);
-      }
+      const FacJob upd = fac_job_args(panel, MP, panel, MP, trail, MP, rem, rem, 1, 2, -1.0, 1.0, 1);
+      // Acc[i, 0:kb+1] += L[i,kb] J[kb, 0:kb+1]
+      const FacJob push = fac_job_args(panel, MP, Jk, MP, J + (size_t)(kb + 1) * 128 * MP, MP, rem, 128 * (kb + 1), 0, 2, 1.0, 1.0);
+      if (int rc = launch_fac_pair(pan, row ? inv_row : none, st)) return rc;
+      if (int rc = launch_fac_pair(upd, want_inverse ? push : none, st)) return rc;
     } else if (row) {
-      GEMM(false, false, inv_row);
+      if (int rc = launch_fac_pair(inv_row, none, st)) return rc;
     }
   }
   return 0;
