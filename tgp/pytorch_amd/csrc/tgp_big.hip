@@ -184,6 +184,7 @@ static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   const int nj = g.n / GT, nb = g.m / GT;
   dim3 grid(g.pair ? (nj + 1) / 2 : nj, nb, g.ksplit), block(256);
   if (g.xcd == 3) grid = dim3(nb * (nb + 1) / 2 * g.ksplit, 1, 1);
+  if (g.xcd == 4) grid.y = (nb + 7) & ~7;   // whole groups of 8 tile rows (one per XCD); the padding rows return at once
   hipLaunchKernelGGL((k_gemm<TA, TB, MOD, EPI>), grid, block, GEMM_LDS_BYTES, st, g);
   LAUNCH_CHECK();
   return 0;
@@ -205,9 +206,26 @@ static int gemm_normalise(GemmArgs& g) {
        reinterpret_cast<uintptr_t>(g.k_scale)) & 15)
     return -1;
   if (g.add != nullptr && g.beta != 0.0) return -1;  // the epilogue reads one extra matrix, not two
+  if (g.xcd == 4) g.xcd = 1;   // 4 is the launcher's own choice (below)
   // triangular op(B) without split-K: pair column tiles so that all workgroups run the same number of stages
   g.pair = ((g.tri & (TRI_B_LOWER | TRI_B_UPPER)) && !(g.tri & (TRI_A_LOWER | TRI_A_UPPER | TRI_C_LOWER)) && g.ksplit == 1 &&
             g.n / GT > 1) ? 1 : 0;
+  if (g.pair) {
+    // Pairing makes every workgroup equal (nj + 1 k-blocks) but halves their number: with 1-2 workgroups per CU that can
+    // leave a quarter of the chip with twice the work (a 10 000-row minibatch at M = 1000: 316 workgroups of 9 blocks on
+    // 256 CUs = 18 block times against 2844 / 256 = 11.1).  Estimate both in k-block times; where the unpaired launch is
+    // better it runs in the per-XCD heaviest-column-first order (xcd 4): the long workgroups start at once, the short
+    // ones fill the end of the launch (measured on that minibatch: 317 us paired, 300 unpaired in row order, 250 in
+    // this order; one workgroup per CU instead of two was slower).
+    const long nrow = g.m / GT, nj = g.n / GT;
+    const long paired = ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1);
+    long unpaired = (nrow * nj * (nj + 1) / 2 + 255) / 256;
+    if (unpaired < nj) unpaired = nj;
+    if (unpaired * 108 < paired * 100) {
+      g.pair = 0;
+      g.xcd = 4;
+    }
+  }
   if ((g.tri & TRI_C_LOWER) && g.ksplit > 1 && g.m == g.n && !(g.tri & ~TRI_C_LOWER)) g.xcd = 3;
   else if (g.xcd == 3) g.xcd = 0;
   return 0;

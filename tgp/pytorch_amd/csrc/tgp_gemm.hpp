@@ -52,7 +52,8 @@ struct GemmArgs {
   int pair;            // set by the launcher: triangular op(B), column tiles j and n/128-1-j handled by one workgroup
   int xcd;             // workgroup -> tile mapping: 0 natural, 1 all column tiles of a tile ROW share an XCD (they
                        // re-read the same op(A) rows), 2 all tiles of a k SLAB share an XCD (split-K operands),
-                       // 3 (set by the launcher for TRI_C_LOWER + split-K) compact lower-triangle enumeration
+                       // 3 (set by the launcher for TRI_C_LOWER + split-K) compact lower-triangle enumeration,
+                       // 4 (set by the launcher for an unpaired triangular op(B)) per-XCD heavy-column-first order
 };
 
 inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int n, int k,
@@ -281,6 +282,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int rest = s % per;
     by = rest / gx;
     bx = rest % gx;
+  } else if (g.xcd == 4 && ((int)gridDim.y & 7) == 0) {
+    // unpaired triangular op(B): every XCD (id = linear id mod 8) owns the tile rows by = xcd, xcd + 8, ... and walks them
+    // column tile by column tile, HEAVIEST column first -- the column tiles of a row still start together (they share the
+    // op(A) rows in that XCD's L2) and what is left for the end of the launch are the short tiles
+    const int gx = gridDim.x, L = bx + gx * by, xc = L & 7, sq = L >> 3, nrx = (int)gridDim.y >> 3;
+    const int w = sq / nrx;
+    by = xc + 8 * (sq % nrx);
+    bx = (g.tri & TRI_B_LOWER) ? w : gx - 1 - w;
+    if (by * GT >= g.m) return;   // the launcher rounds the tile rows up to a multiple of 8
   } else if (g.xcd == 3) {
     // compact split-K enumeration of the lower block triangle: gridDim.x = ntl * ksplit, slab-major, and the ids
     // that share an XCD (same id mod 8) take a contiguous run of (slab, tile) pairs -- equal load per XCD and the
