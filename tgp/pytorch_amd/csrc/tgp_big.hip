@@ -1188,14 +1188,10 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
     if (int rc = fk.after(0, st, sx)) return rc;
     sh = sx;
   }
-  // (deferred, the product runs unsplit -- every split-k scratch is in use by the row phase it runs beside; its 64
-  //  workgroups take ~150 us of the 1.8 ms the first chunk's full-chip GEMMs need)
-  if (defer_hw) {
-    if (int rc = launch_gemm(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER), sh))
-      return rc;
-  } else {
-    GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER));
-  }
+  // (split-k either way: the scratch of gemm_mm is not used by the row phase, and the main stream's next user -- the
+  //  backward chain -- comes after the join; unsplit, the 64 long workgroups slowed the first row product by 90 us)
+  if (int rc = gemm_mm(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.Hp, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER), p, ws, sh))
+    return rc;
   hipLaunchKernelGGL(k_big_wvec, dim3(MP / 64), dim3(WVEC_THREADS), 0, sh, p, ws);
   LAUNCH_CHECK();
   return 0;
