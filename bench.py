@@ -54,6 +54,10 @@ WORKLOADS = {
     # BASELINE.json configs[4], one GPU's shard of the 2M-row full batch (8 x 250k), reference's airline flow 5x6
     "tgp_airline_tanh5x6": dict(N=250000, D=8, M=1000, S=32, flow="tanh5x6", B=5, c=52),
     "tgp_airline_mb10k": dict(N=10000, D=8, M=1000, S=32, flow="tanh5x6", B=5, c=52),    # C5b: minibatch 10k rows
+    # one GPU's 1/8 of that minibatch (SURVEY 8d, C5b "1250 rows/GPU"): what a rank of the 8-GPU run computes per step --
+    # the replicated M x M phases and 1 250 rows (run it with `--gpus 8 --scaling strong --workload tgp_airline_mb10k`
+    # on a node; this single-GPU workload shows the per-rank step without the collective)
+    "tgp_airline_mb10k_rank8": dict(N=1250, D=8, M=1000, S=32, flow="tanh5x6", B=5, c=52),
 }
 
 

@@ -235,9 +235,33 @@ static bool gemm_has_epi(const GemmArgs& g) {
   return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
 }
 
+static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st);
+
 int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   if (gemm_normalise(g)) return -1;
+  {
+    // products without operand modifiers, with a (possibly triangular) op(B), whose 128 x 128 tiling leaves the chip mostly
+    // idle: 64 x 64 tiles.
+    // Times in units of one 128^3 k-block on a CU: the big tiling's longest workgroup / balance, against the small
+    // tiling's (a 64^3 block is 1/8 of it, two resident workgroups share a CU).
+    const bool plain = !ta && !gemm_has_mod(g) && g.ksplit == 1 && !(g.tri & ~(TRI_B_LOWER | TRI_B_UPPER)) && g.k % 64 == 0;
+    if (plain) {
+      const long nrow = g.m / GT, nj = g.n / GT, kb = g.k / GT;
+      const bool tri = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) != 0;
+      const long per_row = tri ? nj * (nj + 1) / 2 : nj * kb;
+      const long longest = tri ? nj : kb;
+      long big = g.pair ? ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1) : (nrow * per_row + 255) / 256;
+      if (!g.pair && big < longest) big = longest;
+      // small tiling, in eighths of a block time: total / 256 CUs, or the longest tile at half rate
+      const long nj2 = 2 * nj, rows2 = (g.m + 63) / 64;
+      const long per_row2 = tri ? nj2 * (nj2 + 1) / 2 : nj2 * 2 * kb;
+      long small8 = (rows2 * per_row2 + 255) / 256;
+      const long longest2 = 2 * (tri ? nj2 : 2 * kb);
+      if (small8 < longest2) small8 = longest2;
+      if (small8 * 10 < big * 8 * 7) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
+    }
+  }
   const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
   const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
   if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
@@ -393,6 +417,167 @@ static int launch_fac_pair(const FacJob& a, const FacJob& b, hipStream_t st) {
   }
   const int na = fac_tiles(a), nb2 = b.m > 0 ? fac_tiles(b) : 0;
   hipLaunchKernelGGL(k_fac_pair, dim3(na + nb2), dim3(256), 2 * 128 * FAC_LD * sizeof(double), st, a, b, na);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_gemm64: C = alpha op(A) op(B) on 64 x 64 tiles (4 waves x 32 x 32), any k (multiple of 64), A stored [m][k], B
+// stored [n][k] (TB) or [k][n]; triangular op(B) trims the k range per column tile.  For products whose 128 x 128 tiling
+// cannot fill the chip (a rank's 1 250 rows of an 8-GPU minibatch: 10 tile rows x 8 columns = 80 workgroups, the longest
+// walking 8 k-blocks of 16.5 us one after the other): four times the workgroups, a quarter of the time per k-block.
+// Unpaired, per-XCD heaviest-column-first order (as k_gemm's xcd 4).  K advances 64 per stage through one LDS buffer per
+// operand, the next stage's global loads in flight under the current stage's MFMAs.
+// ---------------------------------------------------------------------------------------------------
+struct G64Args {
+  const double* A;
+  const double* B;
+  double* C;
+  int lda, ldb, ldc, m, n, k, tb, tri;
+  double alpha;
+  // epilogue of k_gemm (EPI): x = alpha acc + gamma add ; C = x col_scale row_scale + rowv colv + beta C
+  const double* add;
+  int ldadd;
+  double gamma, beta;
+  const double* col_scale;
+  const double* row_scale;
+  const double* rowv;
+  const double* colv;
+};
+
+template <bool TB, bool EPI>
+__device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  int kb = 0, ke = g.k;
+  if (g.tri & TRI_B_LOWER) kb = max(kb, j0);
+  if (g.tri & TRI_B_UPPER) ke = min(ke, j0 + 64);
+  d2 ra[8], rb[8];
+  auto load_stage = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u, x = e >> 5, k2 = e & 31;
+      ra[u] = *reinterpret_cast<const d2*>(g.A + (size_t)(i0 + x) * g.lda + k0 + 2 * k2);
+      if (TB) rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)(j0 + x) * g.ldb + k0 + 2 * k2);
+      else rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)(k0 + (e >> 5)) * g.ldb + j0 + 2 * (e & 31));
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + 256 * u, x = e >> 5, k2 = e & 31;
+      *reinterpret_cast<d2*>(As + x * FAC_LD + 2 * k2) = ra[u];
+      if (TB) *reinterpret_cast<d2*>(Bs + x * FAC_LD + 2 * k2) = rb[u];
+      else {
+        Bs[(2 * k2) * FAC_LD + x] = rb[u][0];        // here x is the k row (e >> 5) and k2 the column pair
+        Bs[(2 * k2 + 1) * FAC_LD + x] = rb[u][1];
+      }
+    }
+  };
+  d4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = {0, 0, 0, 0};
+  if (kb < ke) load_stage(kb);
+  for (int k0 = kb; k0 < ke; k0 += 64) {
+    store_stage();
+    __syncthreads();
+    if (k0 + 64 < ke) load_stage(k0 + 64);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = As[(wi + 16 * a + r) * FAC_LD + 4 * s + q];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = Bs[(wj + 16 * b + r) * FAC_LD + 4 * s + q];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = TGP_MFMA(af[a], bf[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  if (!EPI) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr];
+  } else {
+    // the same arithmetic, in the same order, as k_gemm's EPI epilogue (every read issued ahead of the stores)
+    const bool ha = g.add != nullptr;
+    const double* __restrict__ E = ha ? g.add : g.C;
+    const int lde = ha ? g.ldadd : g.ldc;
+    const bool he = ha || g.beta != 0.0;
+    const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
+    double rs[2][4], rv[2][4], ein[2][2][4], cs[2], cv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = i0 + wi + 16 * a + q + 4 * rr;
+        rs[a][rr] = g.row_scale ? g.row_scale[row] : 1.0;
+        rv[a][rr] = g.rowv ? g.rowv[row] : 0.0;
+      }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + wj + 16 * b + r;
+      cs[b] = g.col_scale ? g.col_scale[col] : 1.0;
+      cv[b] = g.colv ? g.colv[col] : 0.0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ein[a][b][rr] = he ? E[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * lde + col] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          double x = g.alpha * acc[a][b][rr] + ca * ein[a][b][rr];
+          x = x * cs[b] * rs[a][rr] + rv[a][rr] * cv[b] + cb * ein[a][b][rr];
+          g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = x;
+        }
+  }
+}
+
+template <bool EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm64(G64Args g, int gx, int gy8) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char g64_smem[];
+  double* As = reinterpret_cast<double*>(g64_smem);
+  double* Bs = As + 64 * FAC_LD;
+  // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
+  const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
+  const int w = sq / nrx, by = xc + 8 * (sq % nrx);
+  int bx = w;
+  if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
+  if (by * 64 >= g.m) return;
+  if (g.tb) g64_tile<true, EPI>(g, by * 64, bx * 64, As, Bs);
+  else g64_tile<false, EPI>(g, by * 64, bx * 64, As, Bs);
+}
+
+static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st) {
+  static bool attr_done[2] = {false, false};
+  const size_t lds = (size_t)2 * 64 * FAC_LD * sizeof(double);
+  const bool epi = gemm_has_epi(g);
+  const void* f = epi ? reinterpret_cast<const void*>(k_gemm64<true>) : reinterpret_cast<const void*>(k_gemm64<false>);
+  if (!attr_done[epi]) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    attr_done[epi] = true;
+  }
+  G64Args a;
+  a.A = g.A; a.B = g.B; a.C = g.C; a.lda = g.lda; a.ldb = g.ldb; a.ldc = g.ldc; a.m = g.m; a.n = g.n; a.k = g.k; a.tb = tb ? 1 : 0;
+  a.tri = g.tri; a.alpha = g.alpha;
+  a.add = g.add; a.ldadd = g.ldadd; a.gamma = g.gamma; a.beta = g.beta; a.col_scale = g.col_scale; a.row_scale = g.row_scale;
+  a.rowv = g.rowv; a.colv = g.colv;
+  const int gx = g.n / 64, gy8 = (g.m / 64 + 7) & ~7;
+  if (epi) hipLaunchKernelGGL(k_gemm64<true>, dim3((unsigned)(gx * gy8)), dim3(256), lds, st, a, gx, gy8);
+  else hipLaunchKernelGGL(k_gemm64<false>, dim3((unsigned)(gx * gy8)), dim3(256), lds, st, a, gx, gy8);
   LAUNCH_CHECK();
   return 0;
 }
