@@ -196,6 +196,10 @@ int tgp_gemm_f64(int32_t trans_a, int32_t trans_b, int32_t tri, int32_t m, int32
 int tgp_kl_whitened_f64(const double* m, const double* Lam, int32_t M, double* out, double* g_m, double* g_Lam,
                         void* stream);
 
+/* Workspace of the two stand-alone likelihood entries below (per-workgroup partial sums; the workgroup count depends on
+ * N: the flow kernel gives small problems 16 lanes per row instead of 4). */
+size_t tgp_ell_workspace_bytes(int32_t N, int32_t P, int32_t RP);
+
 /* SVGP closed-form expected log-likelihood (likelihoods/GaussianLinearMean.py:60-87 + dsp/utils.py:164-195),
  * summed over rows and multiplied by `scale`.  out[0] = ELL, out[1] = dELL/dlog_var_noise; g_mu, g_v: (N). */
 int tgp_ell_gauss_f64(const double* Y, const double* mu, const double* v, int32_t N, const double* log_var_noise,

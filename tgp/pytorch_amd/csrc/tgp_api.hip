@@ -194,6 +194,11 @@ int tgp_knm_f64(const double* X, const double* Z, const double* raw_ls, const do
   return launch_knm(X, Z, raw_ls, raw_os, N, M, D, K, static_cast<hipStream_t>(stream));
 }
 
+size_t tgp_ell_workspace_bytes(int32_t N, int32_t P, int32_t RP) {
+  if (N < 1 || P < 0 || RP < 0) return 0;
+  return tgp::lik_workspace_doubles(N, P, RP) * sizeof(double);
+}
+
 size_t tgp_cholesky_workspace_bytes(int32_t M) {
   if (M <= TGP_FUSED_MAX_M) return 0;
   return big_cholesky_workspace_doubles(M) * sizeof(double);

@@ -15,8 +15,14 @@ namespace tgp {
     if (e_ != hipSuccess) return set_error(e_, __FILE__, __LINE__); \
   } while (0)
 
+// k_ell_flow: lanes per data row.  4 by default (64 rows per workgroup); 16 for small problems (16 rows per workgroup): a
+// rank's 1 250 rows of an 8-GPU minibatch were 20 workgroups, each lane walking 8 quadrature nodes through 30 tanh steps
+// and back -- 91 us of one dependent chain, whatever N; with 16 lanes per row a lane has 2 nodes and 79 workgroups run.
+static int ell_flow_lpr(int N) { return N <= 4096 ? 16 : 4; }
+
 size_t lik_workspace_doubles(int N, int P, int RP) {
-  const size_t nb = (size_t)(N + 63) / 64 + 1;  // k_ell_flow: 64 rows per block
+  const int rows = 256 / ell_flow_lpr(N);
+  const size_t nb = (size_t)(N + rows - 1) / rows + 1;  // k_ell_flow: one partial per workgroup
   return nb * (size_t)(2 + P) + 2 * (size_t)P + 64;
 }
 
@@ -362,23 +368,31 @@ static int flow_lds(const tgp_model& md, int nblk, int NB, size_t* bytes) {
 int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, const double* mu, const double* v, const double* rowp,
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st) {
-  // 4 lanes per row; nodes in flight per lane: all of the lane's nodes when the checkpoint stack fits (the per-step
-  // wave reductions of the shared-parameter partials are then paid once), else fewer
+  // nodes in flight per lane: all of the lane's nodes when the checkpoint stack fits (the per-step wave reductions of
+  // the shared-parameter partials are then paid once), else fewer
   size_t lds = 0;
-  int NB = md.S > 16 ? 8 : 4;
+  const int LPR = ell_flow_lpr(md.N);
+  int NB = LPR == 4 ? (md.S > 16 ? 8 : 4) : (md.S > 32 ? 4 : (md.S > 16 ? 2 : 1));
   while (NB > 1 && (flow_lds(md, fp.nblk, NB, &lds) != 0 || lds > 120 * 1024)) NB >>= 1;
   if (int rc = flow_lds(md, fp.nblk, NB, &lds)) return rc;
-  const int nb = (md.N + 63) / 64;
-  static size_t cur[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
-#define ELLF_LAUNCH(nbv, slot)                                                                                            \
-  do {                                                                                                                    \
-    if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow<4, nbv>), lds, &cur[slot])) return rc;               \
-    hipLaunchKernelGGL((k_ell_flow<4, nbv>), dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp); \
+  const int rows = 256 / LPR;
+  const int nb = (md.N + rows - 1) / rows;
+  static size_t cur[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+#define ELLF_LAUNCH(lpr, nbv, slot)                                                                                         \
+  do {                                                                                                                      \
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow<lpr, nbv>), lds, &cur[slot])) return rc;               \
+    hipLaunchKernelGGL((k_ell_flow<lpr, nbv>), dim3(nb), dim3(256), lds, st, md, fp, Y, mu, v, rowp, ws, g_mu, g_v, g_rowp); \
   } while (0)
-  if (NB == 8) ELLF_LAUNCH(8, 0);
-  else if (NB == 4) ELLF_LAUNCH(4, 1);
-  else if (NB == 2) ELLF_LAUNCH(2, 2);
-  else ELLF_LAUNCH(1, 3);
+  if (LPR == 4) {
+    if (NB == 8) ELLF_LAUNCH(4, 8, 0);
+    else if (NB == 4) ELLF_LAUNCH(4, 4, 1);
+    else if (NB == 2) ELLF_LAUNCH(4, 2, 2);
+    else ELLF_LAUNCH(4, 1, 3);
+  } else {
+    if (NB == 4) ELLF_LAUNCH(16, 4, 4);
+    else if (NB == 2) ELLF_LAUNCH(16, 2, 5);
+    else ELLF_LAUNCH(16, 1, 6);
+  }
 #undef ELLF_LAUNCH
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_parts, dim3((2 + md.P + 31) / 32), dim3(256), 0, st, ws, nb, 2 + md.P, out, g_theta, 2);

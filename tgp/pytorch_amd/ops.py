@@ -381,8 +381,7 @@ def ell_flow(Y, mu, v, lvn, flow, theta, S, rowp=None, scale=1.0):
     theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
     dev, N = Y.device, Y.numel()
     md, keep = _flow_model(N, S, flow, theta, lvn, dev, scale)
-    nws = (N // 64 + 2) * (2 + flow.P) + 2 * flow.P + 128
-    ws = torch.empty(nws, dtype=torch.float64, device=dev)
+    ws = torch.empty(lib.tgp_ell_workspace_bytes(N, flow.P, md.RP) // 8 + 16, dtype=torch.float64, device=dev)
     out = torch.empty(2, dtype=torch.float64, device=dev)
     gmu, gv = torch.empty_like(mu), torch.empty_like(v)
     gth = torch.empty(max(flow.P, 1), dtype=torch.float64, device=dev)
