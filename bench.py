@@ -262,14 +262,22 @@ def main():
             for ek, st in extra:
                 with torch.cuda.stream(st):
                     (ek.step if args.no_graph else ek.replay)()
-    for _ in range(args.warmup):
-        run()
+    # K steps: single-rank graph runs go through the engine's unrolled graph (U steps per graph launch, the remainder one
+    # by one -- engine.replay_many; `config.launch` names U); everything else step by step
+    many = (not args.no_graph) and not extra and world == 1 and getattr(eng, "gU", None) is not None
+
+    def run_steps(k):
+        if many:
+            eng.replay_many(k)
+        else:
+            for _ in range(k):
+                run()
+    run_steps(args.warmup)
     dts = []
     for _ in range(max(args.repeats, 1)):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        run_steps(args.steps)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -326,7 +334,7 @@ def main():
             "repeats": len(dts), "ms_per_step_min": 1e3 * dts[0] / args.steps, "ms_per_step_max": 1e3 * dts[-1] / args.steps,
             "config": {"workload": args.workload, "rows_per_gpu": int(Xr.shape[0]), "D": w["D"], "M": w["M"], "S": w["S"],
                        "flow": w["flow"], "global_rows_per_step": n_global, "parallelism": "row-shard x%d" % world,
-                       "launch": "eager" if args.no_graph else "hipgraph", "final_elbo": elbo, "process_group": pg,
+                       "launch": "eager" if args.no_graph else ("hipgraph, %d steps per graph launch" % eng.unroll if many else "hipgraph"), "final_elbo": elbo, "process_group": pg,
                        "replicas": 1 + len(extra)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

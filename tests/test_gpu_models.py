@@ -556,6 +556,42 @@ def test_engine_id_tgp_hip_mlps_match_oracle_adam_history(graph):
     assert rel_err(eng.fp.view("Z").cpu(), leaves["Z"].detach()) < 1e-7
 
 
+@pytest.mark.parametrize("flow", ["tanh3x2", "idsal3"])
+def test_unrolled_graph_equals_single_step_replays(flow):
+    """engine.replay_many: U steps per graph launch (the second captured graph) + the remainder one by one, against the
+    same number of single-step replays: scalars of EVERY step (the unrolled steps write theirs to engine.hist_u through
+    the step's redirected `out` argument) and the final parameters, bit for bit."""
+    import bench
+    from tgp.pytorch_amd.engine import ElboEngine
+    w = dict(N=700, D=4, M=30, S=12, flow=flow, B=3, c=20, mlp=dict(H=50, L=2, p=0.25))
+    prob = orc.synthetic_problem(w["N"], w["D"], w["M"], seed=6, flow=flow, S=w["S"])
+    kw = {}
+    if flow == "idsal3":
+        spec, W0 = bench.make_mlp(w, seed=0)
+        kw = dict(mlp=spec, mlp_weights=W0, mlp_training=True)      # dropout on: the masks follow the device step counter
+
+    def make():
+        return ElboEngine(prob["X"], prob["Y"], prob["params"], float(prob["N_total"]), flow_blocks=prob["program"], S=w["S"],
+                          device=DEV, **kw)
+    n = 11                                       # 2 x U(4) + 3 single steps
+    e1 = make()
+    e1.capture(unroll=1)
+    assert e1.gU is None
+    h1 = torch.zeros(n, 3, dtype=torch.float64, device=DEV)
+    e1.replay_many(n, h1)
+    eu = make()
+    eu.capture(unroll=4)
+    assert eu.unroll == 4 and eu.gU is not None
+    hu = torch.zeros(n, 3, dtype=torch.float64, device=DEV)
+    eu.replay_many(n, hu)
+    torch.cuda.synchronize()
+    e1.check_status(); eu.check_status()
+    assert torch.equal(h1, hu), (h1 - hu).abs().max()
+    assert torch.equal(e1.fp.data, eu.fp.data)
+    assert torch.equal(e1.fp.out[:3], eu.fp.out[:3]) and torch.equal(hu[-1], eu.fp.out[:3])
+    assert float((hu[1:, 0] - hu[:-1, 0]).abs().min()) > 0.0          # eleven different steps, not one step eleven times
+
+
 def test_device_jitter_ladder_inside_the_captured_step():
     """The resident engine cannot ask the host to retry a failed Cholesky: psd_safe_cholesky's ladder (dsp/utils.py:256-269)
     runs inside k_prep_a.  Duplicated inducing points: without the ladder the status word reports the pivot; with it the

@@ -159,13 +159,18 @@ class ElboEngine:
             self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
         self._side = None
         self.pipeline_steps = True      # ID_TGP, one rank: capture the rotated unit (see capture())
+        self._out = None                # redirected scalar output while the unrolled graph is being captured
+        self.unroll = 1                 # steps per replay of self.gU (capture())
+        self.gU = None
+        self.hist_u = None
         self.graph = None
         self._warm = False
 
     # ---- one step, eager launches ------------------------------------------------------------------
     def elbo(self, phases=7):
+        out = self.fp.out if self._out is None else self._out      # (ELBO, ELL, KL) of this step: see capture(unroll)
         rc = self.lib.tgp_elbo_step_phases_f64(self.md, L.ptr(self.X), L.ptr(self.Y), L.ptr(self.rowp),
-                                               L.ptr(self.fp.out), self.gs, None, None, L.ptr(self.status),
+                                               L.ptr(out), self.gs, None, None, L.ptr(self.status),
                                                L.ptr(self.ws), self.ws.numel() * 8, phases, L.stream_ptr())
         L.check(rc, "tgp_elbo_step_phases_f64")
         self._warm = True
@@ -246,7 +251,7 @@ class ElboEngine:
             self.post_step()
 
     # ---- HIP graph ----------------------------------------------------------------------------------
-    def capture(self, with_allreduce=None):
+    def capture(self, with_allreduce=None, unroll=None):
         """Capture one full step.  With world_size > 1 the all-reduce stays outside (two graphs) unless
         with_allreduce=True."""
         if not self._warm:
@@ -267,8 +272,7 @@ class ElboEngine:
             self.elbo(1)
             self.mlp_forward(self.step_nn)
             torch.cuda.synchronize()
-            self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
+            def unit():
                 main = torch.cuda.current_stream()
                 side = self._side
                 self.elbo(2)
@@ -286,6 +290,10 @@ class ElboEngine:
                     self._adam_segment(n_plain, self.fp.n, self.nn_wd, self.step_nn)
                     self.mlp_forward(self.step_nn)
                 main.wait_stream(side)
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
+                unit()
+            self._capture_unrolled(unit, unroll)
             self.graph = "rotated"
             return
         if self.world_size > 1 and not with_allreduce:
@@ -301,14 +309,53 @@ class ElboEngine:
                 post()
             self.graph = "split"
         else:
-            self.g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
+            def unit():
                 pre()
                 self.forward_backward()
                 self.allreduce()
                 self.adam()
                 post()
+            self.g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
+                unit()
+            if self.world_size == 1:
+                self._capture_unrolled(unit, unroll)
             self.graph = "full"
+
+    def _capture_unrolled(self, unit, unroll):
+        """A second graph of U consecutive steps (one rank only).  Launching a graph costs ~5 us of idle GPU between two
+        replays of the 7-launch chain (14 us with the two-stream ID_TGP unit): U steps per launch pay it once (Power TGP
+        129.5 -> 125 us per step at U = 8-10, ID_TGP 148 -> 141).  The same kernels in the same order: results are
+        bit-identical to U single-step replays.  The scalars of the first U - 1 steps go to self.hist_u (the step's `out`
+        argument is redirected: no copy node), the last step's to fp.out as always."""
+        U = int(unroll if unroll is not None else os.environ.get("TGP_GRAPH_UNROLL", "10"))
+        self.unroll, self.gU = 1, None
+        if U < 2:
+            return
+        self.hist_u = torch.zeros(U - 1, 4, dtype=torch.float64, device=self.device)
+        self.gU = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gU, capture_error_mode=CAPTURE_MODE):
+            for u in range(U):
+                self._out = self.hist_u[u] if u < U - 1 else None
+                unit()
+        self._out = None
+        self.unroll = U
+
+    def replay_many(self, n, hist=None, row0=0):
+        """n steps: floor(n / U) replays of the unrolled graph, the rest one by one.  hist[row0 + i] <- (ELBO, ELL, KL) of
+        step i (device-to-device copies between replays, nothing synchronises)."""
+        k, U = 0, self.unroll
+        while self.gU is not None and n - k >= U:
+            self.gU.replay()
+            if hist is not None:
+                hist[row0 + k:row0 + k + U - 1].copy_(self.hist_u[:, :3])
+                hist[row0 + k + U - 1].copy_(self.fp.out[:3])
+            k += U
+        while k < n:
+            self.replay()
+            if hist is not None:
+                hist[row0 + k].copy_(self.fp.out[:3])
+            k += 1
 
     def replay(self):
         if self.graph in ("full", "rotated"):
@@ -407,9 +454,9 @@ class MinibatchEngine:
         self.cursor.zero_()
 
     def capture(self):
-        self.full.capture()
+        self.full.capture(unroll=1)      # steps are replayed one by one (per-step history copies, the ragged last batch)
         if self.last is not None:
-            self.last.capture()
+            self.last.capture(unroll=1)
 
     def run_epoch(self, hist=None, row0=0, replay=True):
         """One pass over the data: nfull full batches + the ragged one.  hist[row0 + i] <- (ELBO, ELL, KL) of step i."""

@@ -181,15 +181,19 @@ class Trainer_SP_regression:
         hist = torch.empty(max(n_epochs * spe, 1), 3, dtype=torch.float64, device=eng.device)
         t0 = time.time()
         last = 0
+        ep_done = 0
         for ep in range(n_epochs):
             if mb:
                 # the loader's own permutation stream (torch RandomSampler semantics), written to the device once per
                 # epoch; the batches are then gathered by index inside the captured steps
                 eng.set_order(self.train_loader.epoch_permutation())
                 eng.run_epoch(hist, ep * spe)
-            else:
-                eng.replay()
-                hist[ep].copy_(eng.fp.out[:3])          # device-to-device, no synchronisation
+            elif ep >= ep_done:
+                # one full-batch step per epoch: all epochs up to the next report in as few graph launches as the engine's
+                # unrolled graph allows (engine.replay_many); the scalars of every step land in `hist` on the device
+                nxt = n_epochs if self.validate_each <= 0 else min(n_epochs, (ep // self.validate_each + 1) * self.validate_each)
+                eng.replay_many(nxt - ep, hist, ep)
+                ep_done = nxt
             self.total_trainer_epochs += 1
             if self.validate_each > 0 and (ep + 1) % self.validate_each == 0:
                 h = hist[last * spe:(ep + 1) * spe].mean(0).cpu()     # the only host sync: once per `validate_each` epochs
