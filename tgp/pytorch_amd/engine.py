@@ -330,7 +330,7 @@ class ElboEngine:
         argument is redirected: no copy node), the last step's to fp.out as always."""
         U = int(unroll if unroll is not None else os.environ.get("TGP_GRAPH_UNROLL", "10"))
         self.unroll, self.gU = 1, None
-        if U < 2:
+        if U < 2 or (unroll is None and self.M > 128):      # general-M steps take milliseconds: nothing to gain, ~100 nodes each
             return
         self.hist_u = torch.zeros(U - 1, 4, dtype=torch.float64, device=self.device)
         self.gU = torch.cuda.CUDAGraph()
