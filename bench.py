@@ -2,21 +2,25 @@
 """bench.py -- ELBO-steps/sec of the TGP sparse-variational hot path on MI355X.
 
     python bench.py --gpus 1 --steps 2000 --warmup 100
+    python bench.py --gpus N --steps K --warmup W        (N > 1 and no RANK in the environment: bench.py starts its own N
+                                                          ranks -- a fresh `python -m torch.distributed.run` child, created
+                                                          BEFORE this process touches the GPU; it never execs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W           (the same thing with the launcher on the outside)
 
 One "step" = forward ELBO + backward + Adam update on one full Power-sized minibatch (reference semantics,
 code/dsp/trainers/trainer_base.py:337-342), float64 like the reference's main.py.  Default workload =
 BASELINE.json configs[2]: TGP on Power (N=8611 training rows, D=4), M=100, 3-block tanh flow (StepTanhL 3x2),
 S=32 Gauss-Hermite nodes; synthetic seeded data of that shape, data resident in HBM.
 Multi-GPU (one process per GPU, torch.distributed over RCCL): rows are sharded, ONE all-reduce of the flat
-[gradient | ELBO, ELL, KL] buffer per step, replicated Adam.  `--scaling weak` (default): every rank owns a
-workload-sized row shard of a W-times larger minibatch, `value` counts workload-sized shard-steps per second over the
-whole job.  `--scaling strong`: the SAME workload's rows are split W ways (north_star's "Power at 1/2/4/8 GPUs"; at
-Power size this cannot scale -- the replicated M x M work and the collective do not shrink -- and the line says what
-it measures), `value` = steps of the whole problem per second.  The documented BASELINE configs[4] line is
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus 8 --workload tgp_airline_tanh5x6 --steps 20 --warmup 3        (N = 2 M rows, 250 k per GPU)
+[gradient | ELBO, ELL, KL] buffer per step, replicated Adam.  `--scaling strong` (default for the Power / Boston
+workloads): the SAME problem's rows are split W ways -- north_star's "Power at 1/2/4/8 MI355X"; `value` = steps of the
+whole 8611-row problem per second (at this size it cannot scale: the replicated M x M work and the collective do not
+shrink, and the line says so by its number).  `--scaling weak` (default for the airline workloads, whose per-GPU shard
+is the workload): every rank owns a workload-sized row shard of a W-times larger minibatch, `value` counts
+workload-sized shard-steps per second over the whole job, and the metric string names the W x N-row minibatch it
+steps.  The documented BASELINE configs[4] line is
+    python bench.py --gpus 8 --workload tgp_airline_tanh5x6 --steps 20 --warmup 3     (N = 2 M rows, 250 k per GPU, weak)
 `--capture-allreduce` records the collective inside the HIP graph instead of between two graphs.
 
 Timing: after W warm-up steps the K steps are timed `--repeats` times (default 5), each repeat bracketed by a barrier +
@@ -63,6 +67,22 @@ WORKLOADS = {
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+BASELINE_METRIC = "ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32"
+
+
+def metric_name(workload, w, n_global):
+    """BASELINE.json's metric string ONLY for the configuration it is quoted on -- TGP on Power, the whole 8611-row problem
+    per step (one GPU, or its rows split over the ranks); anything else says what it steps."""
+    if workload == "tgp_power_tanh3x2" and n_global == w["N"]:
+        return BASELINE_METRIC
+    if n_global == w["N"]:
+        return "ELBO-steps/sec (N x M kernel + chol + flow), workload %s" % workload
+    # weak scaling: W workload-sized row shards of one W x N-row minibatch per step; `value` counts shard-steps
+    # (tgp_airline_tanh5x6 on 8 GPUs = BASELINE configs[4]: 8 x 250 000 = the 2 M-row full batch)
+    return ("ELBO shard-steps/sec (N x M kernel + chol + flow), workload %s: %d shards of %d rows = one %d-row "
+            "minibatch per step" % (workload, n_global // w["N"], w["N"], n_global))
 
 
 def rows_kernel_flops(w):
@@ -164,6 +184,24 @@ def cpu_baseline(prob, budget_s=15.0, max_steps=400, mlp=None):
                       "chosen by calibration), %.1f s" % (n, ns, N, ", rate scaled by rows" if ns < N else "", best, dt)}
 
 
+def launch_ranks(n):
+    """Parent of a multi-GPU run: `python -m torch.distributed.run` as a child process (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port), stdout / stderr inherited.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: starting %d ranks: %s" % (n, " ".join(cmd[1:])))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,13 +212,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K steps; the median is reported")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="default: strong for the Power / Boston workloads (north_star: the same problem on 1/2/4/8 GPUs), "
+                         "weak for the airline workloads (a rank's 250 k rows are 1/8 of configs[4])")
     ap.add_argument("--capture-allreduce", action="store_true", help="capture the collective inside the HIP graph")
     ap.add_argument("--replicas", type=int, default=1, help="(1 GPU only) K independent training runs of the workload on K "
                     "streams, value = their aggregate steps/s: how the chip is filled when several UCI splits train at once")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
                     "--pmc pass of THIS build (tools/probes/pmc_summary.py); without it roofline.traffic is null")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "weak" if args.workload.startswith("tgp_airline") else "strong"
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as the driver runs it: start the N ranks ourselves.  The parent has made NO GPU call
+        # yet (importing torch does not initialise HIP) and never execs: a fresh child runs the launcher, every rank
+        # re-enters this file with RANK / LOCAL_RANK / WORLD_SIZE set, rank 0 prints the JSON line on the inherited
+        # stdout, and the parent exits with the child's code.
+        return launch_ranks(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +243,9 @@ def main():
     # duplicate devices.  The measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("TGP_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (RCCL needs one device per rank; TGP_BENCH_BACKEND=gloo "
+                         "rehearses the multi-rank control flow on fewer)" % (world, ndev))
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -326,8 +378,7 @@ def main():
               "allreduce_doubles": eng.fp.n + eng.fp.extra}
         result = {
             # BASELINE.json's metric string for the configuration it is quoted on; other workloads say what they are
-            "metric": ("ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32" if args.workload == "tgp_power_tanh3x2"
-                       else "ELBO-steps/sec (N x M kernel + chol + flow), workload %s" % args.workload),
+            "metric": metric_name(args.workload, w, n_global),
             "value": units * args.steps / dt, "unit": "ELBO-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -351,4 +402,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -125,10 +125,6 @@ const char* tgp_last_error(void);
 /* sha256 (first 16 hex digits) of the kernel sources this library was compiled from (csrc Makefile SRC_HASH): the
    Python binding recomputes it from the tree and refuses a stale binary. */
 const char* tgp_source_hash(void);
-/* Row kernel of the fused training step (M <= 128): 0 = one wave per 16-row group (tgp_rows.hpp; default), 1 = the
-   team-split kernel (tgp_rows2.hpp: four waves per group, up to three groups per workgroup, every CU busy at Power
-   size) whenever the batch has at most 768 groups and its LDS image fits.  Process-wide; same results to rounding. */
-int tgp_set_rows_kernel(int32_t mode);
 
 /* Bytes of workspace the calls below need for a problem of this shape (training is the maximum). */
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP);

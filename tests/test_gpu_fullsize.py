@@ -77,58 +77,6 @@ def test_step0_matches_reference_at_full_size(name):
         assert float(((v - g["v"]).abs() / g["v"].abs()).max()) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["power_svgp", "power_sal2", "power_tanh3x2", "power_idsal3", "boston_svgp", "med_idsal3"])
-def test_team_split_row_kernel_matches_reference(name):
-    """tgp_set_rows_kernel(1): the team-split row kernel (csrc/tgp_rows2.hpp; three teams of four waves per workgroup at
-    Power size, one at Boston size) against the same reference fixtures, and bit-reproducible run to run."""
-    from tgp.pytorch_amd import lib
-    g = load_golden(name)
-    h = lib.load()
-    h.tgp_set_rows_kernel(1)
-    try:
-        out, grads, status, mu, v, _ = hip_step0(g)
-        out2, grads2, _, _, _, _ = hip_step0(g)
-    finally:
-        h.tgp_set_rows_kernel(0)
-    assert int(status[0]) == 0
-    assert rel_err(out[0], g["ELBO"]) < TOL_VAL and rel_err(out[1], g["ELL"]) < TOL_VAL
-    for k, t in grads.items():
-        assert rel_err(t, g[NAMES[k]]) < TOL_GRAD, (k, rel_err(t, g[NAMES[k]]))
-        assert torch.equal(t, grads2[k]), k
-    assert torch.equal(out, out2)
-    if "mu" in g:
-        assert rel_err(mu, g["mu"]) < 1e-9
-
-
-@pytest.mark.parametrize("N,flow", [(5000, "sal2"), (4097, None), (777, "tanh2x2"), (12000, "sal1")])
-def test_team_split_row_kernel_equals_one_wave_kernel(N, flow):
-    """Both row kernels on the same seeded problem (two teams per workgroup at N=5000, one at N<=4096, ragged last
-    group; N=12000 is served by three teams): values 1e-12, gradients 1e-9."""
-    from oracle import tgp_oracle as orc
-    from tgp.pytorch_amd import lib, ops
-    prob = orc.synthetic_problem(N, 4, 100, seed=7, flow=flow, S=32)
-    p = {k: v.to(DEV) for k, v in prob["params"].items()}
-    X, Y = prob["X"].to(DEV), prob["Y"].to(DEV)
-    spec = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, DEV) if flow else None
-
-    def run():
-        out, g, st, _ = ops.elbo_step(X, Y, p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"],
-                                      p["log_var_noise"], float(N), flow=spec, theta=p.get("theta"), S=32)
-        torch.cuda.synchronize()
-        assert int(st[0]) == 0
-        return out.cpu(), {k: t.cpu() for k, t in g.items()}
-    a, ga = run()
-    h = lib.load()
-    h.tgp_set_rows_kernel(1)
-    try:
-        b, gb = run()
-    finally:
-        h.tgp_set_rows_kernel(0)
-    assert rel_err(b[:3], a[:3]) < 1e-12
-    for k in ga:
-        assert rel_err(gb[k], ga[k]) < 1e-9, k
-
-
 def test_known_answers_on_real_power():
     """ELBO -81723.694286, ELL -81198.047513, KLD 525.646773 at initialisation, SVGP == identity TGP."""
     a = hip_step0(load_golden("power_init_svgp"))[0]

@@ -715,3 +715,24 @@ def test_engine_id_tgp_training_mode_dropout_matches_host_restated_masks(graph):
     assert rel_err(torch.tensor(hist, dtype=torch.float64), torch.tensor(ref, dtype=torch.float64)) < 1e-8
     assert rel_err(eng.fp.view("nn").cpu(), Wn.detach()) < 1e-7
     assert rel_err(eng.fp.view("Z").cpu(), leaves["Z"].detach()) < 1e-7
+
+
+@pytest.mark.parametrize("N", [1600, 2048, 4096, 4097, 8611])
+def test_ell_gauss_stand_alone_at_every_size(N):
+    """ops.ell_gauss / GaussianLinearMean.expected_log_prob size their workspace with tgp_ell_workspace_bytes: the old
+    host formula was too small for 1600 < N <= 4096 and N > ~8100 (TGP_E_WORKSPACE)."""
+    from oracle import tgp_oracle as orc
+    g = torch.Generator().manual_seed(N)
+    Y, mu = torch.randn(N, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
+    v = torch.rand(N, generator=g, dtype=torch.float64) + 0.1
+    lvn = torch.tensor([-1.3], dtype=torch.float64)
+    ell, g_eta, gmu, gv = ops.ell_gauss(Y.to(DEV), mu.to(DEV), v.to(DEV), lvn.to(DEV), scale=1.7)
+    leaves = [t.clone().requires_grad_(True) for t in (mu, v, lvn)]
+    e0 = 1.7 * orc.ell_gauss(Y, *leaves)
+    e0.backward()
+    assert rel_err(ell.cpu(), e0.detach()) < 1e-12 and rel_err(gmu.cpu(), leaves[0].grad) < 1e-12
+    assert rel_err(gv.cpu(), leaves[1].grad) < 1e-12 and rel_err(g_eta.cpu(), leaves[2].grad) < 1e-12
+    from tgp.pytorch_amd.likelihoods import GaussianLinearMean
+    lik = GaussianLinearMean(1, 0.05, True).to(DEV)
+    out = lik.expected_log_prob(Y.to(DEV).reshape(1, -1), mu.to(DEV).reshape(1, -1), v.to(DEV).reshape(1, -1))
+    assert out.shape == (1,) and bool(torch.isfinite(out).all())

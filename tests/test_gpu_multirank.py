@@ -64,3 +64,25 @@ def test_engine_graphs_with_a_live_rccl_group(tmp_path):
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["graphs"] == [None, "split", "full"], res["graphs"]
     assert res["split_equals_eager"] and res["full_equals_eager"], res
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it): the parent must start the two ranks
+    itself -- a fresh torch.distributed.run child, created before the parent touches the GPU -- and relay rank 0's JSON
+    line.  Two ranks share the box's one GPU, so the rehearsal backend is gloo; on a multi-GPU node the same command
+    runs over RCCL.  Default scaling for the BASELINE workload is strong: the same 8611-row problem split two ways."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", TGP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+                        "--repeats", "2", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    assert res["metric"] == "ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32"
+    assert res["config"]["global_rows_per_step"] == 8611 and res["config"]["rows_per_gpu"] in (4305, 4306)
+    pg = res["config"]["process_group"]
+    assert pg["world_size"] == 2 and pg["backend"] == "gloo" and pg["allreduce"] == "between two graphs"
+    assert res["value"] > 0 and res["config"]["final_elbo"] == res["config"]["final_elbo"]

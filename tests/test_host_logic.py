@@ -159,3 +159,42 @@ def test_product_generator_draws_what_the_oracle_generator_draws(flow, perturb):
         torch.set_default_dtype(old)
     ref = orc.synthetic_problem(257, 4, 19, seed=5, flow=flow, S=20, perturb=perturb)
     assert _same(ref, mine)
+
+
+def test_bench_gpus_n_starts_its_own_ranks_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` without RANK in the environment (how the driver runs it) hands over to a fresh
+    torch.distributed.run child with one rank per GPU and relays its exit code; with RANK set (a rank started by a
+    launcher) it does not spawn again.  No GPU here: the spawn is observed, not executed."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = list(cmd), dict(env)
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched by the parent")))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    assert bench.main() == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_metric_label_follows_what_is_stepped():
+    import bench
+    w = bench.WORKLOADS["tgp_power_tanh3x2"]
+    assert bench.metric_name("tgp_power_tanh3x2", w, 8611) == bench.BASELINE_METRIC          # 1 GPU, or strong scaling
+    weak = bench.metric_name("tgp_power_tanh3x2", w, 8 * 8611)
+    assert weak != bench.BASELINE_METRIC and "8 shards of 8611 rows" in weak
+    a = bench.WORKLOADS["tgp_airline_tanh5x6"]
+    assert "2000000-row" in bench.metric_name("tgp_airline_tanh5x6", a, 8 * 250000)

@@ -67,11 +67,6 @@ const char* tgp_last_error(void) { return g_err; }
 #endif
 const char* tgp_source_hash(void) { return TGP_SRC_HASH; }
 
-int tgp_set_rows_kernel(int32_t mode) {
-  set_rows_kernel(mode);
-  return 0;
-}
-
 size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP) {
   return tgp_workspace_bytes_kernel(N, D, M, S, nblk, P, RP, TGP_KERNEL_SCALE_RBF);
 }
@@ -125,7 +120,6 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   p.nslots = fp.nslots;
-  select_rows_kernel(p, fp);
   if (phases & TGP_PHASE_PREPARE)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (phases & TGP_PHASE_ROWS)

@@ -46,8 +46,6 @@ namespace tgp {
 struct Plan {
   int N, D, M, S, nblk, P, RP, lik;
   int MT, MP, DP, CT, CT16, ntri, nblocks;
-  int T2;   // teams per workgroup of the team-split row kernel (tgp_rows2.hpp); 0 = one-wave-per-group kernel
-  int nb2;  // its workgroup count; `nblocks` (= number of slabs) is set to it when that kernel is selected
   int nslots;  // store-mode flow stack slots
   int zs_lds;  // k_prep_a keeps Zs in LDS (set by the launcher from the LDS budget)
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
@@ -69,16 +67,6 @@ enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// team-split row kernel: teams per workgroup for N rows = ceil(#16-row groups / 256 CUs); 0 when the batch is large
-// enough for the one-wave-per-group kernel to fill the chip by itself
-#define TGP_R2_MAX_TEAMS 3
-__host__ __device__ inline int row2_teams(int N) {
-  const int ng = (N + 15) / 16;
-  const int T = (ng + 255) / 256;
-  return T <= TGP_R2_MAX_TEAMS ? (T < 1 ? 1 : T) : 0;
-}
-__host__ __device__ inline int row2_blocks(int N, int T) { return ((N + 15) / 16 + T - 1) / T; }
-
 inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
@@ -89,8 +77,6 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.ntri = p.MT * (p.MT + 1) / 2;
   p.nblocks = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
   if (p.nblocks < 1) p.nblocks = 1;
-  p.T2 = 0;
-  p.nb2 = row2_teams(N) > 0 ? row2_blocks(N, row2_teams(N)) : 0;
   p.slab_G = 0;
   p.slab_T = p.slab_G + (size_t)p.ntri * 256;
   p.slab_S = p.slab_T + (size_t)p.MP * p.CT16;
@@ -112,7 +98,7 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.redp = o; o += TGP_RSPLIT * p.slab_len;
   p.PPW = p.DP + 2;
   p.PP = o; o += (size_t)p.MT * p.MP * p.PPW;
-  p.slabs = o; o += (size_t)(p.nblocks > p.nb2 ? p.nblocks : p.nb2) * p.slab_len;  // either row kernel's slabs
+  p.slabs = o; o += (size_t)p.nblocks * p.slab_len;
   p.total = o;
   return 0;
 }

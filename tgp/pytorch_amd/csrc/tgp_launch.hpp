@@ -31,8 +31,6 @@ int launch_kl(const double* m, const double* Lam, int M, double* out, double* g_
 int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* status, hipStream_t st);
 
 // tgp_rows.hip
-void set_rows_kernel(int mode);
-void select_rows_kernel(Plan& p, const FlowProg& fp);  // sets p.T2 / p.nblocks for a TRAINING step (call after make_plan)
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 

@@ -333,13 +333,15 @@ class ElboEngine:
         if U < 2 or (unroll is None and self.M > 128):      # general-M steps take milliseconds: nothing to gain, ~100 nodes each
             return
         self.hist_u = torch.zeros(U - 1, 4, dtype=torch.float64, device=self.device)
-        self.gU = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gU, capture_error_mode=CAPTURE_MODE):
-            for u in range(U):
-                self._out = self.hist_u[u] if u < U - 1 else None
-                unit()
-        self._out = None
-        self.unroll = U
+        gU = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(gU, capture_error_mode=CAPTURE_MODE):
+                for u in range(U):
+                    self._out = self.hist_u[u] if u < U - 1 else None
+                    unit()
+        finally:
+            self._out = None        # a failed capture must not leave later steps writing their scalars into hist_u
+        self.gU, self.unroll = gU, U
 
     def replay_many(self, n, hist=None, row0=0):
         """n steps: floor(n / U) replays of the unrolled graph, the rest one by one.  hist[row0 + i] <- (ELBO, ELL, KL) of

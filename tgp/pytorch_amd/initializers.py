@@ -129,6 +129,8 @@ class IdInitEngine:
                                      0.9, 0.999, 1e-8, 0.0, L.ptr(self.step_dev), 0, sp), "tgp_adam_dev_f64")
 
     def run(self, num_epochs):
+        if num_epochs < 1:
+            return 0.0                                # the reference's loop body never runs: loss_acc stays 0.0
         self.epoch()                                  # eager once: kernel attributes, allocator warm-up
         torch.cuda.synchronize()
         if num_epochs > 1:
@@ -163,6 +165,10 @@ def find_forward_params_input_dependent_flow(x_loader, FLOW, optimizer_fn=None, 
         nets, targets = id_nets_and_targets(FLOW)
         spec = mlp_spec(nets, seed=cg.config_seed) if nets else None
         if spec is not None:
+            warnings.warn("Using default optimizer (optim.Adam(trainable_params, lr=0.01))", Warning)
+            if num_epochs is None:
+                warnings.warn("Using default number of epochs (100)", Warning)
+            numpy.random.seed(seed)                   # as the reference does (initializers.py:126): later numpy draws agree
             FLOW.to(cg.device)
             eng = IdInitEngine(x_loader.X, nets, targets, spec, lr=0.01)
             loss_acc = eng.run(100 if num_epochs is None else num_epochs)
@@ -170,8 +176,10 @@ def find_forward_params_input_dependent_flow(x_loader, FLOW, optimizer_fn=None, 
             FLOW.turn_off_initializer_parameters()
             return FLOW, loss_acc
     if optimizer_fn is None:
+        warnings.warn("Using default optimizer (optim.Adam(trainable_params, lr=0.01))", Warning)
         optimizer_fn = lambda trainable_params: optim.Adam(trainable_params, lr=0.01)   # noqa: E731
     if num_epochs is None:
+        warnings.warn("Using default number of epochs (100)", Warning)
         num_epochs = 100
     numpy.random.seed(seed)
     params = [p for _, p in FLOW.named_parameters()]

@@ -52,7 +52,6 @@ _SIGS = {
     "tgp_version": (C.c_int, []),
     "tgp_last_error": (C.c_char_p, []),
     "tgp_source_hash": (C.c_char_p, []),
-    "tgp_set_rows_kernel": (C.c_int, [C.c_int32]),
     "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
     "tgp_workspace_bytes_kernel": (C.c_size_t, [C.c_int32] * 8),
     "tgp_kernel_matrix_f64": (C.c_int, [C.c_int32, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp]),

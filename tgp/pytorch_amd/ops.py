@@ -353,7 +353,7 @@ def ell_gauss(Y, mu, v, lvn, scale=1.0):
     lib = L.load()
     Y, mu, v, lvn = _c(Y.reshape(-1), "Y"), _c(mu, "mu"), _c(v, "v"), _c(lvn, "lvn")
     N = Y.numel()
-    ws = torch.empty(N // 256 * 2 + 256, dtype=torch.float64, device=Y.device)
+    ws = torch.empty(lib.tgp_ell_workspace_bytes(N, 0, 0) // 8 + 16, dtype=torch.float64, device=Y.device)
     out = torch.empty(2, dtype=torch.float64, device=Y.device)
     gmu, gv = torch.empty_like(mu), torch.empty_like(v)
     L.check(lib.tgp_ell_gauss_f64(L.ptr(Y), L.ptr(mu), L.ptr(v), N, L.ptr(lvn), float(scale), L.ptr(out), L.ptr(gmu),

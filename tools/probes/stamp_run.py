@@ -1,4 +1,5 @@
 import os, sys, torch
+os.environ.setdefault("TGP_ALLOW_STALE_LIB", "1")   # the stamped build carries no source hash (build_stamp.sh)
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import tgp.pytorch_amd.lib as L
 L.LIB_PATH = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools/probes/stamp/libtgp_hip.so")
