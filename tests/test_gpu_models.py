@@ -721,7 +721,7 @@ def test_engine_id_tgp_training_mode_dropout_matches_host_restated_masks(graph):
 def test_ell_gauss_stand_alone_at_every_size(N):
     """ops.ell_gauss / GaussianLinearMean.expected_log_prob size their workspace with tgp_ell_workspace_bytes: the old
     host formula was too small for 1600 < N <= 4096 and N > ~8100 (TGP_E_WORKSPACE)."""
-    from oracle import tgp_oracle as orc
+    from tgp.pytorch_amd import ops
     g = torch.Generator().manual_seed(N)
     Y, mu = torch.randn(N, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
     v = torch.rand(N, generator=g, dtype=torch.float64) + 0.1
@@ -736,3 +736,23 @@ def test_ell_gauss_stand_alone_at_every_size(N):
     lik = GaussianLinearMean(1, 0.05, True).to(DEV)
     out = lik.expected_log_prob(Y.to(DEV).reshape(1, -1), mu.to(DEV).reshape(1, -1), v.to(DEV).reshape(1, -1))
     assert out.shape == (1,) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("N,M,D", [(1, 1, 1), (33, 5, 13), (1000, 101, 4), (517, 300, 16), (4099, 100, 8)])
+def test_stand_alone_distance_kernels_every_tiling(N, M, D):
+    """tgp_knm_f64 / tgp_kmm_f64 / tgp_kernel_matrix_f64 (the tiled kernel k_cov_tile: 32 x 128 blocks, column pairs,
+    16-byte stores or the 8-byte path when the row stride is odd) against the oracle's gpytorch restatement: ragged row
+    and column tiles, several column tiles, odd strides, D up to 16, both covariance functions, jitter on the diagonal."""
+    from tgp.pytorch_amd import ops
+    g = torch.Generator().manual_seed(1000 * N + M)
+    X, Z = torch.randn(N, D, generator=g, dtype=torch.float64), torch.randn(M, D, generator=g, dtype=torch.float64)
+    rl = torch.randn(D, generator=g, dtype=torch.float64) * 0.3 + 1.5
+    ro = torch.tensor([0.7], dtype=torch.float64)
+    Xd, Zd, rld, rod = X.to(DEV), Z.to(DEV), rl.to(DEV), ro.to(DEV)
+    assert rel_err(ops.knm(Xd, Zd, rld, rod).cpu(), orc.scale_rbf(X, Z, rl, ro)) < 1e-13
+    Kmm = ops.kmm(Zd, rld, rod, jitter=1e-3).cpu()
+    assert rel_err(Kmm, orc.scale_rbf(Z, Z, rl, ro) + 1e-3 * torch.eye(M, dtype=torch.float64)) < 1e-13
+    for name, fn in (("scale_rbf", orc.scale_rbf), ("scale_matern32", orc.scale_matern32)):
+        assert rel_err(ops.kernel_matrix(Xd, Zd, rld, rod, kernel=name).cpu(), fn(X, Z, rl, ro)) < 1e-12, name
+        Kxx = ops.kernel_matrix(Zd, None, rld, rod, kernel=name, jitter=0.25).cpu()
+        assert rel_err(Kxx, fn(Z, Z, rl, ro) + 0.25 * torch.eye(M, dtype=torch.float64)) < 1e-12, name

@@ -742,53 +742,100 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
 // ---------------------------------------------------------------------------------------------------
 // stand-alone entry points that live on the M x M side
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_kmm(const double* __restrict__ Z, const double* __restrict__ raw_ls, const double* __restrict__ raw_os,
-                      int M, int D, double jitter, double* __restrict__ K) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * M) return;
-  const int r = i / M, c = i % M;
-  double d2 = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double il = 1.0 / softplus_d(raw_ls[d]);
-    const double t = Z[r * D + d] * il - Z[c * D + d] * il;
-    d2 += t * t;
+// K(X1, X2) tile kernel behind tgp_kmm_f64 / tgp_knm_f64 / tgp_kernel_matrix_f64 (gpytorch ScaleKernel(RBFKernel | MaternKernel)
+// as instance_kernel builds them, models/utils_models.py:188-204; call sites models/sparse_MF_SP.py:313-319).
+// Block = 32 rows of X1 x 128 columns (rows of X2); thread = one PAIR of adjacent columns x 8 rows:
+//   * the inverse lengthscales 1/softplus(raw_ls) are formed once per block (16 lanes), not per element and dimension;
+//   * the block's 32 scaled X1 rows are staged in LDS with coalesced loads (their D values are contiguous in X1) and read
+//     back as broadcasts; the two scaled X2 rows of a thread stay in registers;
+//   * 16-byte stores, 64 lanes x 16 B = 1 KB contiguous per row segment (8-byte stores when the row stride N2 is odd);
+//   * RBF: four exponentials at a time, stage by stage (exp_fast_n); Matern through cov_value.
+// HBM-bound by its output: 8 N1 N2 bytes written, (N1 + N2) D read (measured: profiles/r03_pmc_hbm_*).
+#define COV_ROWS 32
+#define COV_COLS 128
+__global__ __launch_bounds__(256) void k_cov_tile(int kernel, const double* __restrict__ X1, int N1,
+                                                   const double* __restrict__ X2, int N2, int D,
+                                                   const double* __restrict__ raw_ls, const double* __restrict__ raw_os,
+                                                   double jitter, int self, double* __restrict__ K) {
+  __shared__ double xl[COV_ROWS * 16];
+  __shared__ double ils[16];
+  const int tid = threadIdx.x, cp = tid & 63, rg = tid >> 6;
+  const long n0 = (long)blockIdx.x * COV_ROWS;
+  const int m0 = blockIdx.y * COV_COLS + 2 * cp;
+  if (tid < 16) ils[tid] = tid < D ? 1.0 / softplus_d(raw_ls[tid]) : 0.0;
+  const double s2 = softplus_d(raw_os[0]);
+  // the thread's two X2 rows (clamped: out-of-range columns compute a finite value that is never stored)
+  double z0[16], z1[16];
+  {
+    const long ma = m0 < N2 ? m0 : N2 - 1, mb = m0 + 1 < N2 ? m0 + 1 : N2 - 1;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      z0[d] = d < D ? X2[ma * D + d] : 0.0;
+      z1[d] = d < D ? X2[mb * D + d] : 0.0;
+    }
   }
-  K[i] = softplus_d(raw_os[0]) * exp(-0.5 * d2) + (r == c ? jitter : 0.0);
-}
-
-__global__ void k_knm(const double* __restrict__ X, const double* __restrict__ Z, const double* __restrict__ raw_ls,
-                      const double* __restrict__ raw_os, int N, int M, int D, double* __restrict__ K) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)N * M) return;
-  const size_t r = i / M;
-  const int c = (int)(i % M);
-  double d2 = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double il = 1.0 / softplus_d(raw_ls[d]);
-    const double t = X[r * D + d] * il - Z[c * D + d] * il;
-    d2 += t * t;
+  const long nrem = (long)N1 - n0, nr = nrem < COV_ROWS ? nrem : COV_ROWS;
+  double xv[2];
+  {
+    // 32 rows x D values are one contiguous run of X1: coalesced
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + 256 * u;
+      xv[u] = i < nr * D ? X1[n0 * D + i] : 0.0;
+    }
   }
-  K[i] = softplus_d(raw_os[0]) * exp(-0.5 * d2);
-}
-
-// K(X1, X2) for either covariance function (tgp_kernel_matrix_f64); X2 == nullptr: K(X1, X1) + jitter I
-__global__ void k_kernel_matrix(int kernel, const double* __restrict__ X1, int N1, const double* __restrict__ X2, int N2,
-                                int D, const double* __restrict__ raw_ls, const double* __restrict__ raw_os, double jitter,
-                                double* __restrict__ K) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool self = X2 == nullptr;
-  const int n2 = self ? N1 : N2;
-  if (i >= (size_t)N1 * n2) return;
-  const size_t r = i / n2;
-  const size_t c = i % n2;
-  const double* B = self ? X1 : X2;
-  double d2 = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double il = 1.0 / softplus_d(raw_ls[d]);
-    const double t = X1[r * D + d] * il - B[c * D + d] * il;
-    d2 += t * t;
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 16; ++d) { z0[d] *= ils[d]; z1[d] *= ils[d]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = tid + 256 * u;
+    if (i < COV_ROWS * D) xl[(i / D) * 16 + i % D] = xv[u] * ils[i % D];
   }
-  K[i] = cov_value(kernel, softplus_d(raw_os[0]), d2) + ((self && r == c) ? jitter : 0.0);
+  __syncthreads();
+  const bool pair_ok = (N2 & 1) == 0;
+#pragma unroll
+  for (int u0 = 0; u0 < 8; u0 += 2) {
+    double e[4];
+    long rown[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int nl = rg * 8 + u0 + u;
+      rown[u] = n0 + nl;
+      double da = 0.0, db = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double x = xl[nl * 16 + d];
+        const double ta = x - z0[d], tb = x - z1[d];
+        da += ta * ta;
+        db += tb * tb;
+      }
+      e[2 * u] = da;
+      e[2 * u + 1] = db;
+    }
+    if (kernel == TGP_KERNEL_SCALE_RBF) {
+      TGP_EACH(u, 4) e[u] *= -0.5;
+      exp_fast_n<4>(e);
+      TGP_EACH(u, 4) e[u] *= s2;
+    } else {
+      TGP_EACH(u, 4) e[u] = cov_value(kernel, s2, e[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (rown[u] >= N1) continue;
+      double ka = e[2 * u], kb = e[2 * u + 1];
+      if (self) {
+        if (rown[u] == m0) ka += jitter;
+        if (rown[u] == m0 + 1) kb += jitter;
+      }
+      double* o = K + rown[u] * (long)N2 + m0;
+      if (pair_ok && m0 + 1 < N2) {
+        *reinterpret_cast<double2*>(o) = make_double2(ka, kb);
+      } else {
+        if (m0 < N2) o[0] = ka;
+        if (m0 + 1 < N2) o[1] = kb;
+      }
+    }
+  }
 }
 
 // whitened KL + gradients (models/sparse_MF_SP.py:406-431), single block
@@ -921,28 +968,31 @@ int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, d
   return 0;
 }
 
-int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
-               hipStream_t st) {
-  hipLaunchKernelGGL(k_kmm, dim3((M * M + 255) / 256), dim3(256), 0, st, Z, raw_ls, raw_os, M, D, jitter, K);
+static int launch_cov_tile(int kernel, const double* X1, int N1, const double* X2, int N2, int D, const double* raw_ls,
+                           const double* raw_os, double jitter, int self, double* K, hipStream_t st) {
+  if (D < 1 || D > 16) return TGP_E_UNSUPPORTED;
+  if (N1 < 1 || N2 < 1) return 0;
+  const unsigned gx = (unsigned)((N1 + COV_ROWS - 1) / COV_ROWS), gy = (unsigned)((N2 + COV_COLS - 1) / COV_COLS);
+  if (gy > 65535u) return TGP_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_cov_tile, dim3(gx, gy), dim3(256), 0, st, kernel, X1, N1, X2, N2, D, raw_ls, raw_os, jitter, self, K);
   LAUNCH_CHECK();
   return 0;
+}
+
+int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
+               hipStream_t st) {
+  return launch_cov_tile(TGP_KERNEL_SCALE_RBF, Z, M, Z, M, D, raw_ls, raw_os, jitter, 1, K, st);
 }
 
 int launch_knm(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int N, int M, int D,
                double* K, hipStream_t st) {
-  const size_t tot = (size_t)N * M;
-  hipLaunchKernelGGL(k_knm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, Z, raw_ls, raw_os, N, M, D, K);
-  LAUNCH_CHECK();
-  return 0;
+  return launch_cov_tile(TGP_KERNEL_SCALE_RBF, X, N, Z, M, D, raw_ls, raw_os, 0.0, 0, K, st);
 }
 
 int launch_kernel_matrix(int kernel, const double* X1, int N1, const double* X2, int N2, int D, const double* raw_ls,
                          const double* raw_os, double jitter, double* K, hipStream_t st) {
-  const size_t tot = (size_t)N1 * (X2 ? N2 : N1);
-  hipLaunchKernelGGL(k_kernel_matrix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, kernel, X1, N1, X2, N2, D, raw_ls,
-                     raw_os, jitter, K);
-  LAUNCH_CHECK();
-  return 0;
+  if (X2 == nullptr) return launch_cov_tile(kernel, X1, N1, X1, N1, D, raw_ls, raw_os, jitter, 1, K, st);
+  return launch_cov_tile(kernel, X1, N1, X2, N2, D, raw_ls, raw_os, 0.0, 0, K, st);
 }
 
 int launch_kl(const double* m, const double* Lam, int M, double* out, double* g_m, double* g_Lam, hipStream_t st) {
