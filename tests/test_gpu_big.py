@@ -320,3 +320,83 @@ def test_device_jitter_ladder_on_the_general_path():
         assert bool(torch.isfinite(e1.fp.grad).all())
         # K_MM + 1e-8 I has condition ~1e8: two correct factorisations agree to ~1e-8 on the ELBO, not bitwise
         assert rel_err(e1.fp.out[:3].cpu(), ref[:3].cpu()) < 1e-6
+
+
+def test_big_path_ragged_last_chunk_in_the_small_problem_likelihood_mode():
+    """TGP_BIG_CHUNK=4224, N=8224: chunks of 4224 rows (4 lanes per row in k_ell_flow, 67 partials) and a ragged last one
+    of 4000 rows (<= 4096: 16 lanes per row, 250 partials) -- the likelihood workspace is sized for either mode."""
+    script = _CHUNK_SCRIPT.replace('[(1000, 6, 160, "sal2", 16), (700, 5, 140, "idsal2", 8), (901, 4, 130, None, 8)]',
+                                   '[(8224, 4, 130, "sal2", 16)]')
+    assert "8224" in script
+    env = dict(os.environ, TGP_BIG_CHUNK="4224")
+    r = subprocess.run([sys.executable, "-c", script % (ROOT, os.path.join(ROOT, "tests"))], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("N", [10000, 20000])
+def test_big_airline_recipe_sizes_match_oracle(N):
+    """BASELINE configs[4]'s model (D=8, M=1000, StepTanhL 5x6, S=32) against the CPU oracle at the reference's Airline
+    minibatch size (10 000 rows, main.py:74) and at 20 000 rows -- more than one natural 16 384-row chunk (no test hook)."""
+    g = _oracle_case(N, 8, 1000, "tanh5x6", 32, seed=21)
+    out, grads, status, _ = run_hip(g)
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    compare(out, grads, g)
+    assert float(torch.triu(grads["Lam"], 1).abs().max()) == 0.0
+
+
+_SHARD_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_big import _shard_step
+out, grads = _shard_step(250000)
+torch.save({"out": out, "grads": grads}, sys.argv[1])
+print("SHARD_OK")
+"""
+
+
+def _shard_step(N, lo=0, hi=None, mb_global=None):
+    """One ELBO step of configs[4]'s per-GPU shard shape (rows [lo, hi) of the seeded N-row problem) through the C ABI."""
+    from tgp.pytorch_amd import ops
+    from tgp.pytorch_amd.synthetic import synthetic_problem
+    dev = _dev()
+    prob = synthetic_problem(N, 8, 1000, seed=0, flow="tanh5x6", S=32)
+    hi = N if hi is None else hi
+    p = {k: t.to(dev) for k, t in prob["params"].items()}
+    flow = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, dev)
+    out, g, st, _ = ops.elbo_step(prob["X"][lo:hi].to(dev), prob["Y"][lo:hi].to(dev), p["Z"], p["raw_lengthscale"],
+                                  p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], float(N), flow=flow,
+                                  theta=p["theta"], S=32, kl_scale=1.0 if mb_global is None else 0.5, mb_global=mb_global)
+    torch.cuda.synchronize()
+    assert int(st[0]) == 0 and int(st[1]) == 0
+    return out.cpu(), {k: t.cpu() for k, t in g.items()}
+
+
+def test_big_full_shard_properties(tmp_path):
+    """The real per-GPU shard of BASELINE configs[4]: N = 250 000 rows, D = 8, M = 1000, StepTanhL 5x6, S = 32 (16 natural
+    row chunks).  Too large for the CPU oracle, so the size-independent properties: bit reproducibility; shard additivity
+    (the whole shard == its two 125 000-row halves summed, each with KL weight 1/2 -- what two ranks would all-reduce);
+    natural chunking == chunking forced to 8 192 rows (TGP_BIG_CHUNK, read once per process: a child process)."""
+    N = 250000
+    out, grads = _shard_step(N)
+    out2, grads2 = _shard_step(N)
+    assert torch.equal(out, out2)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+    assert bool(torch.isfinite(out).all()) and float(torch.triu(grads["Lam"], 1).abs().max()) == 0.0
+    # two half shards (ranks 0 and 1 of a 2-rank job): ELL adds, KL is replicated, gradients add with KL weight 1/2 each
+    oa, ga = _shard_step(N, 0, N // 2, mb_global=N)
+    ob, gb = _shard_step(N, N // 2, N, mb_global=N)
+    assert rel_err(oa[1] + ob[1], out[1]) < 1e-9 and rel_err(oa[2], out[2]) < 1e-12
+    for k in grads:
+        assert rel_err(ga[k] + gb[k], grads[k]) < 1e-8, (k, rel_err(ga[k] + gb[k], grads[k]))
+    # forced chunking in a child process
+    f = os.path.join(str(tmp_path), "forced.pt")
+    env = dict(os.environ, TGP_BIG_CHUNK="8192")
+    r = subprocess.run([sys.executable, "-c", _SHARD_SCRIPT % (ROOT, os.path.join(ROOT, "tests")), f], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert "SHARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    forced = torch.load(f)
+    assert rel_err(forced["out"][:3], out[:3]) < 1e-10
+    for k in grads:
+        assert rel_err(forced["grads"][k], grads[k]) < 1e-8, (k, rel_err(forced["grads"][k], grads[k]))

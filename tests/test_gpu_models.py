@@ -269,6 +269,31 @@ def test_fully_bayesian_log_likelihood_applies_mc_dropout():
     import numpy
     want = (lp + 0.5 * float(numpy.log(numpy.pi))).sum() - 200 * float(numpy.float32(0.5) * numpy.log(numpy.float32(numpy.pi)))
     assert rel_err(one.cpu(), want.reshape(1).cpu()) < 1e-9
+    # S_MC = 3 samples in ONE pass (the reference's X.repeat to (S_MC, N, Dx)): the nets run over 3 * 200 rows in one
+    # launch, sample s of row n carries the mask of row s * 200 + n at the next counter value; predictive moments of
+    # the same pass = the mixture over the samples (sparse_MF_SP.py:516-531)
+    S = 3
+    step = int(model._cfg["mlp_step"][0]) + 1
+    masks = [[torch.from_numpy(ops.mlp_keep_mask(mspec.seed, step, k, l, S * 200, mspec.H, mspec.drop_p)).to(torch.float64)
+              for l in range(mspec.L)] for k in range(mspec.nnets)]
+    rowp_s = _torch_mlps(prob["X"].repeat(S, 1), W.cpu(), mspec, masks).to(DEV)
+    three, _ = model.test_log_likelihood(X, Y, False, Ystd, S_MC_NNet=S)
+    mu_q, v_q = mq.reshape(-1).contiguous(), cq.reshape(-1).contiguous()
+    m1s, m2s, lps = ops.predict(mu_q.repeat(S), v_q.repeat(S), lvn, spec, theta.detach() if theta is not None else None,
+                                model.quad_points, rowp_s, Y=Y.reshape(-1).repeat(S), Y_std=1.0)
+    stack = lps.reshape(S, 200) + 0.5 * float(numpy.log(numpy.pi)) - float(numpy.float32(0.5) * numpy.log(numpy.float32(numpy.pi)))
+    want3 = torch.logsumexp(stack, 0).sum() - 200 * numpy.log(S)
+    assert rel_err(three.cpu(), want3.reshape(1).cpu()) < 1e-9
+    step = int(model._cfg["mlp_step"][0]) + 1
+    masks = [[torch.from_numpy(ops.mlp_keep_mask(mspec.seed, step, k, l, S * 200, mspec.H, mspec.drop_p)).to(torch.float64)
+              for l in range(mspec.L)] for k in range(mspec.nnets)]
+    rowp_s = _torch_mlps(prob["X"].repeat(S, 1), W.cpu(), mspec, masks).to(DEV)
+    m1, m2, _, _ = model.predictive_distribution(X, diagonal=True, S_MC_NNet=S)
+    mY, cY, _ = ops.predict(mu_q.repeat(S), v_q.repeat(S), lvn, spec, theta.detach() if theta is not None else None,
+                            model.quad_points, rowp_s)
+    mY, cY = mY.reshape(S, 200), cY.reshape(S, 200)
+    assert rel_err(m1.reshape(-1).cpu(), mY.mean(0).cpu()) < 1e-10
+    assert rel_err(m2.reshape(-1).cpu(), ((cY + mY ** 2).mean(0) - mY.mean(0) ** 2).cpu()) < 1e-9
 
 
 def test_cholesky_failure_protocol():
@@ -756,3 +781,28 @@ def test_stand_alone_distance_kernels_every_tiling(N, M, D):
         assert rel_err(ops.kernel_matrix(Xd, Zd, rld, rod, kernel=name).cpu(), fn(X, Z, rl, ro)) < 1e-12, name
         Kxx = ops.kernel_matrix(Zd, None, rld, rod, kernel=name, jitter=0.25).cpu()
         assert rel_err(Kxx, fn(Z, Z, rl, ro) + 0.25 * torch.eye(M, dtype=torch.float64)) < 1e-12, name
+
+
+def test_flow_networks_outside_the_mlp_kernel_raise():
+    """One MLP implementation on the whole path: a network the HIP kernel does not cover (H = 100 > 64) raises instead of
+    silently evaluating through torch.nn."""
+    from tgp.pytorch_amd import lib
+    from tgp.pytorch_amd.flow import compile_flow, instance_flow, nets_rowp
+    from tgp.pytorch_amd.flows import SAL
+    idf = instance_flow(SAL(1, input_dependent=True, input_dim=4, num_hidden_layers=2, batch_norm=0, dropout=0.25,
+                            hidden_dim=100, hidden_activation="relu", inference="MC_dropout")).to(DEV)
+    idf.turn_off_initializer_parameters()
+    nets = compile_flow(idf)[2]
+    with pytest.raises(lib.TgpError):
+        nets_rowp(nets, torch.zeros(10, 4, dtype=torch.float64, device=DEV))
+    ok = instance_flow(SAL(1, input_dependent=True, input_dim=4, num_hidden_layers=2, batch_norm=0, dropout=0.25,
+                           hidden_dim=50, hidden_activation="relu", inference="MC_dropout")).to(DEV).eval()
+    ok.turn_off_initializer_parameters()
+    nets = compile_flow(ok)[2]
+    Xr = torch.randn(77, 4, dtype=torch.float64, device=DEV)
+    got = nets_rowp(nets, Xr)
+    with torch.no_grad():
+        want = torch.cat([n(Xr) for n in nets], -1)
+    assert rel_err(got.cpu(), want.cpu()) < 1e-12
+    f = torch.randn(5, 77, dtype=torch.float64, device=DEV)
+    assert ok(f, Xr).shape == f.shape

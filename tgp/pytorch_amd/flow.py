@@ -193,10 +193,7 @@ class CompositeFlow(Flow):
             return f
         dev = f.device
         theta = torch.stack([p.detach().reshape(()) for p in theta_list]).to(dev) if theta_list else None
-        rowp = None
-        if nets:
-            with torch.no_grad():
-                rowp = torch.cat([net(X) for net in nets], dim=-1).reshape(-1, len(nets)).contiguous()
+        rowp = nets_rowp(nets, X.reshape(-1, X.shape[-1])) if nets else None     # HIP MLP kernel, one launch for all nets
         flat = f.detach().reshape(-1, f.shape[-1]).contiguous()
         return ops.flow_eval(flat, spec, theta, rowp, want=("G",))["G"].reshape(f.shape)
 
@@ -254,6 +251,35 @@ def mlp_spec(nets, seed=0):
         return spec
     except (KeyError, AttributeError, IndexError, TypeError):
         return None
+
+
+_mask_step = {}     # device -> int32[2] counter behind the dropout masks drawn outside the training step
+
+
+def nets_rowp(nets, X2d, samples=1, spec=None):
+    """Per-row flow parameters (rows, len(nets)) of an input-dependent flow through tgp_mlp_forward_f64 -- the ONE MLP
+    implementation of this package (training, evaluation, moments, sampling); no autograd here (the training step
+    differentiates through ops.MlpFunction).  Dropout follows the nets' Dropout LAYERS (train mode in training and in the
+    fully Bayesian evaluation, where enable_eval_dropout() re-enables only them, models/utils_models.py:358-364).
+    `samples` > 1 evaluates the rows `samples` times in the same launch -- what the reference does by expanding X to
+    (S_MC, N, Dx) (models/sparse_MF_SP.py:753-758): output row s * N + n, every (sample, row) with its own mask.
+    Architectures the kernel does not cover (H > 64, L > 3, mixed nets, batch norm) raise: nothing falls back to torch.nn."""
+    spec = mlp_spec(nets, seed=cg.config_seed) if spec is None else spec
+    if spec is None:
+        raise L.TgpError("input-dependent flow networks outside the HIP MLP kernel's coverage (one architecture "
+                         "D -> H x L -> 1 with H <= 64, 1 <= L <= 3, relu/tanh, dropout): no torch.nn fallback in this package")
+    X2d = X2d.detach()
+    if not X2d.is_cuda or X2d.dtype != torch.float64:
+        raise L.TgpError("input-dependent flows run on the GPU in float64 (got %s %s)" % (X2d.device, X2d.dtype))
+    drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
+    step = _mask_step.get(str(X2d.device))
+    if step is None:
+        step = _mask_step[str(X2d.device)] = torch.zeros(2, dtype=torch.int32, device=X2d.device)
+    if drop_on:
+        step[0] += 1                                    # a fresh mask per call
+    W = torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()])
+    Xs = X2d.contiguous() if samples == 1 else X2d.repeat(samples, 1)
+    return ops.mlp_forward(spec, Xs, W, bool(drop_on), step)
 
 
 def compile_flow(flow):

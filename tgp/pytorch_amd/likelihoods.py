@@ -55,9 +55,8 @@ class GaussianNonLinearMean(_GaussianBase):
         theta = torch.stack([p.detach().reshape(()) for p in theta_list]).to(dev) if theta_list else None
         rowp = None
         if nets:
-            with torch.no_grad():
-                x = X[0] if X.dim() == 3 else X
-                rowp = torch.cat([net(x) for net in nets], dim=-1).contiguous()
+            from .flow import nets_rowp
+            rowp = nets_rowp(nets, X[0] if X.dim() == 3 else X)      # the HIP MLP kernel (dropout follows the layers)
         return spec, theta, rowp
 
     def expected_log_prob(self, Y, gauss_mean, gauss_cov, flow, X, **kwargs):

@@ -7,7 +7,8 @@ main.py / trainer idiom works unchanged:
     ELBO, ELL, KLD = model.ELBO(x, y);  (-ELBO).backward();  optimizer.step()
 
 What differs is underneath: every number is produced by the HIP kernels of libtgp_hip.so (fused row kernel,
-blocked Cholesky, hand-derived adjoints).  There is NO CPU fallback: calling these methods with CPU tensors
+blocked Cholesky, hand-derived adjoints, the MLP kernel for the input-dependent flows' networks in training AND in
+every evaluation method).  There is NO CPU fallback: calling these methods with CPU tensors
 raises (the oracle in oracle/ is the CPU restatement, and it is test infrastructure only).
 Restrictions of this build (asserted): one output GP (Dy = 1, all BASELINE configs), whitened q(u),
 zero mean, 'scale_rbf' kernel, float64.
@@ -129,9 +130,11 @@ class sparse_MF_SP(nn.Module):
                 self.q_U.variational_mean[0], self.q_U.chol_variational_covar[0],
                 self.likelihood.log_var_noise.reshape(-1)[:1])
 
-    def _flow_inputs(self, X2d, with_grad):
-        """(FlowSpec or None, theta, rowp): shared scalars stacked into one vector, per-row parameters from the MLPs
-        (dropout follows the module's train/eval state, as in the reference)."""
+    def _flow_inputs(self, X2d, with_grad, samples=1):
+        """(FlowSpec or None, theta, rowp): shared scalars stacked into one vector, per-row parameters from the MLPs on the
+        HIP kernel (dropout follows the nets' Dropout layers, as in the reference).  `samples` > 1 (fully Bayesian
+        evaluation): the rows are evaluated `samples` times in ONE launch, rowp row s * N + n, every (sample, row) with
+        its own dropout mask -- the reference's X.repeat to (S_MC, N, Dx), models/sparse_MF_SP.py:753-758."""
         if isinstance(self.likelihood, GaussianLinearMean):
             return None, None, None
         spec, theta_list, nets = compile_flow(self.G_matrix[0])
@@ -145,21 +148,23 @@ class sparse_MF_SP(nn.Module):
                     self._cfg["mlp"] = mlp_spec(nets, seed=cg.config_seed)
                     self._cfg["mlp_step"] = torch.zeros(2, dtype=torch.int32, device=X2d.device)
                 mspec = self._cfg["mlp"]
-                if mspec is not None:
-                    # all nets in one HIP launch (tgp_mlp_forward/backward_f64); a fresh dropout mask per call, the same
-                    # one for this call's backward (the counter moves before the forward, not after it)
-                    self._cfg["mlp_step"][0] += 1
-                    W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
-                    # dropout is on when the nets' Dropout layers are in train mode: in training, and in the fully
-                    # Bayesian evaluation, where enable_eval_dropout() re-enables ONLY those layers after eval()
-                    # (models/utils_models.py:358-364) -- the container's own .training flag is False there
-                    drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
-                    # the counter is snapshotted per call: a second forward before this call's backward (loss accumulated
-                    # over minibatches, an evaluation between ELBO() and backward()) must not change the mask the
-                    # backward recomputes
-                    rowp = ops.MlpFunction.apply(X2d.contiguous(), W, mspec, bool(drop_on), self._cfg["mlp_step"].clone())
-                else:
-                    rowp = torch.cat([net(X2d) for net in nets], dim=-1)
+                if mspec is None:
+                    raise ops.L.TgpError("the flow's parameter networks are outside the HIP MLP kernel's coverage (one "
+                                         "architecture D -> H x L -> 1, H <= 64, 1 <= L <= 3, relu/tanh, dropout); this "
+                                         "package has no torch.nn fallback for them")
+                # all nets in one HIP launch (tgp_mlp_forward/backward_f64); a fresh dropout mask per call, the same
+                # one for this call's backward (the counter moves before the forward, not after it)
+                self._cfg["mlp_step"][0] += 1
+                W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
+                # dropout is on when the nets' Dropout layers are in train mode: in training, and in the fully
+                # Bayesian evaluation, where enable_eval_dropout() re-enables ONLY those layers after eval()
+                # (models/utils_models.py:358-364) -- the container's own .training flag is False there
+                drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
+                # the counter is snapshotted per call: a second forward before this call's backward (loss accumulated
+                # over minibatches, an evaluation between ELBO() and backward()) must not change the mask the
+                # backward recomputes
+                Xs = X2d.contiguous() if samples == 1 else X2d.repeat(samples, 1)
+                rowp = ops.MlpFunction.apply(Xs, W, mspec, bool(drop_on), self._cfg["mlp_step"].clone())
         return spec, theta, rowp
 
     # ---- model computations ------------------------------------------------------------------------
@@ -217,12 +222,15 @@ class sparse_MF_SP(nn.Module):
             mean_q_f, cov_q_f = self.marginal_variational_qf_parameters(X3, diagonal=True, is_duvenaud=False)
             if self.fully_bayesian:
                 assert S_MC_NNet is not None
-                mY, cY = [], []
-                for _ in range(S_MC_NNet):       # one dropout mask per MC sample (sparse_MF_SP.py:753-758)
-                    a, b = self.likelihood.marginal_moments(mean_q_f.squeeze(2), cov_q_f.squeeze(2), flow=self.G_matrix, X=X3)
-                    mY.append(a)
-                    cY.append(b)
-                mY, cY = torch.stack(mY, 1), torch.stack(cY, 1)       # (Dy, S, MB)
+                # all S_MC dropout samples in ONE pass, as the reference does by expanding X to (S_MC, N, Dx)
+                # (sparse_MF_SP.py:753-758): one MLP launch over S_MC * N rows (a mask per sample and row), one
+                # tgp_predict_f64 launch, then the mixture moments (:516-531)
+                S, MB = int(S_MC_NNet), X3.shape[1]
+                spec, theta, rowp = self._flow_inputs(X3[0], with_grad=False, samples=S)
+                lvn = self.likelihood.log_var_noise.detach().reshape(-1)[:1].contiguous()
+                mY, cY, _ = ops.predict(mean_q_f.reshape(-1).repeat(S), cov_q_f.reshape(-1).repeat(S), lvn, spec,
+                                        theta.detach() if theta is not None else None, self.quad_points, rowp)
+                mY, cY = mY.reshape(1, S, MB), cY.reshape(1, S, MB)       # (Dy, S, MB)
                 m1 = mY.mean(1)
                 m2 = (cY + mY ** 2).mean(1) - m1 ** 2
             else:
@@ -254,23 +262,24 @@ class sparse_MF_SP(nn.Module):
                 _, _, lp = ops.predict(mu, v, lvn, Y=Y, Y_std=ystd)
                 log_p_y = lp.sum().reshape(1)
             else:
-                n_mc = S_MC_NNet if self.fully_bayesian else 1
-                rows = []
-                for _ in range(n_mc):
-                    spec, theta, rowp = self._flow_inputs(X3[0], with_grad=False)
-                    _, _, lp = ops.predict(mu, v, lvn, spec, theta.detach() if theta is not None else None,
-                                           self.quad_points, rowp, Y=Y, Y_std=ystd)
-                    # kernel: logsumexp_s[log(w_s/sqrt(pi)) + logN]; the reference sums log w_s + logN and subtracts
-                    # 0.5*log(pi) where cg.pi is a float32 tensor (sparse_MF_SP.py:768-776): rebuild exactly that
-                    rows.append(lp + 0.5 * float(numpy.log(numpy.pi)))
+                # S_MC dropout samples (fully Bayesian) in ONE pass: the nets over S_MC * N rows, one tgp_predict_f64
+                # launch over the same rows (sparse_MF_SP.py:753-768 expands X, Y the same way)
+                n_mc = int(S_MC_NNet) if self.fully_bayesian else 1
+                spec, theta, rowp = self._flow_inputs(X3[0], with_grad=False, samples=n_mc)
+                rep = (lambda t: t.repeat(n_mc)) if n_mc > 1 else (lambda t: t)
+                _, _, lp = ops.predict(rep(mu), rep(v), lvn, spec, theta.detach() if theta is not None else None,
+                                       self.quad_points, rowp, Y=rep(Y.reshape(-1)), Y_std=ystd)
+                # kernel: logsumexp_s[log(w_s/sqrt(pi)) + logN]; the reference sums log w_s + logN and subtracts
+                # 0.5*log(pi) where cg.pi is a float32 tensor (sparse_MF_SP.py:768-776): rebuild exactly that
+                lp = lp.reshape(n_mc, MB) + 0.5 * float(numpy.log(numpy.pi))
                 # float32 arithmetic of the reference's constant, with the correctly rounded float32 log(pi) (a host
                 # torch.log in float32 differs by 1 ulp between CPU ISAs, which would make the result host-dependent)
                 log_pi32 = numpy.log(numpy.float32(numpy.pi))
                 if self.fully_bayesian:
-                    stack = torch.stack(rows, 0) - float(numpy.float32(0.5) * log_pi32)
+                    stack = lp - float(numpy.float32(0.5) * log_pi32)
                     log_p_y = (torch.logsumexp(stack, 0).sum() - MB * numpy.log(n_mc)).reshape(1)
                 else:
-                    log_p_y = (rows[0].sum() - float(numpy.float32(0.5 * MB) * log_pi32)).reshape(1)
+                    log_p_y = (lp[0].sum() - float(numpy.float32(0.5 * MB) * log_pi32)).reshape(1)
         self.train()
         return log_p_y, predictive_params
 
