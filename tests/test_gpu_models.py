@@ -763,7 +763,8 @@ def test_ell_gauss_stand_alone_at_every_size(N):
     assert out.shape == (1,) and bool(torch.isfinite(out).all())
 
 
-@pytest.mark.parametrize("N,M,D", [(1, 1, 1), (33, 5, 13), (1000, 101, 4), (517, 300, 16), (4099, 100, 8)])
+@pytest.mark.parametrize("N,M,D", [(1, 1, 1), (33, 5, 13), (1000, 101, 4), (517, 300, 16), (4099, 100, 8), (777, 512, 8),
+                                   (130, 2, 16), (129, 256, 16), (5000, 1000, 8)])
 def test_stand_alone_distance_kernels_every_tiling(N, M, D):
     """tgp_knm_f64 / tgp_kmm_f64 / tgp_kernel_matrix_f64 (the tiled kernel k_cov_tile: 32 x 128 blocks, column pairs,
     16-byte stores or the 8-byte path when the row stride is odd) against the oracle's gpytorch restatement: ragged row

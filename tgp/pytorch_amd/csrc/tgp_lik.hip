@@ -191,15 +191,35 @@ __global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, FlowProg fp, co
   double* tp = reinterpret_cast<double*>(smem_raw);
   double* tg = tp + (md.P + 2) / 2 * 2;
   flow_params_lds(md, fp, tp, tg);
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
   FlowDev F{fp.blk, fp.nblk, tp, tg};
-  const double* rp = rowp ? rowp + (i % N) * md.RP : nullptr;
-  double der;
-  const double g = flow_forward(F, f[i], rp, nullptr, 0, &der);
-  if (G) G[i] = g;
-  if (dG) dG[i] = der;
-  if (logdG) logdG[i] = log(der);
+  // four elements per thread, a grid stride apart (coalesced), evaluated stage by stage (flow_forward_n)
+  constexpr int NB = 4;
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  double fv[NB], der[NB];
+  const double* rp[NB];
+  TGP_EACH(u, NB) {
+    const size_t i = i0 + u * stride;
+    const size_t ic = i < total ? i : 0;
+    fv[u] = f[ic];
+    rp[u] = rowp ? rowp + (ic % N) * md.RP : nullptr;
+  }
+  if (dG || logdG) flow_forward_n<NB, true>(F, fv, rp, der);
+  else flow_forward_n<NB, false>(F, fv, rp, der);
+  if (logdG) {
+    double lg[NB];
+    TGP_EACH(u, NB) lg[u] = der[u];
+    TGP_EACH(u, NB) {
+      const size_t i = i0 + u * stride;
+      if (i < total) logdG[i] = log(lg[u]);
+    }
+  }
+  TGP_EACH(u, NB) {
+    const size_t i = i0 + u * stride;
+    if (i < total) {
+      if (G) G[i] = fv[u];
+      if (dG) dG[i] = der[u];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -234,17 +254,30 @@ __global__ __launch_bounds__(256) void k_predict(tgp_model md, FlowProg fp, cons
   const double sdy = Y_std * sqrt(noise), var = sdy * sdy;
   const double yy = Y ? Y_std * Y[n] : 0.0;
   double m1 = 0.0, e2 = 0.0, mx = -INFINITY, se = 0.0;
-  for (int s = 0; s < md.S; ++s) {
-    const double g = flow_forward(F, m_ + sq * md.xs[s], rp, nullptr, 0, nullptr);
-    const double wsn = md.wn[s];
-    m1 += wsn * g;
-    e2 += wsn * g * g;
-    if (logp && Y) {
-      // log w_s = log(wn_s) + 0.5 log(pi); the caller adds the reference's constants
-      const double r = yy - Y_std * g;
-      const double t = log(wsn) - 0.5 * (TGP_LOG_2PI_REF + log(var) + r * r / var);
-      if (t > mx) { se = se * exp(mx - t) + 1.0; mx = t; }
-      else se += exp(t - mx);
+  const double lvar = log(var), ivar = 1.0 / var;
+  constexpr int NB = 4;  // quadrature nodes in flight (stage-by-stage evaluation, flow_forward_n)
+  for (int s0 = 0; s0 < md.S; s0 += NB) {
+    double g[NB], der[NB], wsn[NB];
+    const double* rpn[NB];
+    TGP_EACH(u, NB) {
+      const int s = s0 + u < md.S ? s0 + u : md.S - 1;
+      g[u] = m_ + sq * md.xs[s];
+      wsn[u] = s0 + u < md.S ? md.wn[s] : 0.0;
+      rpn[u] = rp;
+    }
+    flow_forward_n<NB, false>(F, g, rpn, der);
+    TGP_EACH(u, NB) {
+      if (s0 + u < md.S) {
+        m1 += wsn[u] * g[u];
+        e2 += wsn[u] * g[u] * g[u];
+        if (logp && Y) {
+          // log w_s = log(wn_s) + 0.5 log(pi); the caller adds the reference's constants
+          const double r = yy - Y_std * g[u];
+          const double t = log(wsn[u]) - 0.5 * (TGP_LOG_2PI_REF + lvar + r * r * ivar);
+          if (t > mx) { se = se * exp(mx - t) + 1.0; mx = t; }
+          else se += exp(t - mx);
+        }
+      }
     }
   }
   if (m1o) m1o[n] = m1;
@@ -406,7 +439,7 @@ int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, i
                      double* logdG, hipStream_t st) {
   const size_t total = (size_t)S * N;
   const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
-  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, st, md, fp, f, total, N, rowp, G,
+  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 1023) / 1024)), dim3(256), lds, st, md, fp, f, total, N, rowp, G,
                      dG, logdG);
   LAUNCH_CHECK();
   return 0;

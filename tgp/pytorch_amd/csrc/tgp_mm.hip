@@ -742,28 +742,28 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
 // ---------------------------------------------------------------------------------------------------
 // stand-alone entry points that live on the M x M side
 // ---------------------------------------------------------------------------------------------------
-// K(X1, X2) tile kernel behind tgp_kmm_f64 / tgp_knm_f64 / tgp_kernel_matrix_f64 (gpytorch ScaleKernel(RBFKernel | MaternKernel)
-// as instance_kernel builds them, models/utils_models.py:188-204; call sites models/sparse_MF_SP.py:313-319).
-// Block = 32 rows of X1 x 128 columns (rows of X2); thread = one PAIR of adjacent columns x 8 rows:
-//   * the inverse lengthscales 1/softplus(raw_ls) are formed once per block (16 lanes), not per element and dimension;
-//   * the block's 32 scaled X1 rows are staged in LDS with coalesced loads (their D values are contiguous in X1) and read
-//     back as broadcasts; the two scaled X2 rows of a thread stay in registers;
-//   * 16-byte stores, 64 lanes x 16 B = 1 KB contiguous per row segment (8-byte stores when the row stride N2 is odd);
-//   * RBF: four exponentials at a time, stage by stage (exp_fast_n); Matern through cov_value.
-// HBM-bound by its output: 8 N1 N2 bytes written, (N1 + N2) D read (measured: profiles/r03_pmc_hbm_*).
-#define COV_ROWS 32
+// K(X1, X2) behind tgp_kmm_f64 / tgp_knm_f64 / tgp_kernel_matrix_f64 (gpytorch ScaleKernel(RBFKernel | MaternKernel) as
+// instance_kernel builds them, models/utils_models.py:188-204; call sites models/sparse_MF_SP.py:313-319).  Both kernels
+// below are bound by their output (8 N1 N2 bytes written against (N1 + N2) D read; profiles/r03_pmc_hbm_standalone.csv):
+//   * the inverse lengthscales 1/softplus(raw_ls) and the outputscale are formed once per block, not per element;
+//   * the block's scaled X1 rows are staged in LDS with coalesced loads (their D values are contiguous in X1);
+//   * 16-byte stores (8-byte ones when the row stride N2 is odd); RBF: four exponentials at a time, stage by stage.
+//
+// k_cov_tile (any N2): block = 64 rows of X1 x 128 columns (rows of X2); thread = one PAIR of adjacent columns x 16
+// rows, its two scaled X2 rows in registers, the X1 rows read back from LDS as broadcasts.
+#define COV_ROWS 64
 #define COV_COLS 128
 __global__ __launch_bounds__(256) void k_cov_tile(int kernel, const double* __restrict__ X1, int N1,
                                                    const double* __restrict__ X2, int N2, int D,
                                                    const double* __restrict__ raw_ls, const double* __restrict__ raw_os,
                                                    double jitter, int self, double* __restrict__ K) {
   __shared__ double xl[COV_ROWS * 16];
-  __shared__ double ils[16];
+  __shared__ double ils[17];
   const int tid = threadIdx.x, cp = tid & 63, rg = tid >> 6;
   const long n0 = (long)blockIdx.x * COV_ROWS;
   const int m0 = blockIdx.y * COV_COLS + 2 * cp;
   if (tid < 16) ils[tid] = tid < D ? 1.0 / softplus_d(raw_ls[tid]) : 0.0;
-  const double s2 = softplus_d(raw_os[0]);
+  if (tid == 64) ils[16] = softplus_d(raw_os[0]);
   // the thread's two X2 rows (clamped: out-of-range columns compute a finite value that is never stored)
   double z0[16], z1[16];
   {
@@ -775,32 +775,30 @@ __global__ __launch_bounds__(256) void k_cov_tile(int kernel, const double* __re
     }
   }
   const long nrem = (long)N1 - n0, nr = nrem < COV_ROWS ? nrem : COV_ROWS;
-  double xv[2];
-  {
-    // 32 rows x D values are one contiguous run of X1: coalesced
+  double xv[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = tid + 256 * u;
-      xv[u] = i < nr * D ? X1[n0 * D + i] : 0.0;
-    }
+  for (int u = 0; u < 4; ++u) {  // COV_ROWS x D values are one contiguous run of X1: coalesced
+    const int i = tid + 256 * u;
+    xv[u] = i < nr * D ? X1[n0 * D + i] : 0.0;
   }
   __syncthreads();
+  const double s2 = ils[16];
 #pragma unroll
   for (int d = 0; d < 16; ++d) { z0[d] *= ils[d]; z1[d] *= ils[d]; }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < 4; ++u) {
     const int i = tid + 256 * u;
     if (i < COV_ROWS * D) xl[(i / D) * 16 + i % D] = xv[u] * ils[i % D];
   }
   __syncthreads();
   const bool pair_ok = (N2 & 1) == 0;
-#pragma unroll
-  for (int u0 = 0; u0 < 8; u0 += 2) {
+#pragma unroll 2
+  for (int u0 = 0; u0 < 16; u0 += 2) {
     double e[4];
     long rown[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int nl = rg * 8 + u0 + u;
+      const int nl = rg * 16 + u0 + u;
       rown[u] = n0 + nl;
       double da = 0.0, db = 0.0;
       for (int d = 0; d < D; ++d) {
@@ -835,6 +833,77 @@ __global__ __launch_bounds__(256) void k_cov_tile(int kernel, const double* __re
         if (m0 + 1 < N2) o[1] = kb;
       }
     }
+  }
+}
+
+// k_cov_flat (N2 even, N2 * D <= 4096: K_NM with M = 100 is the case that matters -- a 128-column tile would idle 22 %
+// of the lanes): block = COVF_ROWS rows x ALL columns, i.e. one contiguous run of the output; thread = element pairs
+// e = 2 tid, 2 tid + 512, ... of that run (row r = e / N2, columns c = e % N2 and c + 1), every lane busy whatever N2 is.
+// Both operands come from LDS in dimension-major layout: zT[d][c] (a wave reads 64 consecutive pairs: conflict-free
+// 16-byte reads), xT[d][r] (one or two rows per wave: broadcasts).
+#define COVF_ROWS 128
+__global__ __launch_bounds__(256) void k_cov_flat(int kernel, const double* __restrict__ X1, int N1,
+                                                   const double* __restrict__ X2, int N2, int D,
+                                                   const double* __restrict__ raw_ls, const double* __restrict__ raw_os,
+                                                   double jitter, int self, double* __restrict__ K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* zT = reinterpret_cast<double*>(smem_raw);  // D x N2
+  double* xT = zT + (size_t)D * N2;                  // D x COVF_ROWS
+  __shared__ double ils[17];
+  const int tid = threadIdx.x;
+  const long n0 = (long)blockIdx.x * COVF_ROWS;
+  const long nrem = (long)N1 - n0;
+  const int nr = (int)(nrem < COVF_ROWS ? nrem : COVF_ROWS);
+  if (tid < 16) ils[tid] = tid < D ? 1.0 / softplus_d(raw_ls[tid]) : 0.0;
+  if (tid == 64) ils[16] = softplus_d(raw_os[0]);
+  __syncthreads();
+  for (int i = tid; i < N2 * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    zT[d * N2 + c] = X2[i] * ils[d];
+  }
+  for (int i = tid; i < nr * D; i += 256) {
+    const int r = i / D, d = i - r * D;
+    xT[d * COVF_ROWS + r] = X1[n0 * D + i] * ils[d];
+  }
+  __syncthreads();
+  const double s2 = ils[16];
+  const int npairs = nr * (N2 / 2);
+  // two pairs (four elements) per trip; (r, c) advance incrementally: no division in the loop
+  const int sr = 512 / N2, sc = 512 - sr * N2;
+  int e = 2 * tid, r = e / N2, c = e - r * N2;
+  double* __restrict__ Ko = K + n0 * (long)N2;
+  for (int p = tid; p < npairs; p += 512) {
+    int r1 = r + sr, c1 = c + sc;
+    if (c1 >= N2) { c1 -= N2; ++r1; }
+    const bool has1 = p + 256 < npairs;
+    const int rb = has1 ? r1 : r, cb = has1 ? c1 : c;
+    double ev[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int d = 0; d < D; ++d) {
+      const double xa = xT[d * COVF_ROWS + r], xb = xT[d * COVF_ROWS + rb];
+      const double2 za = *reinterpret_cast<const double2*>(zT + d * N2 + c);
+      const double2 zb = *reinterpret_cast<const double2*>(zT + d * N2 + cb);
+      const double t0 = xa - za.x, t1 = xa - za.y, t2 = xb - zb.x, t3 = xb - zb.y;
+      ev[0] += t0 * t0; ev[1] += t1 * t1; ev[2] += t2 * t2; ev[3] += t3 * t3;
+    }
+    if (kernel == TGP_KERNEL_SCALE_RBF) {
+      TGP_EACH(u, 4) ev[u] *= -0.5;
+      exp_fast_n<4>(ev);
+      TGP_EACH(u, 4) ev[u] *= s2;
+    } else {
+      TGP_EACH(u, 4) ev[u] = cov_value(kernel, s2, ev[u]);
+    }
+    if (self) {
+      if (n0 + r == c) ev[0] += jitter;
+      if (n0 + r == c + 1) ev[1] += jitter;
+      if (n0 + rb == cb) ev[2] += jitter;
+      if (n0 + rb == cb + 1) ev[3] += jitter;
+    }
+    *reinterpret_cast<double2*>(Ko + e) = make_double2(ev[0], ev[1]);
+    if (has1) *reinterpret_cast<double2*>(Ko + e + 512) = make_double2(ev[2], ev[3]);
+    // advance by 1024 elements = two steps of 512
+    r = r1 + sr; c = c1 + sc;
+    if (c >= N2) { c -= N2; ++r; }
+    e += 1024;
   }
 }
 
@@ -972,6 +1041,15 @@ static int launch_cov_tile(int kernel, const double* X1, int N1, const double* X
                            const double* raw_os, double jitter, int self, double* K, hipStream_t st) {
   if (D < 1 || D > 16) return TGP_E_UNSUPPORTED;
   if (N1 < 1 || N2 < 1) return 0;
+  if ((N2 & 1) == 0 && N2 >= 2 && (long)N2 * D <= 4096 && N2 <= 512 && (reinterpret_cast<uintptr_t>(K) & 15) == 0) {
+    const unsigned gx = (unsigned)((N1 + COVF_ROWS - 1) / COVF_ROWS);
+    const size_t lds = ((size_t)D * N2 + (size_t)D * COVF_ROWS) * sizeof(double);
+    static size_t lds_cur = 48 * 1024;
+    if (int rc = ensure_lds(reinterpret_cast<const void*>(k_cov_flat), lds, &lds_cur)) return rc;
+    hipLaunchKernelGGL(k_cov_flat, dim3(gx), dim3(256), lds, st, kernel, X1, N1, X2, N2, D, raw_ls, raw_os, jitter, self, K);
+    LAUNCH_CHECK();
+    return 0;
+  }
   const unsigned gx = (unsigned)((N1 + COV_ROWS - 1) / COV_ROWS), gy = (unsigned)((N2 + COV_COLS - 1) / COV_COLS);
   if (gy > 65535u) return TGP_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_cov_tile, dim3(gx, gy), dim3(256), 0, st, kernel, X1, N1, X2, N2, D, raw_ls, raw_os, jitter, self, K);
