@@ -61,7 +61,7 @@ struct Plan {
 };
 
 // hdr slots
-enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_STAMP = 8, H_N = 32 };
+enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_STAMP = 8, H_PSTAMP = 32, H_N = 64 };
 // slab scalar slots
 enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 
@@ -379,6 +379,67 @@ __device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], i
     });
   });
   return bad;
+}
+
+// Cholesky of a 16-COLUMN PANEL by one wave, registers only (round 3: the critical chain of both blocked factorisations).
+//   dg : the diagonal tile, replicated in each of the wave's four 16-lane rows: lane (l & 15) owns row l & 15
+//        in : dg[c] = A_jj[l & 15][c] (lower part valid)     out: dg[c] = L_jj[l & 15][c]
+//   a  : one row of the panel BELOW the diagonal tile per lane (64 rows per wave; PANEL = false: none)
+//        in : a[c] = A[row_l][c], already updated by the block columns to the left
+//        out: a[c] = L[row_l][c] = (A_panel L_jj^-T)[row_l][c]
+// The rank-1 update of pivot k is applied to the panel rows in the same instructions' shadow (the multiplier L[j][k] is
+// the broadcast the diagonal tile needs anyway), so a whole block column of L comes out of ONE pass: no inverse of the
+// diagonal tile and no triangular solve on the chain (the left-looking schedule of rounds 1-2 paid potrf + trtri
+// interleaved in one wave -- 800 instructions, issue-bound -- then a panel product and a diagonal update per block column).
+// Any wave can run this on its own 64 panel rows: it factorises its own copy of the diagonal tile redundantly and needs
+// nothing from the other waves.  Returns the first bad pivot (1-based; 0 = ok), the same in every lane.
+template <bool PANEL>
+__device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16]) {
+  int bad = 0;
+  static_for<16>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double d = bcast_row_k<k>(dg[k]);
+    if (!(d > 0.0) && bad == 0) bad = k + 1;  // the same in every lane; also catches NaN
+    const double rinv = rsqrt_nr(d);
+    dg[k] *= rinv;  // column k of L_jj (lane k: d / sqrt(d))
+    if constexpr (PANEL) a[k] *= rinv;
+    static_for<16>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j > k) {
+        const double b = bcast_row_k<j>(dg[k]);  // L_jj[j][k]
+        dg[j] = fma(-dg[k], b, dg[j]);
+        if constexpr (PANEL) a[j] = fma(-a[k], b, a[j]);
+        asm volatile("" : "+v"(dg[j]));  // done here (see potrf_trtri16)
+        if constexpr (PANEL) asm volatile("" : "+v"(a[j]));
+      }
+    });
+  });
+  return bad;
+}
+
+// Inverse of a 16x16 lower-triangular tile by one wave: in dg[c] = L[l & 15][c]; out x[r] = (L^-1)[r][l & 15] (column
+// `lane` of the inverse, zero above the diagonal).  Off the factorisation's chain (a helper wave runs it one block
+// column behind).
+__device__ __forceinline__ void trtri16(const double (&dg)[16], double (&x)[16], int lane) {
+  double gate = 0.0;  // x[k-1]: the broadcasts of step k are tied behind it (below)
+  static_for<16>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const double rinv = rcp_fast(bcast_row_k<k>(dg[k]));
+    double s0 = 0.0, s1 = 0.0;
+    static_for<16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      if constexpr (m < k) {
+        // None of the 120 broadcasts depends on x: left alone hipcc issues them all up front and keeps them alive
+        // (240 VGPRs: the callers spilled).  The empty asm makes step k's operands wait for x[k-1].
+        double t = dg[m];
+        asm volatile("" : "+v"(t) : "v"(gate));
+        if constexpr ((m & 1) == 0) s0 = fma(bcast_row_k<k>(t), x[m], s0);
+        else s1 = fma(bcast_row_k<k>(t), x[m], s1);
+      }
+    });
+    x[k] = (lane == k) ? rinv : (lane < k ? -(s0 + s1) * rinv : 0.0);
+    gate = x[k];
+  });
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -27,7 +27,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
                                                          int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave number as a SCALAR: every task / tile index derived from it stays in SGPRs and its branches are scalar
+  // branches (as a VGPR value hipcc treats them as divergent: exec-mask code, vector address arithmetic, spills)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, MT = p.MT;
 
@@ -128,29 +131,26 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   }
 
   // ---------------- block 0: blocked Cholesky (torch.cholesky, dsp/utils.py:239) + inverse ------------------------
-#ifdef TGP_STAMPS
-  double tph[4] = {0, 0, 0, 0};
-  unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
-#define PSTAMP(i) do { unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tph[i] += (double)(tn_ - tlast); tlast = tn_; } while (0)
-  double twv[5] = {0, 0, 0, 0, 0};
-  unsigned long long twl = 0;
-#define WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long tn_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); if ((i) > 0) twv[i] += (double)(tn_ - twl); twl = tn_; } while (0)
-#else
-#define PSTAMP(i) do { } while (0)
-#define WSTAMP(i) do { } while (0)
-#endif
-  // Wave 0 runs the critical chain (issue-bound: potrf_trtri16) and shares its SIMD with wave 4 (a workgroup's waves
-  // go to the SIMDs cyclically): wave 4 stays idle in this block so that the chain has the SIMD to itself; the six
-  // waves on the other three SIMDs are the helpers (hw = 0..5).
-  constexpr int NH = PREP_THREADS / 64 - 2;
-  const int hw = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  // Round-3 schedule: RIGHT-looking, one 16-column PANEL factorisation per block column (potrf_panel16: the diagonal
+  // tile and every row below it leave one register pass of one wave -- no inverse of the diagonal tile, no triangular
+  // solve, no panel product on the critical chain), everything GEMM-shaped on the other waves:
+  //   iteration j, phase P : wave 0 (and wave 1 for the rows beyond 64 below the diagonal): column j of L;
+  //                          the other waves, off the chain: [j = 0] fill of K_MM columns 1.. ; [j >= 1] the trailing
+  //                          update of column j-1 on the tiles (i, k >= j+1), the inverse Dinv_{j-1} of diagonal tile
+  //                          j-1 (trtri16), the tiles of row j-2 of J = L^-1, the write-out of finished tile rows
+  //                phase U : tiles (i, j+1) -= L(i, j) L(j+1, j)^T, one tile per wave (4 MFMAs): all column j+1 needs
+  // Two LDS-only barriers per block column; the chain per block column is potrf_panel16 (3.4 k cycles) + phase U,
+  // against potrf+trtri (4.6 k) + panel product + diagonal update + the helpers' skew in the left-looking schedule of
+  // rounds 1-2 (10 k cycles per block column measured).
+  constexpr int NW = PREP_THREADS / 64;
   const int LD = MP + 1;
   double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
   double* Dt = sm + (size_t)MP * LD;         // MT x 256: inverses of the diagonal tiles (row-major, zero above diag)
   double* zs = Dt + (size_t)MT * 256;        // MP x DP scaled inducing points, present when p.zs_lds (LDS budget allows)
-  __shared__ int s_info, s_nan;
+  __shared__ int s_info, s_nan, s_next;
   __shared__ double s_ils[16];
-  if (tid == 0) { s_info = 0; s_nan = 0; }
+  if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; }
+  int tbase = 0;  // first task id of the current window (the same in every wave)
   if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   const double s2 = softplus_d(md.raw_os[0]);
   const bool zl = p.zs_lds != 0;
@@ -172,9 +172,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     if (rr < M) {
       double d2 = 0.0;
       if (zl) {
-        for (int d = 0; d < DP; ++d) {
-          const double tt = zs[rr * DP + d] - zs[cc * DP + d];
-          d2 += tt * tt;
+        // DP is 4, 8 or 16 and the rows are 32-byte aligned: two 16-byte reads per operand and four dimensions per trip
+        for (int d = 0; d < DP; d += 4) {
+          const double2 a0 = *reinterpret_cast<const double2*>(zs + rr * DP + d), a1 = *reinterpret_cast<const double2*>(zs + rr * DP + d + 2);
+          const double2 b0 = *reinterpret_cast<const double2*>(zs + cc * DP + d), b1 = *reinterpret_cast<const double2*>(zs + cc * DP + d + 2);
+          const double t0 = a0.x - b0.x, t1 = a0.y - b0.y, t2 = a1.x - b1.x, t3 = a1.y - b1.y;
+          d2 += t0 * t0; d2 += t1 * t1; d2 += t2 * t2; d2 += t3 * t3;
         }
       } else {  // M = 128 with D > 8: no LDS left next to A; read Z through L1/L2
         for (int d = 0; d < D; ++d) {
@@ -190,41 +193,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     }
     return k;
   };
-  // left-looking tile: acc = sum_{kbeg <= k < kend} L[i-tile rows, k] * L[j-tile rows, k]   (both operands in LDS)
+  // acc = sum_{kbeg <= k < kend} L[i-tile rows, k] * L[j-tile rows, k]   (both operands in LDS)
   auto ll_sum = [&](int i0, int j0, int kbeg, int kend) {
     d4 acc = {0, 0, 0, 0};
     return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
                      kend, acc);
-  };
-  // tile (i, c) -= sum_{kbeg <= k < kend} L[i rows, k] L[c rows, k]^T in place (one wave; C/D layout read-modify-write)
-  auto sub_sum = [&](int i, int c, int kbeg, int kend) {
-    if (kend <= kbeg) return;
-    const d4 upd = ll_sum(16 * i, 16 * c, kbeg, kend);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] -= upd[rr];
-  };
-  // panel tile (i, c): L_ic = (A_ic - sum_{k<c} L_ik L_ck^T) Dinv_c^T ; own tile, read fully before it is rewritten
-  // (kbeg > 0: the part of the left-looking sum below kbeg was subtracted from the tile beforehand, see the schedule)
-  auto panel_tile = [&](int i, int c, int kbeg) {
-    const int i0 = 16 * i, c0 = 16 * c;
-    const d4 upd = ll_sum(i0, c0, kbeg, c0);
-    double av[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];   // updated A_ic, C/D layout
-    // (A_ic Dinv_c^T)[row][col] = sum_k A_ic[row][k] Dinv_c[col][k]: A-operand needs A_ic[row = r][k = 4s + q] -> go
-    // through the tile itself: write the updated tile back, then read it in A-operand layout (same wave only)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = av[rr];
-    __builtin_amdgcn_wave_barrier();
-    d4 acc = {0, 0, 0, 0};
-    double a4[4], b4[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(i0 + r) * LD + c0 + 4 * s4 + q]; b4[s4] = Dt[c * 256 + r * 16 + 4 * s4 + q]; }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(a4[s4], b4[s4], acc);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = acc[rr];
   };
   // inverse tile (j, c), c < j:  J_jc = -Dinv_j sum_{c<=kb<j} L_j,kb J_kb,c   (stored transposed in the upper tile (c, j))
   auto inv_tile = [&](int j, int c) {
@@ -243,169 +216,232 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
   };
-
-  // Rows [r0, r1) of K_MM column block c (16 columns) by waves 1..7.  Block c is first read at iteration c (its
-  // diagonal tile, by wave 0) and c+1 (the rest), so each piece is filled one iteration ahead, in the shadow of the
-  // critical chain, instead of all of K_MM before the first pivot.
-  auto fill_block = [&](int c, int r0, int r1) {
-    const int n = (r1 - r0) * 16;
-    if (hw < 0) return;
-    for (int e = hw * 64 + lane; e < n; e += NH * 64) {
-      const int rr = r0 + (e >> 4), cc = 16 * c + (e & 15);
-      if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
-    }
-  };
-  // ---- blocked Cholesky + inverse with LOOKAHEAD, one barrier per block column --------------------------------------
-  // iteration j:  wave 0 (the critical chain)  : panel tile (j, j-1) of step j-1, diagonal update, potrf + trtri of tile j
-  //               waves 1..7 (off the chain)   : iteration 0: fill K_MM column block 0 below tile (0,0) and tile (1,1);
-  //                                              iteration j >= 1: the other panel tiles (i > j, j-1) and the inverse
-  //                                              tiles (j-1, c < j-1) of step j-1, then K_MM column block j below its diagonal tile and tile (j+1,j+1)
-  // psd_safe_cholesky on the device (dsp/utils.py:256-269): when md.jitter_ladder > 0 a failed factorisation is
-  // repeated with jitter_ladder * 10^i, i = 0..2, added to the diagonal, without the host; status[2] reports the
-  // level that succeeded (0 = none needed) so that the caller can issue the reference's warning lazily.
   // Write-out of lower tile (ti, tj): L, J and the J^T tile (tj, ti), by one wave, 128-byte row segments.  A single CU
   // stores at ~30-50 GB/s, so block 0 writes only what is non-zero (the structurally-zero tiles are written by the
-  // otherwise idle tile blocks of this launch) and it does so DURING the factorisation: everything in tile row ti is
-  // final after iteration ti+1, so waves 1..7 store row j-2 at the end of iteration j, in the shadow of wave 0's
-  // chain; only the last row is left for after the loop.  (A retry of the jitter ladder simply stores again.)
-  auto write_tile = [&](int ti, int tj) {
+  // otherwise idle tile blocks of this launch) and it does so DURING the factorisation, in the shadow of the chain.
+  // (A retry of the jitter ladder simply stores again.)
+  auto write_L = [&](int ti, int tj) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      double l, jv;
-      if (ti == tj) {
-        l = cc <= rr ? A[rr * LD + cc] : 0.0;
-        jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
-      } else {
-        l = A[rr * LD + cc];
-        jv = A[cc * LD + rr];
-      }
-      ws[p.L + (size_t)rr * MP + cc] = l;
-      ws[p.J + (size_t)rr * MP + cc] = jv;
+      ws[p.L + (size_t)rr * MP + cc] = (ti != tj || cc <= rr) ? A[rr * LD + cc] : 0.0;
+    }
+  };
+  auto write_J = [&](int ti, int tj) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      ws[p.J + (size_t)rr * MP + cc] = (ti == tj) ? Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)] : A[cc * LD + rr];
       // J^T tile (tj, ti), rows = cols of the J tile: element [16 tj + q+4u][16 ti + r] = J[16 ti + r][16 tj + q+4u]
       const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
       ws[p.JT + (size_t)rt * MP + ct] = (ti == tj) ? Dt[ti * 256 + (ct & 15) * 16 + (rt & 15)] : A[rt * LD + ct];
     }
   };
-  int attempt = 0;
-  for (;; ++attempt) {
-  for (int j = 0; j <= MT; ++j) {
-    const int j0 = 16 * j;
-    if (wave == 0) {
-      if (j < MT) {
-        if (j == 0) {
-          double kv[4];  // four independent exp chains per lane, no branch between them
+  // tile (i, c) -= L[i rows, k0 .. k0+15] L[c rows, k0 .. k0+15]^T : one block column's contribution, 4 MFMAs
+  auto sub16 = [&](int i, int c, int k0) {
+    double a4[4], b4[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) kv[u] = kmm_elem((lane + 64 * u) >> 4, lane & 15);
+    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(16 * i + r) * LD + k0 + 4 * s4 + q]; b4[s4] = A[(16 * c + r) * LD + k0 + 4 * s4 + q]; }
+    double cur[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int rr = (lane + 64 * u) >> 4, cc = lane & 15;
-            if (cc <= rr) A[rr * LD + cc] = kv[u];
-          }
-          __builtin_amdgcn_wave_barrier();
-        } else {
-          WSTAMP(0);
-          // the sums over the block columns before j-2 (panel tile) / before j-1 (diagonal tile) were subtracted by a
-          // helper during iteration j-1: only the newest block column is left on the critical chain
-          panel_tile(j, j - 1, j >= 2 ? 16 * (j - 2) : 0);
-          __builtin_amdgcn_wave_barrier();
-          WSTAMP(1);
-          const d4 upd = ll_sum(j0, j0, 16 * (j - 1), j0);
+    for (int rr = 0; rr < 4; ++rr) cur[rr] = A[(16 * i + q + 4 * rr) * LD + 16 * c + r];
+    d4 acc = {0, 0, 0, 0};
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
-          __builtin_amdgcn_wave_barrier();
-          WSTAMP(2);
-        }
-        double a[16], x[16];
-        const int li = lane & 15;
+    for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(a4[s4], b4[s4], acc);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
-        const int bad = potrf_trtri16(a, x, li);
-#ifdef TGP_STAMPS
-        asm volatile("" ::"v"(x[15]), "v"(a[15]), "v"(x[0]));
-#endif
-        WSTAMP(3);
-        // Store L_jj (row li) and Dinv_j (column li).  The four 16-lane rows of the wave hold the same a[], x[]: row q
-        // stores the columns c = 4 u + q, so all 64 lanes store and every lane issues 4 + 4 plain ds_write_b64 instead
-        // of 16 lanes issuing 16 + 16 under 16 different exec masks (that was 2.0 k of the 9.6 k cycles of an iteration).
-        // The strict upper part of the diagonal tile is never read (potrf reads the lower part, write_tile masks it).
-        {
+    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] = cur[rr] - acc[rr];
+  };
+  // tile (i, c) of K_MM minus the contributions of the block columns [0, ncol) (all final): the tile's first value
+  // in LDS (C/D layout: rows q + 4u, column r); four independent exponential chains per lane
+  auto fill_tile = [&](int i, int c, int ncol) {
+    double kv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const double av4 = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
-            const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-            A[(j0 + li) * LD + j0 + 4 * u + q] = av4;
-            Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
-          }
-        }
-        WSTAMP(4);
-        if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
-      }
-    } else if (hw < 0) {
-      // wave 4: idle (see above)
-    } else if (j == 0) {
-      // K_MM is filled TWO iterations ahead of its first reader (block column c below its diagonal tile at iteration
-      // c-1, tile (c,c) at iteration c-2): the helper that pre-subtracts row j+1's sums at iteration j finds tiles
-      // (j+1, j) and (j+1, j+1) complete
-      fill_block(0, 16, MP);  // tile (0,0) is wave 0's
-      if (MT > 1) { fill_block(1, 16, 32); fill_block(1, 32, MP); }
-      if (MT > 2) fill_block(2, 32, 48);
-    } else {
-      // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2  (at most MT-2 <= 6 tiles for 7 waves)
-      const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
-      if (MT - 2 < NH && hw == NH - 1 && j + 1 < MT) sub_sum(j + 1, j, 0, 16 * (j - 1));   // see t == 0 below
-      for (int t = hw; t < npanel + (j - 1); t += NH) {
-        if (t < npanel) {
-          panel_tile(j + 1 + t, j - 1, 0);
-          if (t == 0) {
-            // row j+1 is wave 0's at the next iteration: take everything that is already final off its chain --
-            //   tile (j+1, j+1) -= sum over block columns 0 .. j-1 (the last one is the panel tile just formed): here;
-            //   tile (j+1, j)   -= sum over block columns 0 .. j-2 (column j-1 needs L(j, j-1), wave 0's tile of THIS
-            //                      iteration, and stays on the chain): by the helper that has no tile this iteration
-            //                      (there are MT-2 tiles for NH helpers), else here as well.  One wave per tile: no race.
-            __builtin_amdgcn_wave_barrier();
-            sub_sum(j + 1, j + 1, 0, 16 * j);
-            if (MT - 2 >= NH) sub_sum(j + 1, j, 0, 16 * (j - 1));
-          }
-        } else {
-          inv_tile(j - 1, t - npanel);
-        }
-      }
-      if (j + 1 < MT) fill_block(j + 1, 16 * (j + 2), MP);               // rest of block j+1: first read at iteration j+1
-      if (j + 2 < MT) fill_block(j + 2, 16 * (j + 2), 16 * (j + 3));     // diagonal tile (j+2, j+2)
-      if (j >= 2)
-        for (int tj = hw; tj <= j - 2; tj += NH) write_tile(j - 2, tj);
+    for (int u = 0; u < 4; ++u) kv[u] = kmm_elem(16 * i + q + 4 * u, 16 * c + r);
+    if (ncol > 0) {
+      const d4 upd = ll_sum(16 * i, 16 * c, 0, 16 * ncol);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] -= upd[u];
     }
-    // The iteration barrier orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it made every iteration
-    // wait for the global stores of write_tile (a store's acknowledgement takes 1-2 us): those stores are read by no
-    // wave of this kernel and may stay in flight across the barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    PSTAMP(j < 4 ? j : 3);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A[(16 * i + q + 4 * u) * LD + 16 * c + r] = kv[u];
+  };
+  // diagonal tile t: its own factorisation (the same arithmetic as the panel wave's copy, bit for bit) with the inverse
+  // riding in its shadow -> L_tt and Dinv_t, by one helper wave while the panel waves factorise block column t
+  // (L_tt is handed back in `lt` and stored by the caller AFTER the window's barrier: the panel waves read the tile's
+  //  input at the start of the same window)
+  auto diag_tile = [&](int t, double (&lt)[4]) {
+    double a[16], x[16];
+    const int li = lane & 15, t0 = 16 * t;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = A[(t0 + li) * LD + t0 + c];
+    const int bad = potrf_trtri16(a, x, li);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same a[], x[]: row q keeps the columns 4u + q
+      lt[u] = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
+      const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+      Dt[t * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
+    }
+    if (lane == 0 && bad != 0 && s_info == 0) s_info = t0 + bad;
+  };
+#define PREP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef TGP_STAMPS
+  // diagnostic build: shader-clock sums of the chain's pieces (wave 0) and of one helper's window work (wave 2)
+  double tph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double tcnt[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tl_ = 0;
+#define PSTAMP0() do { __builtin_amdgcn_sched_barrier(0); tl_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long tn_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); tph[i] += (double)(tn_ - tl_); tl_ = tn_; } while (0)
+#else
+#define PSTAMP0() do { } while (0)
+#define PSTAMP(i) do { } while (0)
+#endif
+  // psd_safe_cholesky on the device (dsp/utils.py:256-269): when md.jitter_ladder > 0 a failed factorisation is
+  // repeated with jitter_ladder * 10^i, i = 0..2, added to the diagonal, without the host; status[2] reports the
+  // level that succeeded (0 = none needed) so that the caller can issue the reference's warning lazily.
+  int attempt = 0;
+  PSTAMP0();
+  for (;; ++attempt) {
+    // block column 0 of K_MM by everybody (it heads the chain); the other columns are filled under potrf(0)
+    for (int e = tid; e < MP * 16; e += PREP_THREADS) {
+      const int rr = e >> 4, cc = e & 15;
+      if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
+    }
+    PREP_BARRIER();
+    PSTAMP(0);
+    for (int j = 0; j < MT; ++j) {
+      const int j0 = 16 * j;
+      const int npan = (MT - 1 - j) * 16;          // rows below the diagonal tile
+      const int npw = npan > 64 ? 2 : (npan > 0 ? 1 : 0);  // panel waves: 0 (rows 0..63 below the tile), 1 (the rest)
+      double ltile[4] = {0.0, 0.0, 0.0, 0.0};
+      bool did_diag = false;
+      // ---- phase P ----
+      if (wave < npw) {
+        // block column j of L below the diagonal tile: this wave's own copy of the diagonal tile + 64 panel rows
+        __builtin_amdgcn_s_setprio(3);   // the chain: wins instruction issue against its SIMD partner's task work
+        const int li = lane & 15, l0 = wave * 64 + lane;
+        const bool has = l0 < npan;
+        const int prow = j0 + 16 + (has ? l0 : 0);
+        double dg[16], a[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
+#ifdef TGP_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PSTAMP(1);
+        (void)potrf_panel16<true>(dg, a);
+#ifdef TGP_STAMPS
+        asm volatile("" ::"v"(dg[15]), "v"(a[15]));
+#endif
+        PSTAMP(2);
+        if (has) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
+        }
+#ifdef TGP_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PSTAMP(3);
+        __builtin_amdgcn_s_setprio(0);
+#ifdef TGP_STAMPS
+        if (wave != 0) { tph[j == 0 ? 7 : 8] += tph[1] + tph[2] + tph[3]; tph[1] = tph[2] = tph[3] = 0.0; }
+#endif
+      } else {
+        // The other waves take this window's tasks from a counter in LDS, heaviest first (all operands are final since
+        // the last barrier and the tasks of one window are independent of each other, so any wave may run any of them;
+        // dealt round-robin the windows were as long as the unluckiest wave's share):
+        //   the diagonal tile j: L_jj and Dinv_j (its own factorisation, the panel waves do not write the tile)
+        //   tile (i, j+2)  = K_MM - block columns 0 .. j-1 (its first value)       i = j+2 .. MT-1   [j = 0: columns 1, 2]
+        //   tiles (j-1, c), c < j-1, of J = L^-1    (Dinv_{j-1}: last window's)
+        //   write-out of J / J^T row j-2
+        //   tile (i, j+1) -= block column j-1                                      i = j+1 .. MT-1
+        //   write-out of L row j-1
+        const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
+        const int nf = j == 0 ? n1 + n2 : n2, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0;
+        const int ns = j >= 1 ? n1 : 0, nwl = j;
+        const int ntask = 1 + nf + ni + nwj + ns + nwl;
+        for (;;) {
+          int t = 0;
+          if (lane == 0) t = atomicAdd(&s_next, 1);
+          t = __builtin_amdgcn_readfirstlane(t) - tbase;
+          if (t >= ntask) break;
+          if (t == 0) { diag_tile(j, ltile); did_diag = true; continue; }
+          t -= 1;
+          if (t < nf) {
+            if (j == 0) { if (t < n1) fill_tile(1 + t, 1, 0); else fill_tile(2 + (t - n1), 2, 0); }
+            else fill_tile(j + 2 + t, j + 2, j);
+            continue;
+          }
+          t -= nf;
+          if (t < ni) { inv_tile(j - 1, t); continue; }
+          t -= ni;
+          if (t < nwj) { write_J(j - 2, t); continue; }
+          t -= nwj;
+          if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
+          t -= ns;
+          write_L(j - 1, t);
+        }
+#ifdef TGP_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j == 0) PSTAMP(7); else PSTAMP(8);
+#endif
+      }
+      tbase += 1 + (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? j - 1 : 0) +
+               (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j + (NW - npw);   // the tasks + one over-grab per task wave
+      PREP_BARRIER();
+      PSTAMP(4);
+      if (did_diag) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) A[(j0 + (lane & 15)) * LD + j0 + 4 * u + q] = ltile[u];
+      }
+      // ---- phase U: block column j+1 -= L(:, j) L(j+1, j)^T, one tile per wave ----
+      if (j + 1 < MT) {
+        for (int i = j + 1 + wave; i < MT; i += NW) sub16(i, j + 1, j0);
+#ifdef TGP_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        PSTAMP(5);
+        PREP_BARRIER();
+        PSTAMP(6);
+      }
+    }
+    if (has_nan) s_nan = 1;
+    __syncthreads();
+    if (s_info == 0 || s_nan != 0 || !(md.jitter_ladder > 0.0) || attempt == 3) break;
+    __syncthreads();  // everybody has read s_info
+    if (tid == 0) s_info = 0;
+    jit = md.jitter + md.jitter_ladder * (attempt == 0 ? 1.0 : (attempt == 1 ? 10.0 : 100.0));
+    __syncthreads();
   }
-  if (has_nan) s_nan = 1;
-  __syncthreads();
-  if (s_info == 0 || s_nan != 0 || !(md.jitter_ladder > 0.0) || attempt == 3) break;
-  __syncthreads();  // everybody has read s_info
-  if (tid == 0) s_info = 0;
-  jit = md.jitter + md.jitter_ladder * (attempt == 0 ? 1.0 : (attempt == 1 ? 10.0 : 100.0));
-  __syncthreads();
+  // ---- tail: J row MT-1 (Dinv_{MT-1} came with the last window), the last write-outs ----
+  {
+    const int ni = MT - 1, nwl = MT, nwj = MT >= 2 ? MT - 1 : 0;
+    const int ntask = ni + nwl + nwj;
+    for (int t = wave; t < ntask; t += NW) {
+      if (t < ni) inv_tile(MT - 1, t);
+      else if (t < ni + nwl) write_L(MT - 1, t - ni);
+      else write_J(MT - 2, t - (ni + nwl));
+    }
+    PREP_BARRIER();
+    for (int t = wave; t < MT; t += NW) write_J(MT - 1, t);
   }
-  // ---- the last tile row (the earlier rows left during the factorisation, see write_tile) ----
-  for (int tj = wave; tj < MT; tj += PREP_THREADS / 64) write_tile(MT - 1, tj);
+  PSTAMP(9);
+#ifdef TGP_STAMPS
+  if (lane == 0) {
+    if (wave == 0)
+      for (int i = 0; i < 10; ++i) ws[p.hdr + H_PSTAMP + i] = tph[i];
+    if (wave == 3) for (int i = 1; i <= 5; ++i) { ws[p.hdr + H_PSTAMP + 26 + i] = tph[i]; ws[p.hdr + 20 + i] = tcnt[i]; }
+    ws[p.hdr + H_PSTAMP + 10 + 2 * wave] = tph[7];      // this wave's window work, j = 0
+    ws[p.hdr + H_PSTAMP + 11 + 2 * wave] = tph[8];      // ... summed over j >= 1 (panel / diagonal-tile / task waves alike)
+  }
+#endif
   if (tid == 0) {
     status[0] = s_info;
     status[1] = s_nan;
     status[2] = s_info == 0 ? attempt : 0;
   }
-#ifdef TGP_STAMPS
-  if (tid == 0) {
-    unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 4; ++i) ws[p.hdr + H_STAMP + 12 + i] = tph[i];
-    ws[p.hdr + H_STAMP + 16] = (double)(tn_ - tlast);
-    for (int i = 1; i < 5; ++i) ws[p.hdr + H_STAMP + 18 + i] = twv[i];
-
-  }
-#endif
+#undef PREP_BARRIER
 }
 
 size_t prep_a_lds_bytes(const Plan& p) {
