@@ -219,7 +219,8 @@ def main():
     ap.add_argument("--replicas", type=int, default=1, help="(1 GPU only) K independent training runs of the workload on K "
                     "streams, value = their aggregate steps/s: how the chip is filled when several UCI splits train at once")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
-                    "--pmc pass of THIS build (tools/probes/pmc_summary.py); without it roofline.traffic is null")
+                    "--pmc pass, keyed by the source hash of the library it was measured on (default: "
+                    "profiles/rows_traffic.json); a summary of other sources is rejected and roofline.traffic is null")
     args = ap.parse_args()
     if args.scaling is None:
         args.scaling = "weak" if args.workload.startswith("tgp_airline") else "strong"
@@ -364,10 +365,20 @@ def main():
                  "SYRK, statistics) + flow quadrature" if big else
                  "k_rows (fused K_NM + 4 triangular GEMMs + flow quadrature + SYRK)")
         achieved = flop / (k_ms * 1e-3) / 1e12
-        traffic = None                     # measured by a separate --pmc pass of the same build, never a committed constant
-        if args.traffic_json and os.path.exists(args.traffic_json):
+        # HBM bytes per launch of the dominant kernel: from a rocprofv3 --pmc pass (separate FETCH_SIZE / WRITE_SIZE passes,
+        # tools/probes/profile_round.sh) of THE SAME SOURCES -- the summary carries the source hash of the library it was
+        # measured on and is rejected when the library loaded now was built from anything else; never a bare constant
+        traffic = None
+        tj = args.traffic_json or os.path.join(ROOT, "profiles", "rows_traffic.json")
+        if os.path.exists(tj):
             try:
-                traffic = json.load(open(args.traffic_json)).get(args.workload)
+                from tgp.pytorch_amd import lib as _lib
+                rec = json.load(open(tj))
+                if rec.get("source_hash") == _lib.load().tgp_source_hash().decode():
+                    traffic = rec.get("bytes_per_launch", {}).get(args.workload)
+                else:
+                    log("note: %s was measured on sources %s, this library is %s: roofline.traffic = null"
+                        % (tj, rec.get("source_hash"), _lib.load().tgp_source_hash().decode()))
             except Exception:
                 traffic = None
         units = (world if args.scaling == "weak" else 1) * (1 + len(extra))

@@ -17,9 +17,9 @@
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered, safe
  *     to capture into a hipGraph, and re-entrant when callers use distinct streams + workspaces;
  *     the general-M path (M > 128 or a non-RBF kernel) forks independent phases onto helper streams that the
- *     library creates at the first such call and joins before the call returns (event record / wait: valid under
- *     capture of `stream`, where they become parallel branches of the graph) -- make that first call outside a
- *     capture, and from one host thread at a time (the helper streams and events are per process);
+ *     library creates at a host thread's first such call and joins before the call returns (event record / wait:
+ *     valid under capture of `stream`, where they become parallel branches of the graph) -- make a thread's first
+ *     call outside a capture; the helper streams and events are per host thread, so threads never share them;
  *   - return value: 0 = launched; <0 = -(index of the offending argument) or TGP_E_*;
  *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[4]):
  *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive),

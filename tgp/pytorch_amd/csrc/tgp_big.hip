@@ -70,15 +70,18 @@ static bool big_overlap_enabled() {
   return v != 0;
 }
 
-// helper stream + events for the chunk pipeline (created once per process: one process drives one GPU)
+// helper stream + events for the chunk pipeline (created once per host thread)
 struct BigAux {
   hipStream_t fwd;
   hipEvent_t e0, eF[2], eB[2];
   bool ok;
 };
 static BigAux* big_aux() {
-  static BigAux a;
-  static bool init = false;
+  // one set per HOST THREAD: calls from different threads never share helper streams or events (the ABI is re-entrant
+  // across threads); two engines driven by one thread share a set, which is correct (stream order) and, once their steps
+  // are captured, irrelevant (the forked branches are nodes of each engine's own graph)
+  static thread_local BigAux a;
+  static thread_local bool init = false;
   if (!init) {
     init = true;
     a.ok = hipStreamCreateWithFlags(&a.fwd, hipStreamNonBlocking) == hipSuccess;
@@ -1282,7 +1285,7 @@ struct BigFork {
   }
 };
 static BigFork& big_fork() {
-  static BigFork f;
+  static thread_local BigFork f;  // per host thread, like big_aux()
   return f;
 }
 
