@@ -729,56 +729,49 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* A = reinterpret_cast<double*>(smem_raw);  // 128 x 129: lower = block -> L ; strict-upper TILES hold J^T tiles
   double* Dt = A + 128 * POTRF_LD;                  // 8 x 256: inverses of the diagonal 16x16 tiles
-  __shared__ int s_info;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const int LD = POTRF_LD, MT = 8;
+  __shared__ int s_info, s_next;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: task indices and their branches stay scalar
+  constexpr int LD = POTRF_LD, MT = 8, NW = POTRF_THREADS / 64;
   const size_t o = (size_t)kb * 128;
   double* Lb = Lm + o * ld + o;
   double* Jb = Jm + o * ld + o;
-  if (tid == 0) s_info = 0;
+  if (tid == 0) { s_info = 0; s_next = 0; }
   for (int e = tid; e < 128 * 128; e += POTRF_THREADS) {
     const int rr = e >> 7, cc = e & 127;
-    if (cc <= rr) A[rr * LD + cc] = Lb[(size_t)rr * ld + cc];
+    if ((cc >> 4) <= (rr >> 4)) A[rr * LD + cc] = Lb[(size_t)rr * ld + cc];
   }
   __syncthreads();
-  // Wave 0 runs the critical chain and shares its SIMD with wave 4, which stays idle; the six waves on the other three
-  // SIMDs are the helpers (hw = 0..5) -- the schedule of k_prep_a (tgp_mm.hip), round-2 form: at iteration j a helper
-  // takes everything that is already final off the two left-looking sums of row j + 1, so that only the newest block
-  // column (12 MFMAs instead of 8 j + 4) stays on wave 0's chain at iteration j + 1.
-  constexpr int NH = POTRF_THREADS / 64 - 2;
-  const int hw = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+  // The round-3 schedule of k_prep_a's factorisation block (tgp_mm.hip), on 8 x 8 tiles of 16 with the block read from
+  // global memory instead of generated: right-looking, ONE register pass of one wave per 16-column panel
+  // (potrf_panel16: diagonal tile + every row below it, no inverse / triangular solve / panel product on the chain),
+  // one 4-MFMA update per tile of the next block column between two panels, everything else (catching the later
+  // columns up, the diagonal tiles' inverses, the tiles of J = L^-1, the write-out) taken from a task counter in LDS
+  // by the other waves in the panel pass's shadow.
   auto ll_sum = [&](int i0, int j0, int kbeg, int kend) {
     d4 acc = {0, 0, 0, 0};
     return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
                      kend, acc);
   };
-  // tile (i, c) -= sum_{kbeg <= k < kend} L[i rows, k] L[c rows, k]^T in place (one wave; C/D layout read-modify-write)
-  auto sub_sum = [&](int i, int c, int kbeg, int kend) {
-    if (kend <= kbeg) return;
-    const d4 upd = ll_sum(16 * i, 16 * c, kbeg, kend);
+  // tile (i, c) -= block columns [0, ncol) (all final)
+  auto catchup_tile = [&](int i, int c, int ncol) {
+    const d4 upd = ll_sum(16 * i, 16 * c, 0, 16 * ncol);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] -= upd[rr];
   };
-  // panel tile (i, c): L_ic = (A_ic - sum_{kbeg <= k < 16 c} L_ik L_ck^T) Dinv_c^T  (kbeg > 0: the part below kbeg was
-  // subtracted from the tile beforehand)
-  auto panel_tile = [&](int i, int c, int kbeg) {
-    const int i0 = 16 * i, c0 = 16 * c;
-    const d4 upd = ll_sum(i0, c0, kbeg, c0);
-    double av[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) av[rr] = A[(i0 + q + 4 * rr) * LD + c0 + r] - upd[rr];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = av[rr];
-    __builtin_amdgcn_wave_barrier();
-    d4 acc = {0, 0, 0, 0};
+  // tile (i, c) -= L[i rows, k0 .. k0+15] L[c rows, k0 .. k0+15]^T : one block column's contribution, 4 MFMAs
+  auto sub16 = [&](int i, int c, int k0) {
     double a4[4], b4[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(i0 + r) * LD + c0 + 4 * s4 + q]; b4[s4] = Dt[c * 256 + r * 16 + 4 * s4 + q]; }
+    for (int s4 = 0; s4 < 4; ++s4) { a4[s4] = A[(16 * i + r) * LD + k0 + 4 * s4 + q]; b4[s4] = A[(16 * c + r) * LD + k0 + 4 * s4 + q]; }
+    double cur[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) cur[rr] = A[(16 * i + q + 4 * rr) * LD + 16 * c + r];
+    d4 acc = {0, 0, 0, 0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(a4[s4], b4[s4], acc);
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(i0 + q + 4 * rr) * LD + c0 + r] = acc[rr];
+    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] = cur[rr] - acc[rr];
   };
   auto inv_tile = [&](int j, int c) {
     const int j0 = 16 * j, c0 = 16 * c;
@@ -796,68 +789,126 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
   };
-  for (int j = 0; j <= MT; ++j) {
+  auto diag_tile = [&](int t, double (&lt)[4]) {
+    double a[16], x[16];
+    const int li = lane & 15, t0 = 16 * t;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = A[(t0 + li) * LD + t0 + c];
+    const int bad = potrf_trtri16(a, x, li);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same a[], x[]: row q keeps the columns 4u + q
+      lt[u] = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
+      const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+      Dt[t * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
+    }
+    if (lane == 0 && bad != 0 && s_info == 0) s_info = t0 + bad;
+  };
+  // write-out of tile (ti, tj) of the block: L (ti >= tj; the strict upper part of a diagonal tile as zeros), J likewise,
+  // zeros for the tiles above the diagonal (the block arrives with K's symmetric copy there)
+  auto write_L = [&](int ti, int tj) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      Lb[(size_t)rr * ld + cc] = (ti != tj || cc <= rr) ? A[rr * LD + cc] : 0.0;
+    }
+  };
+  auto write_J = [&](int ti, int tj) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      Jb[(size_t)rr * ld + cc] = (ti == tj) ? Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)] : A[cc * LD + rr];
+    }
+  };
+  auto zero_tile = [&](int ti, int tj) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
+      Lb[(size_t)rr * ld + cc] = 0.0;
+      Jb[(size_t)rr * ld + cc] = 0.0;
+    }
+  };
+#define POTRF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  int tbase = 0;
+  for (int j = 0; j < MT; ++j) {
     const int j0 = 16 * j;
-    if (wave == 0) {
-      if (j < MT) {
-        if (j > 0) {
-          panel_tile(j, j - 1, j >= 2 ? 16 * (j - 2) : 0);
-          __builtin_amdgcn_wave_barrier();
-          const d4 upd = ll_sum(j0, j0, 16 * (j - 1), j0);
+    const int npan = (MT - 1 - j) * 16;
+    const int npw = npan > 64 ? 2 : (npan > 0 ? 1 : 0);
+    double ltile[4] = {0.0, 0.0, 0.0, 0.0};
+    bool did_diag = false;
+    if (wave < npw) {
+      __builtin_amdgcn_s_setprio(3);
+      const int li = lane & 15, l0 = wave * 64 + lane;
+      const bool has = l0 < npan;
+      const int prow = j0 + 16 + (has ? l0 : 0);
+      double dg[16], a[16];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) A[(j0 + q + 4 * rr) * LD + j0 + r] -= upd[rr];
-          __builtin_amdgcn_wave_barrier();
-        }
-        double a[16], x[16];
-        const int li = lane & 15;
+      for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = A[(j0 + li) * LD + j0 + c];
-        const int bad = potrf_trtri16(a, x, li);
-        // the four 16-lane rows of the wave hold the same a[], x[]: row q stores the columns 4 u + q (all 64 lanes store,
-        // 4 + 4 plain ds_write_b64 each; the strict upper part of the diagonal tile is never read)
+      for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
+      (void)potrf_panel16<true>(dg, a);
+      if (has) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double av4 = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
-          const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-          A[(j0 + li) * LD + j0 + 4 * u + q] = av4;
-          Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
-        }
-        if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
+        for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
       }
-    } else if (hw >= 0 && j > 0) {
-      // step j-1: panel tiles i = j+1 .. MT-1, inverse tiles c = 0 .. j-2
-      const int npanel = MT - 1 - j > 0 ? MT - 1 - j : 0;
-      for (int t = hw; t < npanel + (j - 1); t += NH) {
-        if (t < npanel) {
-          panel_tile(j + 1 + t, j - 1, 0);
-          if (t == 0) {
-            // row j+1 is wave 0's at the next iteration:
-            //   tile (j+1, j+1) -= sum over block columns 0 .. j-1 (the last one is the panel tile just formed);
-            //   tile (j+1, j)   -= sum over block columns 0 .. j-2 (column j-1 needs L(j, j-1), wave 0's tile of THIS iteration)
-            __builtin_amdgcn_wave_barrier();
-            sub_sum(j + 1, j + 1, 0, 16 * j);
-            sub_sum(j + 1, j, 0, 16 * (j - 1));
-          }
-        } else {
-          inv_tile(j - 1, t - npanel);
-        }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      // tasks of this window, heaviest first: the diagonal tile j (L_jj, Dinv_j) | tiles (i, j+2) -= block columns
+      // 0 .. j-1 | tiles (j-1, c) of J | write-out of J row j-2 | tiles (i, j+1) -= block column j-1 | write-out of L row
+      // j-1 | [j = 0] zeros above the diagonal
+      const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
+      const int nc = j >= 1 ? n2 : 0, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0, ns = j >= 1 ? n1 : 0, nwl = j;
+      const int nz = j == 0 ? MT * (MT - 1) / 2 : 0;
+      const int ntask = 1 + nc + ni + nwj + ns + nwl + nz;
+      for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&s_next, 1);
+        t = __builtin_amdgcn_readfirstlane(t) - tbase;
+        if (t >= ntask) break;
+        if (t == 0) { diag_tile(j, ltile); did_diag = true; continue; }
+        t -= 1;
+        if (t < nc) { catchup_tile(j + 2 + t, j + 2, j); continue; }
+        t -= nc;
+        if (t < ni) { inv_tile(j - 1, t); continue; }
+        t -= ni;
+        if (t < nwj) { write_J(j - 2, t); continue; }
+        t -= nwj;
+        if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
+        t -= ns;
+        if (t < nwl) { write_L(j - 1, t); continue; }
+        t -= nwl;
+        int ti = 0;  // t -> (ti < tj): row-major over the strict upper triangle of tiles
+        while (t >= MT - 1 - ti) { t -= MT - 1 - ti; ++ti; }
+        zero_tile(ti, ti + 1 + t);
       }
     }
-    __syncthreads();
-  }
-  for (int e = tid; e < 128 * 128; e += POTRF_THREADS) {
-    const int rr = e >> 7, cc = e & 127, ti = rr >> 4, tj = cc >> 4;
-    double l = 0.0, jv = 0.0;
-    if (ti == tj) {
-      l = cc <= rr ? A[rr * LD + cc] : 0.0;
-      jv = Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)];
-    } else if (ti > tj) {
-      l = A[rr * LD + cc];
-      jv = A[cc * LD + rr];
+    {
+      const int n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
+      tbase += 1 + (j >= 1 ? n2 : 0) + (j >= 1 ? j - 1 : 0) + (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j +
+               (j == 0 ? MT * (MT - 1) / 2 : 0) + (NW - npw);
     }
-    Lb[(size_t)rr * ld + cc] = l;
-    Jb[(size_t)rr * ld + cc] = jv;
+    POTRF_BARRIER();
+    if (did_diag) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[(j0 + (lane & 15)) * LD + j0 + 4 * u + q] = ltile[u];
+    }
+    if (j + 1 < MT) {
+      for (int i = j + 1 + wave; i < MT; i += NW) sub16(i, j + 1, j0);
+      POTRF_BARRIER();
+    }
   }
+  // tail: J row MT-1 (Dinv_{MT-1} came with the last window), the last write-outs
+  {
+    const int ni = MT - 1, nwl = MT, nwj = MT - 1;
+    for (int t = wave; t < ni + nwl + nwj; t += NW) {
+      if (t < ni) inv_tile(MT - 1, t);
+      else if (t < ni + nwl) write_L(MT - 1, t - ni);
+      else write_J(MT - 2, t - (ni + nwl));
+    }
+    POTRF_BARRIER();
+    for (int t = wave; t < MT; t += NW) write_J(MT - 1, t);
+  }
+#undef POTRF_BARRIER
+  __syncthreads();
   if (tid == 0 && s_info != 0 && status[0] == 0) status[0] = (int)o + s_info;
 }
 
