@@ -789,20 +789,6 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
   };
-  auto diag_tile = [&](int t, double (&lt)[4]) {
-    double a[16], x[16];
-    const int li = lane & 15, t0 = 16 * t;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = A[(t0 + li) * LD + t0 + c];
-    const int bad = potrf_trtri16(a, x, li);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same a[], x[]: row q keeps the columns 4u + q
-      lt[u] = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
-      const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-      Dt[t * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
-    }
-    if (lane == 0 && bad != 0 && s_info == 0) s_info = t0 + bad;
-  };
   // write-out of tile (ti, tj) of the block: L (ti >= tj; the strict upper part of a diagonal tile as zeros), J likewise,
   // zeros for the tiles above the diagonal (the block arrives with K's symmetric copy there)
   auto write_L = [&](int ti, int tj) {
@@ -835,37 +821,54 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
     const int npw = npan > 64 ? 2 : (npan > 0 ? 1 : 0);
     double ltile[4] = {0.0, 0.0, 0.0, 0.0};
     bool did_diag = false;
-    if (wave < npw) {
+    if (wave < npw || (npw == 0 && wave == 0)) {
+      // wave 0 also carries the diagonal tile's inverse in the pass's shadow and owns L_jj, Dinv_j (see k_prep_a)
       __builtin_amdgcn_s_setprio(3);
       const int li = lane & 15, l0 = wave * 64 + lane;
       const bool has = l0 < npan;
-      const int prow = j0 + 16 + (has ? l0 : 0);
-      double dg[16], a[16];
+      const int prow = j0 + (npan > 0 ? 16 : 0) + (has ? l0 : 0);
+      double dg[16], a[16], x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
+      if (npan > 0) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
-      (void)potrf_panel16<true>(dg, a);
-      if (has) {
+        for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
+      }
+      int bad = 0;
+      if (wave == 0) {
+        if (npan > 0) bad = potrf_panel16<true, true>(dg, a, x, li);
+        else bad = potrf_panel16<false, true>(dg, a, x, li);
+      } else {
+        (void)potrf_panel16<true>(dg, a);
+      }
+      if (has && npan > 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
       }
+      if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ltile[u] = q == 0 ? dg[4 * u] : (q == 1 ? dg[4 * u + 1] : (q == 2 ? dg[4 * u + 2] : dg[4 * u + 3]));
+          const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+          Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;
+        }
+        did_diag = true;
+        if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
+      }
       __builtin_amdgcn_s_setprio(0);
     } else {
-      // tasks of this window, heaviest first: the diagonal tile j (L_jj, Dinv_j) | tiles (i, j+2) -= block columns
+      // tasks of this window, heaviest first: tiles (i, j+2) -= block columns
       // 0 .. j-1 | tiles (j-1, c) of J | write-out of J row j-2 | tiles (i, j+1) -= block column j-1 | write-out of L row
       // j-1 | [j = 0] zeros above the diagonal
       const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
       const int nc = j >= 1 ? n2 : 0, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0, ns = j >= 1 ? n1 : 0, nwl = j;
       const int nz = j == 0 ? MT * (MT - 1) / 2 : 0;
-      const int ntask = 1 + nc + ni + nwj + ns + nwl + nz;
+      const int ntask = nc + ni + nwj + ns + nwl + nz;
       for (;;) {
         int t = 0;
         if (lane == 0) t = atomicAdd(&s_next, 1);
         t = __builtin_amdgcn_readfirstlane(t) - tbase;
         if (t >= ntask) break;
-        if (t == 0) { diag_tile(j, ltile); did_diag = true; continue; }
-        t -= 1;
         if (t < nc) { catchup_tile(j + 2 + t, j + 2, j); continue; }
         t -= nc;
         if (t < ni) { inv_tile(j - 1, t); continue; }
@@ -883,8 +886,8 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
     }
     {
       const int n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
-      tbase += 1 + (j >= 1 ? n2 : 0) + (j >= 1 ? j - 1 : 0) + (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j +
-               (j == 0 ? MT * (MT - 1) / 2 : 0) + (NW - npw);
+      tbase += (j >= 1 ? n2 : 0) + (j >= 1 ? j - 1 : 0) + (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j +
+               (j == 0 ? MT * (MT - 1) / 2 : 0) + (NW - (npw > 0 ? npw : 1));
     }
     POTRF_BARRIER();
     if (did_diag) {

@@ -393,14 +393,26 @@ __device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], i
 // interleaved in one wave -- 800 instructions, issue-bound -- then a panel product and a diagonal update per block column).
 // Any wave can run this on its own 64 panel rows: it factorises its own copy of the diagonal tile redundantly and needs
 // nothing from the other waves.  Returns the first bad pivot (1-based; 0 = ok), the same in every lane.
-template <bool PANEL>
-__device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16]) {
+template <bool PANEL, bool TRTRI = false>
+__device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16], double* x = nullptr, int lane = 0) {
   int bad = 0;
   static_for<16>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const double d = bcast_row_k<k>(dg[k]);
     if (!(d > 0.0) && bad == 0) bad = k + 1;  // the same in every lane; also catches NaN
     const double rinv = rsqrt_nr(d);
+    if constexpr (TRTRI) {
+      // row k of X = L_jj^-1 rides in the pass's shadow as in potrf_trtri16: x[r] = X[r][lane & 15]
+      double s0 = 0.0, s1 = 0.0;
+      static_for<16>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < k) {
+          if constexpr ((m & 1) == 0) s0 = fma(bcast_row_k<k>(dg[m]), x[m], s0);
+          else s1 = fma(bcast_row_k<k>(dg[m]), x[m], s1);
+        }
+      });
+      x[k] = (lane == k) ? rinv : (lane < k ? -(s0 + s1) * rinv : 0.0);
+    }
     dg[k] *= rinv;  // column k of L_jj (lane k: d / sqrt(d))
     if constexpr (PANEL) a[k] *= rinv;
     static_for<16>([&](auto jc) {

@@ -265,24 +265,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #pragma unroll
     for (int u = 0; u < 4; ++u) A[(16 * i + q + 4 * u) * LD + 16 * c + r] = kv[u];
   };
-  // diagonal tile t: its own factorisation (the same arithmetic as the panel wave's copy, bit for bit) with the inverse
-  // riding in its shadow -> L_tt and Dinv_t, by one helper wave while the panel waves factorise block column t
-  // (L_tt is handed back in `lt` and stored by the caller AFTER the window's barrier: the panel waves read the tile's
-  //  input at the start of the same window)
-  auto diag_tile = [&](int t, double (&lt)[4]) {
-    double a[16], x[16];
-    const int li = lane & 15, t0 = 16 * t;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = A[(t0 + li) * LD + t0 + c];
-    const int bad = potrf_trtri16(a, x, li);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same a[], x[]: row q keeps the columns 4u + q
-      lt[u] = q == 0 ? a[4 * u] : (q == 1 ? a[4 * u + 1] : (q == 2 ? a[4 * u + 2] : a[4 * u + 3]));
-      const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-      Dt[t * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
-    }
-    if (lane == 0 && bad != 0 && s_info == 0) s_info = t0 + bad;
-  };
 #define PREP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifdef TGP_STAMPS
   // diagnostic build: shader-clock sums of the chain's pieces (wave 0) and of one helper's window work (wave 2)
@@ -315,29 +297,49 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       double ltile[4] = {0.0, 0.0, 0.0, 0.0};
       bool did_diag = false;
       // ---- phase P ----
-      if (wave < npw) {
-        // block column j of L below the diagonal tile: this wave's own copy of the diagonal tile + 64 panel rows
+      if (wave < npw || (npw == 0 && wave == 0)) {
+        // block column j of L: this wave's own copy of the diagonal tile + 64 rows of the panel below it; wave 0 also
+        // carries the tile's inverse in the pass's shadow (4.3 k cycles against 3.4 k without it -- and one 4.6 k-cycle
+        // task less for the other waves, which are bound by instruction issue) and owns L_jj and Dinv_j
         __builtin_amdgcn_s_setprio(3);   // the chain: wins instruction issue against its SIMD partner's task work
         const int li = lane & 15, l0 = wave * 64 + lane;
         const bool has = l0 < npan;
-        const int prow = j0 + 16 + (has ? l0 : 0);
-        double dg[16], a[16];
+        const int prow = j0 + (npan > 0 ? 16 : 0) + (has ? l0 : 0);
+        double dg[16], a[16], x[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
+        if (npan > 0) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
+          for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
+        }
 #ifdef TGP_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         PSTAMP(1);
-        (void)potrf_panel16<true>(dg, a);
+        int bad = 0;
+        if (wave == 0) {
+          if (npan > 0) bad = potrf_panel16<true, true>(dg, a, x, li);
+          else bad = potrf_panel16<false, true>(dg, a, x, li);
+        } else {
+          (void)potrf_panel16<true>(dg, a);
+        }
 #ifdef TGP_STAMPS
         asm volatile("" ::"v"(dg[15]), "v"(a[15]));
 #endif
         PSTAMP(2);
-        if (has) {
+        if (has && npan > 0) {
 #pragma unroll
           for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
+        }
+        if (wave == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same dg[], x[]: row q keeps the columns 4u + q
+            ltile[u] = q == 0 ? dg[4 * u] : (q == 1 ? dg[4 * u + 1] : (q == 2 ? dg[4 * u + 2] : dg[4 * u + 3]));
+            const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
+            Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
+          }
+          did_diag = true;   // L_jj goes to LDS after the window's barrier: the other panel wave reads the tile's input
+          if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
         }
 #ifdef TGP_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -347,11 +349,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #ifdef TGP_STAMPS
         if (wave != 0) { tph[j == 0 ? 7 : 8] += tph[1] + tph[2] + tph[3]; tph[1] = tph[2] = tph[3] = 0.0; }
 #endif
-      } else {
+      } else if (wave != 4) {
+        // (wave 4 shares wave 0's SIMD -- a workgroup's waves go to the SIMDs cyclically -- and stays out of the windows:
+        //  the chain wave is bound by instruction issue and gets the SIMD to itself)
         // The other waves take this window's tasks from a counter in LDS, heaviest first (all operands are final since
         // the last barrier and the tasks of one window are independent of each other, so any wave may run any of them;
         // dealt round-robin the windows were as long as the unluckiest wave's share):
-        //   the diagonal tile j: L_jj and Dinv_j (its own factorisation, the panel waves do not write the tile)
         //   tile (i, j+2)  = K_MM - block columns 0 .. j-1 (its first value)       i = j+2 .. MT-1   [j = 0: columns 1, 2]
         //   tiles (j-1, c), c < j-1, of J = L^-1    (Dinv_{j-1}: last window's)
         //   write-out of J / J^T row j-2
@@ -360,14 +363,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
         const int nf = j == 0 ? n1 + n2 : n2, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0;
         const int ns = j >= 1 ? n1 : 0, nwl = j;
-        const int ntask = 1 + nf + ni + nwj + ns + nwl;
+        const int ntask = nf + ni + nwj + ns + nwl;
         for (;;) {
           int t = 0;
           if (lane == 0) t = atomicAdd(&s_next, 1);
           t = __builtin_amdgcn_readfirstlane(t) - tbase;
           if (t >= ntask) break;
-          if (t == 0) { diag_tile(j, ltile); did_diag = true; continue; }
-          t -= 1;
           if (t < nf) {
             if (j == 0) { if (t < n1) fill_tile(1 + t, 1, 0); else fill_tile(2 + (t - n1), 2, 0); }
             else fill_tile(j + 2 + t, j + 2, j);
@@ -387,8 +388,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         if (j == 0) PSTAMP(7); else PSTAMP(8);
 #endif
       }
-      tbase += 1 + (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? j - 1 : 0) +
-               (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j + (NW - npw);   // the tasks + one over-grab per task wave
+      tbase += (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? j - 1 : 0) +
+               (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j + (NW - 1 - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
       PREP_BARRIER();
       PSTAMP(4);
       if (did_diag) {

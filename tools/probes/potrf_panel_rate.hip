@@ -20,6 +20,7 @@ __global__ __launch_bounds__(64) void k(double* out, unsigned long long* tm, con
     if (WHAT == 1) bad = potrf_panel16<true>(a, pr);
     if (WHAT == 2) bad = potrf_panel16<false>(a, pr);
     if (WHAT == 3) trtri16(a, x, lane & 15);
+    if (WHAT == 4) bad = potrf_panel16<true, true>(a, pr, x, lane & 15);
     double s = bad;
     for (int c = 0; c < 16; ++c) s += a[c] + x[c] + pr[c];
     acc = s;
@@ -34,13 +35,14 @@ int main() {
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) h[i * 16 + j] = (i == j ? 20.0 : 0.0) + 1.0 / (1 + (i > j ? i - j : j - i));
   double* A; hipMalloc(&A, 2048); hipMemcpy(A, h, 2048, hipMemcpyHostToDevice);
   double* out; unsigned long long* tm; hipMalloc(&out, 512); hipMalloc(&tm, 8);
-  const char* names[4] = {"potrf_trtri16 (rounds 1-2)", "potrf_panel16<true> (tile + 64 panel rows)", "potrf_panel16<false> (tile only)", "trtri16 (stand-alone)"};
-  for (int w = 0; w < 4; ++w) {
+  const char* names[5] = {"potrf_trtri16 (rounds 1-2)", "potrf_panel16<true> (tile + 64 panel rows)", "potrf_panel16<false> (tile only)", "trtri16 (stand-alone)", "potrf_panel16<true, true> (tile + 64 rows + inverse)"};
+  for (int w = 0; w < 5; ++w) {
     for (int rep = 0; rep < 2; ++rep) {
       if (w == 0) k<0><<<1, 64>>>(out, tm, A, 20);
       if (w == 1) k<1><<<1, 64>>>(out, tm, A, 20);
       if (w == 2) k<2><<<1, 64>>>(out, tm, A, 20);
       if (w == 3) k<3><<<1, 64>>>(out, tm, A, 20);
+      if (w == 4) k<4><<<1, 64>>>(out, tm, A, 20);
       hipDeviceSynchronize();
     }
     unsigned long long r; hipMemcpy(&r, tm, 8, hipMemcpyDeviceToHost);
