@@ -152,6 +152,28 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
                              double* out, const tgp_grads* grads, double* mu, double* v, int32_t* status,
                              void* workspace, size_t workspace_bytes, uint32_t phases, void* stream);
 
+/* The whole training step of one rank in one call: tgp_elbo_step_f64 followed by tgp_adam_dev_f64 over a flat parameter
+ * buffer (trainers/trainer_base.py:337-342: ELBO, backward, optimizer.step()).  `adam` describes the flat buffers; the
+ * pointers of `grads` must point INTO adam->grads (the engine's layout: every gradient a view of one buffer), no weight
+ * decay.  On the fused path (M <= 128) the update is applied inside the last two backward launches (the q(u) factor's
+ * 10^4 entries by passenger workgroups beside the K_MM adjoint, the rest where the gradients are assembled): one launch
+ * and one dependent pass over the buffers less than the two calls.  Same arithmetic, same results.  Single rank only: a
+ * data-parallel step has its all-reduce between the gradients and the update and keeps the two calls. */
+typedef struct tgp_adam_args {
+  double* params;      /* (n) */
+  double* grads;       /* (n) written by this call */
+  double* exp_avg;     /* (n) */
+  double* exp_avg_sq;  /* (n) */
+  int64_t n;
+  double lr, beta1, beta2, eps;
+  int32_t* step_dev;   /* device int32[2] {step, ticket}, as tgp_adam_dev_f64 */
+  int32_t maximize;    /* != 0: ascend (the gradients are of +ELBO) */
+  int32_t reserved0;
+} tgp_adam_args;
+int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
+                           const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
+                           size_t workspace_bytes, const tgp_adam_args* adam, void* stream);
+
 /* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
  * whitened, diagonal=True).  mu, v: (N). */
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,

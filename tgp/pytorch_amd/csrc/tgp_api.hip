@@ -89,9 +89,9 @@ int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, 
   return tgp_elbo_step_phases_f64(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes, 7u, stream);
 }
 
-int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp,
-                             double* out, const tgp_grads* grads, double* mu, double* v, int32_t* status,
-                             void* workspace, size_t workspace_bytes, uint32_t phases, void* stream) {
+static int elbo_step_impl(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
+                          const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
+                          size_t workspace_bytes, uint32_t phases, const tgp_adam_args* adam, void* stream) {
   if (int rc = check_model(model, true)) return rc;
   if (!X) return -2;
   if (!Y) return -3;
@@ -114,8 +114,29 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   FlowProg fp;
   if (int rc = make_prog(&md, model->lik == TGP_LIK_FLOW, fp)) return rc;
   md.program = nullptr;  // kernels use the by-value copy
-  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF)
-    return launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st);
+  AdamDev ad;
+  if (adam != nullptr) {
+    if (!adam->params || !adam->grads || !adam->exp_avg || !adam->exp_avg_sq || !adam->step_dev || adam->n < 1) return -12;
+    // every gradient of the call must be a view of adam->grads
+    const double* lo = adam->grads;
+    const double* hi = adam->grads + adam->n;
+    const double* gp[7] = {grads->Z, grads->raw_ls, grads->raw_os, grads->m, grads->Lam, grads->log_var_noise, grads->theta};
+    for (int k = 0; k < 7; ++k)
+      if (gp[k] != nullptr && (gp[k] < lo || gp[k] >= hi)) return -12;
+    ad.p = adam->params; ad.g = adam->grads; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.n = (long)adam->n;
+    ad.lam_off = (long)(grads->Lam - adam->grads); ad.lam_n = (long)model->M * model->M;
+    ad.lr = adam->lr; ad.b1 = adam->beta1; ad.b2 = adam->beta2; ad.eps = adam->eps;
+    ad.ln_b1 = log(adam->beta1); ad.ln_b2 = log(adam->beta2); ad.sign = adam->maximize ? -1.0 : 1.0;
+    ad.step_dev = adam->step_dev;
+  }
+  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) {
+    if (int rc = launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st))
+      return rc;
+    if (adam != nullptr)   // general-M path: the update stays a launch of its own
+      return launch_adam_dev(adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq, adam->n, adam->lr, adam->beta1,
+                             adam->beta2, adam->eps, 0.0, adam->step_dev, adam->maximize, st);
+    return 0;
+  }
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
@@ -125,8 +146,22 @@ int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const doub
   if (phases & TGP_PHASE_ROWS)
     if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
   if (phases & TGP_PHASE_BACKWARD)
-    if (int rc = launch_backward_mm(p, md, *grads, out, ws, st)) return rc;
+    if (int rc = launch_backward_mm(p, md, *grads, out, ws, st, adam != nullptr ? &ad : nullptr)) return rc;
   return 0;
+}
+
+int tgp_elbo_step_phases_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp,
+                             double* out, const tgp_grads* grads, double* mu, double* v, int32_t* status,
+                             void* workspace, size_t workspace_bytes, uint32_t phases, void* stream) {
+  return elbo_step_impl(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes, phases, nullptr, stream);
+}
+
+int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
+                           const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
+                           size_t workspace_bytes, const tgp_adam_args* adam, void* stream) {
+  if (adam == nullptr) return -12;
+  return elbo_step_impl(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes,
+                        TGP_PHASE_PREPARE | TGP_PHASE_ROWS | TGP_PHASE_BACKWARD, adam, stream);
 }
 
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,

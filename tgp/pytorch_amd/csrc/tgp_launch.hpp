@@ -20,7 +20,18 @@ inline int ensure_lds(const void* func, size_t bytes, size_t* cur) {
 
 // tgp_mm.hip
 int launch_prepare(const Plan& p, const tgp_model& md, const FlowProg& fp, double* ws, int32_t* status, hipStream_t st);
-int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st);
+// Adam folded into the backward launches of the fused path (tgp_elbo_step_adam_f64); p == nullptr: none
+struct AdamDev {
+  double* p = nullptr;
+  const double* g = nullptr;
+  double* m = nullptr;
+  double* v = nullptr;
+  long n = 0, lam_off = 0, lam_n = 0;  // [lam_off, lam_off + lam_n): the q(u) factor's entries, updated beside the K_MM adjoint
+  double lr = 0, b1 = 0, b2 = 0, eps = 0, ln_b1 = 0, ln_b2 = 0, sign = 1;
+  int32_t* step_dev = nullptr;
+};
+int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st,
+                       const AdamDev* adam = nullptr);
 int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
                hipStream_t st);
 int launch_knm(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int N, int M, int D,

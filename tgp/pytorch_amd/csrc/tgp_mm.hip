@@ -657,11 +657,34 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
 //   Ks(i, j) = 1/2 (Y J)(i, j)  = dELL/dK_MM  (never stored)
 //   PP[i][col][d] = sum_{rows in block i} (Ks o K_MM)[row][col] * [Zs[row][d], 1]   (ARD-RBF parameter partials)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restrict__ ws) {
+// Adam on element i of the flat buffers (torch.optim.Adam; k_adam_dev's arithmetic, tgp_lik.hip)
+__device__ __forceinline__ void adam_elem(const AdamDev& A, long i, double g, double pi, double mi, double vi, double bc1,
+                                          double bc2s) {
+  const double gi = A.sign * g;
+  const double m1 = A.b1 * mi + (1.0 - A.b1) * gi;
+  const double v1 = A.b2 * vi + (1.0 - A.b2) * gi * gi;
+  A.m[i] = m1;
+  A.v[i] = v1;
+  A.p[i] = pi - (A.lr / bc1) * m1 / (sqrt(v1) / bc2s + A.eps);
+}
+
+__global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restrict__ ws, AdamDev ad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Yl = reinterpret_cast<double*>(smem_raw);  // MT x 256
   const int MP = p.MP, MT = p.MT, DP = p.DP, PPW = p.PPW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x >= MT) {
+    // passenger workgroups (tgp_elbo_step_adam_f64): the Adam update of the q(u) factor, whose gradient the previous
+    // launch (k_bwd12) finished -- 10^4 of the step's ~10.5 k parameters, off every chain, on CUs this launch leaves idle.
+    // The step counter is read here and advanced by the NEXT launch (k_bwd5), after every reader.
+    const double step = (double)(ad.step_dev[0] + 1);
+    const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
+    for (long k = (long)(blockIdx.x - MT) * BWD_THREADS + tid; k < ad.lam_n; k += (long)(gridDim.x - MT) * BWD_THREADS) {
+      const long i = ad.lam_off + k;
+      adam_elem(ad, i, ad.g[i], ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
+    }
+    return;
+  }
   const int i = blockIdx.x, i0 = 16 * i;
   const double* __restrict__ J = ws + p.J;
   const double* __restrict__ Q = ws + p.Q;
@@ -709,11 +732,27 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restric
 // ---------------------------------------------------------------------------------------------------
 // k_bwd5: assemble the remaining gradients + the scalars (single block; everything here is O(M D))
 // ---------------------------------------------------------------------------------------------------
+#define BWD5_ADAM_PER_THREAD 4 /* (n - M^2) / 256 rounded up: 530 at Power; more falls back to a loop */
 __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g, double* __restrict__ out,
-                                               double* __restrict__ ws) {
+                                               double* __restrict__ ws, AdamDev ad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* term = reinterpret_cast<double*>(smem_raw);  // M x (D+1): per-(j,d) lengthscale terms, column D = cs_j + T0_j
   const int tid = threadIdx.x;
+  // tgp_elbo_step_adam_f64: this workgroup also applies Adam to everything but the q(u) factor (k_bwd34's passengers
+  // took that).  The optimiser state of a thread's elements is requested NOW, at the top: the loads land under the
+  // gradient assembly below instead of costing a round trip of their own after it.
+  const long n_rest = ad.p != nullptr ? ad.n - ad.lam_n : 0;
+  double ap[BWD5_ADAM_PER_THREAD], am[BWD5_ADAM_PER_THREAD], av[BWD5_ADAM_PER_THREAD];
+  double a_step = 0.0;
+  if (ad.p != nullptr) {
+    a_step = (double)(ad.step_dev[0] + 1);
+#pragma unroll
+    for (int u = 0; u < BWD5_ADAM_PER_THREAD; ++u) {
+      const long k = tid + 256L * u;
+      const long i = k < n_rest ? (k < ad.lam_off ? k : k + ad.lam_n) : 0;
+      ap[u] = ad.p[i]; am[u] = ad.m[i]; av[u] = ad.v[i];
+    }
+  }
   const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, CT16 = p.CT16, PPW = p.PPW, MT = p.MT;
   const double* hdr = ws + p.hdr;
   const double s2 = hdr[H_S2];
@@ -773,6 +812,27 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
       out[2] = kl;
       out[3] = 0.0;
     }
+  }
+  if (ad.p != nullptr) {
+    __syncthreads();  // (drains this workgroup's gradient stores: vmcnt(0) + barrier)
+    const double bc1 = 1.0 - exp_fast(a_step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(a_step * ad.ln_b2));
+#pragma unroll
+    for (int u = 0; u < BWD5_ADAM_PER_THREAD; ++u) {
+      const long k = tid + 256L * u;
+      if (k < n_rest) {
+        const long i = k < ad.lam_off ? k : k + ad.lam_n;
+        // the gradient was stored by another thread of this workgroup a moment ago: read it past the CU's L1
+        const double gi = __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        adam_elem(ad, i, gi, ap[u], am[u], av[u], bc1, bc2s);
+      }
+    }
+    for (long k = tid + 256L * BWD5_ADAM_PER_THREAD; k < n_rest; k += 256) {
+      const long i = k < ad.lam_off ? k : k + ad.lam_n;
+      const double gi = __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      adam_elem(ad, i, gi, ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
+    }
+    // every reader of the step counter (this workgroup above, k_bwd34's passengers in the previous launch) is done
+    if (tid == 0) atomicAdd(&ad.step_dev[0], 1);
   }
 }
 
@@ -1060,16 +1120,20 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
   return 0;
 }
 
-int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st) {
+int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st,
+                       const AdamDev* adam) {
+  const AdamDev ad = adam != nullptr ? *adam : AdamDev();
+  const int npass = adam != nullptr ? (int)((ad.lam_n + BWD_THREADS - 1) / BWD_THREADS) : 0;
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   const size_t lds12 = (size_t)(2 * p.MP * 16 + 16) * sizeof(double);
   if (md.RP > 0) hipLaunchKernelGGL(k_bwd12<0>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
   else hipLaunchKernelGGL(k_bwd12<TGP_PF2>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd34, dim3(p.MT), dim3(BWD_THREADS), ((size_t)p.MT * 256 + 16 * p.DP) * sizeof(double), st, p, ws);
+  hipLaunchKernelGGL(k_bwd34, dim3(p.MT + (npass < 64 ? npass : 64)), dim3(BWD_THREADS), ((size_t)p.MT * 256 + 16 * p.DP) * sizeof(double), st,
+                     p, ws, ad);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), (size_t)p.M * (p.D + 1) * sizeof(double), st, p, md, g, out, ws);
+  hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), (size_t)p.M * (p.D + 1) * sizeof(double), st, p, md, g, out, ws, ad);
   LAUNCH_CHECK();
   return 0;
 }

@@ -157,6 +157,13 @@ class ElboEngine:
         if self.mlp is not None:
             d = self.mlp.struct(self.N, True)
             self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
+        # One rank, shared flow parameters only: ELBO step + Adam in ONE C-ABI call (tgp_elbo_step_adam_f64: on the fused
+        # path the update rides in the last two backward launches -- one launch and one pass over the buffers less)
+        self.fused_adam = self.world_size == 1 and self.mlp is None and os.environ.get("TGP_FUSED_ADAM", "1") != "0"
+        self.ad = L.TgpAdamArgs()
+        self.ad.params, self.ad.grads = L.ptr(fp.data), L.ptr(fp.grad)
+        self.ad.exp_avg, self.ad.exp_avg_sq = L.ptr(fp.exp_avg), L.ptr(fp.exp_avg_sq)
+        self.ad.n, self.ad.step_dev, self.ad.maximize = fp.n, L.ptr(self.step_dev), 1
         self._side = None
         self.pipeline_steps = True      # ID_TGP, one rank: capture the rotated unit (see capture())
         self._out = None                # redirected scalar output while the unrolled graph is being captured
@@ -173,6 +180,16 @@ class ElboEngine:
                                                L.ptr(out), self.gs, None, None, L.ptr(self.status),
                                                L.ptr(self.ws), self.ws.numel() * 8, phases, L.stream_ptr())
         L.check(rc, "tgp_elbo_step_phases_f64")
+        self._warm = True
+
+    def step_adam(self):
+        """forward_backward() + adam() as one call (fused_adam engines): same kernels' arithmetic, same results."""
+        out = self.fp.out if self._out is None else self._out
+        self.ad.lr, self.ad.beta1, self.ad.beta2, self.ad.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        rc = self.lib.tgp_elbo_step_adam_f64(self.md, L.ptr(self.X), L.ptr(self.Y), L.ptr(self.rowp), L.ptr(out), self.gs,
+                                             None, None, L.ptr(self.status), L.ptr(self.ws), self.ws.numel() * 8, self.ad,
+                                             L.stream_ptr())
+        L.check(rc, "tgp_elbo_step_adam_f64")
         self._warm = True
 
     def allreduce(self):
@@ -244,9 +261,12 @@ class ElboEngine:
             return self.replay()
         if self.pre_step is not None:
             self.pre_step()
-        self.forward_backward()
-        self.allreduce()
-        self.adam()
+        if self.fused_adam:
+            self.step_adam()
+        else:
+            self.forward_backward()
+            self.allreduce()
+            self.adam()
         if self.post_step is not None:
             self.post_step()
 
@@ -311,9 +331,12 @@ class ElboEngine:
         else:
             def unit():
                 pre()
-                self.forward_backward()
-                self.allreduce()
-                self.adam()
+                if self.fused_adam:
+                    self.step_adam()
+                else:
+                    self.forward_backward()
+                    self.allreduce()
+                    self.adam()
                 post()
             self.g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):

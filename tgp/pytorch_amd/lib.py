@@ -36,6 +36,12 @@ class TgpGrads(C.Structure):
                 ("theta", _dp), ("rowp", _dp)]
 
 
+class TgpAdamArgs(C.Structure):
+    _fields_ = [("params", _dp), ("grads", _dp), ("exp_avg", _dp), ("exp_avg_sq", _dp), ("n", C.c_int64), ("lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step_dev", _dp), ("maximize", C.c_int32),
+                ("reserved0", C.c_int32)]
+
+
 class TgpMlp(C.Structure):
     _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("nnets", C.c_int32),
                 ("act", C.c_int32), ("training", C.c_int32), ("reserved0", C.c_int32), ("drop_p", C.c_double),
@@ -59,6 +65,8 @@ _SIGS = {
                                     C.c_size_t, _dp]),
     "tgp_elbo_step_phases_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp,
                                            _dp, C.c_size_t, C.c_uint32, _dp]),
+    "tgp_elbo_step_adam_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
+                                         C.c_size_t, C.POINTER(TgpAdamArgs), _dp]),
     "tgp_qf_moments_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
     "tgp_kmm_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _dp]),
     "tgp_knm_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
