@@ -65,7 +65,11 @@ def test_elbo_step_matches_reference_fixture(name):
 
 @pytest.mark.parametrize("N,D,M,flow,S", [(300, 4, 100, "sal2", 32), (1000, 8, 37, "tanh3x2", 32), (129, 13, 5, None, 8),
                                            (513, 6, 128, "sal1", 20), (64, 16, 16, "idsal3", 32), (9, 3, 8, "sal2", 8), (65, 3, 17, "tanh1x1", 5),
-                                           (200, 13, 5, "tanh10x2", 20), (300, 8, 100, "tanh5x6", 32), (150, 4, 30, "sal3", 100)])
+                                           (200, 13, 5, "tanh10x2", 20), (300, 8, 100, "tanh5x6", 32), (150, 4, 30, "sal3", 100),
+                                           # every tile count of the factorisation's panel schedule (MT = 4, 5, 6) and
+                                           # M = 128 with D > 8 (no room for Zs in the factorisation block's LDS)
+                                           (100, 3, 60, None, 8), (250, 5, 70, "sal1", 8), (250, 4, 90, None, 8),
+                                           (200, 13, 128, "sal2", 16)])
 def test_elbo_step_matches_oracle(N, D, M, flow, S):
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(N, D, M, seed=3, flow=flow, S=S)
