@@ -14,10 +14,6 @@ for flow in ("tanh3x2", "sal2", None):
     torch.cuda.synchronize()
     hdr = eng.ws[8:8 + 11].cpu().tolist()
     d = [(hdr[i + 1] - hdr[i]) * 0.01 for i in range(10)]
-    ph = eng.ws[8 + 12:8 + 17].cpu().tolist()
-    print("prep_a block0: kmm %.1f  phase1(update) %.1f  phase2(potrf+trtri) %.1f  phase3(panel+J) %.1f  writeout %.1f us" % tuple(0.01 * t for t in ph))
-    wv = eng.ws[8 + 19:8 + 23].cpu().tolist()
-    print("wave-0 chain (shader cycles, summed over 6 block columns): panel %.0f  diag update %.0f  load+potrf+trtri %.0f  store %.0f" % tuple(wv))
     ex = eng.ws[8 + 17:8 + 19].cpu().tolist()
     print("phase2 detail: write+sync %.1f  G tiles %.1f  s tiles %.1f" % ((ex[0]-hdr[8])*0.01, (ex[1]-ex[0])*0.01, (hdr[9]-ex[1])*0.01))
     ck = eng.ws[8 + 11].item(), eng.ws[8 + 23].item()
