@@ -236,6 +236,14 @@ int tgp_ell_flow_f64(const tgp_model* model, const double* Y, const double* mu, 
 int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_t N, const double* rowp, double* G,
                       double* dG, double* logdG, void* stream);
 
+/* Fused flow + log-Jacobian accumulation: out[0] = sum over the (S,N) array of log dG/df (fixed summation order,
+ * bit-reproducible), G (optional) = the warped values -- the two quantities of a warped-GP likelihood term
+ * (likelihoods/WarpedGaussianLinearMean.py:65-85: log p(y) = log N(G(y) | ...) + sum log G'(y)) in one pass over f,
+ * nothing of size S x N written unless G is asked for. */
+size_t tgp_flow_logdet_workspace_bytes(int32_t S, int32_t N);
+int tgp_flow_logdet_f64(const tgp_model* model, const double* f, int32_t S, int32_t N, const double* rowp, double* G,
+                        double* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Evaluation path given q(f) moments: predictive moments m1, m2
  * (GaussianNonLinearMean.marginal_moments :152-203 / GaussianLinearMean.marginal_moments :89-118) and the
  * per-row test log-likelihood WITHOUT the -0.5*log(pi) constant (models/sparse_MF_SP.py:705-776, 786-799).

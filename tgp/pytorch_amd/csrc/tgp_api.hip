@@ -323,6 +323,30 @@ int tgp_flow_eval_f64(const tgp_model* model, const double* f, int32_t S, int32_
   return launch_flow_eval(md, fp, f, S, N, rowp, G, dG, logdG, static_cast<hipStream_t>(stream));
 }
 
+size_t tgp_flow_logdet_workspace_bytes(int32_t S, int32_t N) {
+  return (((size_t)S * (size_t)N + 1023) / 1024 + 16) * sizeof(double);
+}
+
+int tgp_flow_logdet_f64(const tgp_model* model, const double* f, int32_t S, int32_t N, const double* rowp, double* G,
+                        double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!model) return -1;
+  if (model->nblk > 0 && !model->program) return -1;
+  if (model->P > 0 && !model->theta) return -1;
+  if (!f) return -2;
+  if (S < 1) return -3;
+  if (N < 1) return -4;
+  if (model->RP > 0 && !rowp) return -5;
+  if (!out) return -7;
+  if (!workspace) return -8;
+  if (workspace_bytes < tgp_flow_logdet_workspace_bytes(S, N)) return TGP_E_WORKSPACE;
+  FlowProg fp;
+  if (int rc = make_prog(model, true, fp)) return rc;
+  tgp_model md = *model;
+  md.program = nullptr;
+  return launch_flow_eval(md, fp, f, S, N, rowp, G, nullptr, nullptr, static_cast<hipStream_t>(stream), out,
+                          static_cast<double*>(workspace));
+}
+
 int tgp_predict_f64(const tgp_model* model, const double* mu, const double* v, const double* rowp, const double* Y,
                     double Y_std, double* m1, double* m2, double* logp, void* stream) {
   if (!model || model->N < 1 || !model->log_var_noise) return -1;

@@ -77,7 +77,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
                     double* out, double* g_mu, double* g_v, double* g_theta, double* g_rowp, double* ws,
                     hipStream_t st);
 int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, int S, int N, const double* rowp, double* G, double* dG,
-                     double* logdG, hipStream_t st);
+                     double* logdG, hipStream_t st, double* sum_out = nullptr, double* ws = nullptr);
 int launch_predict(const tgp_model& md, const FlowProg& fp, const double* mu, const double* v, const double* rowp, const double* Y,
                    double Y_std, double* m1, double* m2, double* logp, hipStream_t st);
 int launch_adam(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,

@@ -186,10 +186,12 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, FlowProg fp, const double* __restrict__ f, size_t total, int N,
                                                     const double* __restrict__ rowp, double* __restrict__ G,
-                                                    double* __restrict__ dG, double* __restrict__ logdG) {
+                                                    double* __restrict__ dG, double* __restrict__ logdG,
+                                                    double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* tp = reinterpret_cast<double*>(smem_raw);
   double* tg = tp + (md.P + 2) / 2 * 2;
+  __shared__ double redl[4];
   flow_params_lds(md, fp, tp, tg);
   FlowDev F{fp.blk, fp.nblk, tp, tg};
   // four elements per thread, a grid stride apart (coalesced), evaluated stage by stage (flow_forward_n)
@@ -203,8 +205,18 @@ __global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, FlowProg fp, co
     fv[u] = f[ic];
     rp[u] = rowp ? rowp + (ic % N) * md.RP : nullptr;
   }
-  if (dG || logdG) flow_forward_n<NB, true>(F, fv, rp, der);
+  if (dG || logdG || part) flow_forward_n<NB, true>(F, fv, rp, der);
   else flow_forward_n<NB, false>(F, fv, rp, der);
+  if (part) {
+    // fused log-Jacobian accumulation: sum of log dG/df over this workgroup's elements, fixed order (lane partials ->
+    // butterfly over the wave -> the four waves in LDS); the launcher's second kernel adds the workgroups' partials
+    double sl = 0.0;
+    TGP_EACH(u, NB) sl += (i0 + u * stride < total) ? log(der[u]) : 0.0;
+    sl = wave_sum(sl);
+    if ((threadIdx.x & 63) == 0) redl[threadIdx.x >> 6] = sl;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (redl[0] + redl[1]) + (redl[2] + redl[3]);
+  }
   if (logdG) {
     double lg[NB];
     TGP_EACH(u, NB) lg[u] = der[u];
@@ -436,12 +448,17 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
 }
 
 int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, int S, int N, const double* rowp, double* G, double* dG,
-                     double* logdG, hipStream_t st) {
+                     double* logdG, hipStream_t st, double* sum_out, double* ws) {
   const size_t total = (size_t)S * N;
   const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
-  hipLaunchKernelGGL(k_flow_eval, dim3((unsigned)((total + 1023) / 1024)), dim3(256), lds, st, md, fp, f, total, N, rowp, G,
-                     dG, logdG);
+  const unsigned nb = (unsigned)((total + 1023) / 1024);
+  hipLaunchKernelGGL(k_flow_eval, dim3(nb), dim3(256), lds, st, md, fp, f, total, N, rowp, G, dG, logdG,
+                     sum_out != nullptr ? ws : (double*)nullptr);
   LAUNCH_CHECK();
+  if (sum_out != nullptr) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, ws, (int)nb, 1, sum_out, (double*)nullptr, 1);
+    LAUNCH_CHECK();
+  }
   return 0;
 }
 

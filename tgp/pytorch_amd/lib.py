@@ -80,6 +80,8 @@ _SIGS = {
     "tgp_ell_flow_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t,
                                    _dp]),
     "tgp_flow_eval_f64": (C.c_int, [C.POINTER(TgpModel), _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp]),
+    "tgp_flow_logdet_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "tgp_flow_logdet_f64": (C.c_int, [C.POINTER(TgpModel), _dp, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
     "tgp_predict_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp]),
     "tgp_kmeans_assign_f64": (C.c_int, [_dp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp]),
     "tgp_kmeans_segsum_f64": (C.c_int, [_dp, C.c_int32, _dp, _dp, C.c_int32, _dp, _dp]),

@@ -407,6 +407,23 @@ def flow_eval(f, flow, theta, rowp=None, want=("G", "dG", "logdG")):
     return outs
 
 
+def flow_logdet(f, flow, theta, rowp=None, want_G=False):
+    """sum log dG/df over f (S,N) or (N,) in one fused pass (tgp_flow_logdet_f64); returns (sum 0-d, G or None)."""
+    lib = L.load()
+    f = _c(f, "f")
+    theta, rowp = _c(theta, "theta"), _c(rowp, "rowp")
+    f2 = f.reshape(1, -1) if f.dim() == 1 else f
+    S, N = f2.shape
+    lvn = torch.zeros(1, dtype=torch.float64, device=f.device)
+    md, keep = _flow_model(N, 1, flow, theta, lvn, f.device)
+    G = torch.empty_like(f) if want_G else None
+    out = torch.empty(1, dtype=torch.float64, device=f.device)
+    ws = torch.empty(lib.tgp_flow_logdet_workspace_bytes(S, N) // 8, dtype=torch.float64, device=f.device)
+    L.check(lib.tgp_flow_logdet_f64(md, L.ptr(f2), S, N, L.ptr(rowp), L.ptr(G), L.ptr(out), L.ptr(ws), ws.numel() * 8,
+                                    L.stream_ptr()), "tgp_flow_logdet_f64")
+    return out[0], G
+
+
 def predict(mu, v, lvn, flow=None, theta=None, S=None, rowp=None, Y=None, Y_std=1.0):
     """Predictive moments m1, m2 and per-row test log-likelihood kernel (see tgp_predict_f64)."""
     lib = L.load()
