@@ -347,7 +347,7 @@ class ElboEngine:
 
     def _capture_unrolled(self, unit, unroll):
         """A second graph of U consecutive steps (one rank only).  Launching a graph costs ~5 us of idle GPU between two
-        replays of the 7-launch chain (14 us with the two-stream ID_TGP unit): U steps per launch pay it once (Power TGP
+        replays of the 6-launch chain (14 us with the two-stream ID_TGP unit): U steps per launch pay it once (Power TGP
         129.5 -> 125 us per step at U = 8-10, ID_TGP 148 -> 141).  The same kernels in the same order: results are
         bit-identical to U single-step replays.  The scalars of the first U - 1 steps go to self.hist_u (the step's `out`
         argument is redirected: no copy node), the last step's to fp.out as always."""
