@@ -168,7 +168,8 @@ typedef struct tgp_adam_args {
   double lr, beta1, beta2, eps;
   int32_t* step_dev;   /* device int32[2] {step, ticket}, as tgp_adam_dev_f64 */
   int32_t maximize;    /* != 0: ascend (the gradients are of +ELBO) */
-  int32_t reserved0;
+  uint32_t phases;     /* 0: the whole step; else a TGP_PHASE_* mask as in tgp_elbo_step_phases_f64 -- the update is applied
+                          with TGP_PHASE_BACKWARD (an engine that runs the phases apart, e.g. the two-stream ID_TGP step) */
 } tgp_adam_args;
 int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
                            const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,

@@ -160,8 +160,10 @@ int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double
                            const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
                            size_t workspace_bytes, const tgp_adam_args* adam, void* stream) {
   if (adam == nullptr) return -12;
-  return elbo_step_impl(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes,
-                        TGP_PHASE_PREPARE | TGP_PHASE_ROWS | TGP_PHASE_BACKWARD, adam, stream);
+  const uint32_t all = TGP_PHASE_PREPARE | TGP_PHASE_ROWS | TGP_PHASE_BACKWARD;
+  const uint32_t phases = adam->phases != 0 ? (adam->phases & all) : all;
+  return elbo_step_impl(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes, phases,
+                        (phases & TGP_PHASE_BACKWARD) ? adam : nullptr, stream);
 }
 
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,

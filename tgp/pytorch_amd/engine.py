@@ -163,7 +163,10 @@ class ElboEngine:
         self.ad = L.TgpAdamArgs()
         self.ad.params, self.ad.grads = L.ptr(fp.data), L.ptr(fp.grad)
         self.ad.exp_avg, self.ad.exp_avg_sq = L.ptr(fp.exp_avg), L.ptr(fp.exp_avg_sq)
-        self.ad.n, self.ad.step_dev, self.ad.maximize = fp.n, L.ptr(self.step_dev), 1
+        # (with per-row networks the flat buffer's tail is their weights: a group of its own -- weight decay, second stream;
+        #  the call then updates the prefix only, from the rotated unit's backward phase)
+        self.ad.n = fp.offsets["nn"] if self.mlp is not None else fp.n
+        self.ad.step_dev, self.ad.maximize = L.ptr(self.step_dev), 1
         self._side = None
         self.pipeline_steps = True      # ID_TGP, one rank: capture the rotated unit (see capture())
         self._out = None                # redirected scalar output while the unrolled graph is being captured
@@ -182,10 +185,12 @@ class ElboEngine:
         L.check(rc, "tgp_elbo_step_phases_f64")
         self._warm = True
 
-    def step_adam(self):
-        """forward_backward() + adam() as one call (fused_adam engines): same kernels' arithmetic, same results."""
+    def step_adam(self, phases=0):
+        """forward_backward() + adam() as one call (fused_adam engines): same kernels' arithmetic, same results.
+        `phases` != 0: only those phases (the update rides in the backward phase)."""
         out = self.fp.out if self._out is None else self._out
         self.ad.lr, self.ad.beta1, self.ad.beta2, self.ad.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        self.ad.phases = phases
         rc = self.lib.tgp_elbo_step_adam_f64(self.md, L.ptr(self.X), L.ptr(self.Y), L.ptr(self.rowp), L.ptr(out), self.gs,
                                              None, None, L.ptr(self.status), L.ptr(self.ws), self.ws.numel() * 8, self.ad,
                                              L.stream_ptr())
@@ -301,8 +306,11 @@ class ElboEngine:
                 # chain found every CU taken (5 -> 12 us; the whole step 172 -> 150 us with this order).
                 forked = torch.cuda.Event()
                 forked.record(main)
-                self.elbo(4)
-                self._adam_segment(0, n_plain, 0.0, self.step_dev)
+                if os.environ.get("TGP_FUSED_ADAM", "1") != "0":
+                    self.step_adam(4)            # M x M adjoint + gradient assembly + Adam on the GP / flow parameters
+                else:
+                    self.elbo(4)
+                    self._adam_segment(0, n_plain, 0.0, self.step_dev)
                 self.elbo(1)
                 side.wait_event(forked)
                 with torch.cuda.stream(side):

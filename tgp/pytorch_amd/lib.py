@@ -39,7 +39,7 @@ class TgpGrads(C.Structure):
 class TgpAdamArgs(C.Structure):
     _fields_ = [("params", _dp), ("grads", _dp), ("exp_avg", _dp), ("exp_avg_sq", _dp), ("n", C.c_int64), ("lr", C.c_double),
                 ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("step_dev", _dp), ("maximize", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("phases", C.c_uint32)]
 
 
 class TgpMlp(C.Structure):
