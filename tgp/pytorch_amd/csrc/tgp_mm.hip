@@ -34,9 +34,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   const int r = lane & 15, q = lane >> 4;
   const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, MT = p.MT;
 
-  if (blockIdx.x >= 2) {
+  if (blockIdx.x >= 3) {
     // ---------------- tile blocks: Lq, Lq^T, K_MM copies + S = Lq Lq^T (sparse_MF_SP.py:316,344-346) ------------
-    const int t = blockIdx.x - 2, ti = t / MT, tj = t % MT;
+    const int t = blockIdx.x - 3, ti = t / MT, tj = t % MT;
     if (tid < 256) {
       const int rr = tid >> 4, cc = tid & 15, row = ti * 16 + rr, col = tj * 16 + cc;
       double lq = 0.0, k = 0.0;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     return;
   }
 
-  if (blockIdx.x == 1) {
+  if (blockIdx.x == 2) {
     // ---------------- transforms, padded copies, flow parameter transforms, KL, header ---------------------------
     __shared__ double red1[16];
     double* hdr = ws + p.hdr;
@@ -130,7 +130,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     return;
   }
 
-  // ---------------- block 0: blocked Cholesky (torch.cholesky, dsp/utils.py:239) + inverse ------------------------
+  // ---------------- blocks 0 and 1: blocked Cholesky (torch.cholesky, dsp/utils.py:239) + inverse -------------------
+  // TWO workgroups on two CUs run the same factorisation redundantly (same arithmetic, bit for bit, nothing exchanged)
+  // and share what it leaves behind: block b forms and stores the tile COLUMNS c = b (mod 2) of J = L^-1 (a tile of J
+  // needs only tiles of its own column) and of L.  The task windows, not the chain, bound this launch (the four SIMDs of
+  // one CU saturated by instruction issue): a second CU takes 40 % of a window's work at the price of nothing but a CU
+  // that was idle.
+  const int cb = (int)blockIdx.x;   // 0 or 1: this block's column parity
   // Round-3 schedule: RIGHT-looking, one 16-column PANEL factorisation per block column (potrf_panel16: the diagonal
   // tile and every row below it leave one register pass of one wave -- no inverse of the diagonal tile, no triangular
   // solve, no panel product on the critical chain), everything GEMM-shaped on the other waves:
@@ -361,8 +367,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         //   tile (i, j+1) -= block column j-1                                      i = j+1 .. MT-1
         //   write-out of L row j-1
         const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
-        const int nf = j == 0 ? n1 + n2 : n2, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0;
-        const int ns = j >= 1 ? n1 : 0, nwl = j;
+        // (tile columns of this block's parity: c = 2 t + cb below `n` -> (n + 1 - cb) / 2 of them)
+        const int nf = j == 0 ? n1 + n2 : n2, ni = j >= 1 ? (j - cb) / 2 : 0, nwj = j >= 2 ? (j - cb) / 2 : 0;
+        const int ns = j >= 1 ? n1 : 0, nwl = (j + 1 - cb) / 2;
         const int ntask = nf + ni + nwj + ns + nwl;
         for (;;) {
           int t = 0;
@@ -375,21 +382,22 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
             continue;
           }
           t -= nf;
-          if (t < ni) { inv_tile(j - 1, t); continue; }
+          if (t < ni) { inv_tile(j - 1, 2 * t + cb); continue; }
           t -= ni;
-          if (t < nwj) { write_J(j - 2, t); continue; }
+          if (t < nwj) { write_J(j - 2, 2 * t + cb); continue; }
           t -= nwj;
           if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
           t -= ns;
-          write_L(j - 1, t);
+          write_L(j - 1, 2 * t + cb);
         }
 #ifdef TGP_STAMPS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (j == 0) PSTAMP(7); else PSTAMP(8);
 #endif
       }
-      tbase += (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? j - 1 : 0) +
-               (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j + (NW - 1 - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
+      tbase += (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? (j - cb) / 2 : 0) +
+               (j >= 2 ? (j - cb) / 2 : 0) + (j >= 1 ? MT - 1 - j : 0) + (j + 1 - cb) / 2 +
+               (NW - 1 - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
       PREP_BARRIER();
       PSTAMP(4);
       if (did_diag) {
@@ -417,15 +425,16 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   }
   // ---- tail: J row MT-1 (Dinv_{MT-1} came with the last window), the last write-outs ----
   {
-    const int ni = MT - 1, nwl = MT, nwj = MT >= 2 ? MT - 1 : 0;
+    // (tile columns c = 2 t + cb: of the n columns [0, n) this block owns (n + 1 - cb) / 2)
+    const int ni = (MT - cb) / 2, nwl = (MT + 1 - cb) / 2, nwj = MT >= 2 ? (MT - cb) / 2 : 0;
     const int ntask = ni + nwl + nwj;
     for (int t = wave; t < ntask; t += NW) {
-      if (t < ni) inv_tile(MT - 1, t);
-      else if (t < ni + nwl) write_L(MT - 1, t - ni);
-      else write_J(MT - 2, t - (ni + nwl));
+      if (t < ni) inv_tile(MT - 1, 2 * t + cb);
+      else if (t < ni + nwl) write_L(MT - 1, 2 * (t - ni) + cb);
+      else write_J(MT - 2, 2 * (t - (ni + nwl)) + cb);
     }
     PREP_BARRIER();
-    for (int t = wave; t < MT; t += NW) write_J(MT - 1, t);
+    for (int t = wave; t < (MT + 1 - cb) / 2; t += NW) write_J(MT - 1, 2 * t + cb);
   }
   PSTAMP(9);
 #ifdef TGP_STAMPS
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     ws[p.hdr + H_PSTAMP + 11 + 2 * wave] = tph[8];      // ... summed over j >= 1 (panel / diagonal-tile / task waves alike)
   }
 #endif
-  if (tid == 0) {
+  if (tid == 0 && cb == 0) {   // (block 1 arrives at the same three words)
     status[0] = s_info;
     status[1] = s_nan;
     status[2] = s_info == 0 ? attempt : 0;
@@ -1115,7 +1124,7 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
   const size_t lds = prep_a_lds_bytes(p);
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(k_prep_a), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(k_prep_a, dim3(2 + p.MT * p.MT), dim3(PREP_THREADS), lds, st, p, md, fp, ws, status);
+  hipLaunchKernelGGL(k_prep_a, dim3(3 + p.MT * p.MT), dim3(PREP_THREADS), lds, st, p, md, fp, ws, status);
   LAUNCH_CHECK();
   return 0;
 }
