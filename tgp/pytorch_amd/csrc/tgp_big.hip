@@ -262,7 +262,9 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
       long small8 = (rows2 * per_row2 + 255) / 256;
       const long longest2 = 2 * (tri ? nj2 : 2 * kb);
       if (small8 < longest2) small8 = longest2;
-      if (small8 * 10 < big * 8 * 7) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
+      static int force64 = -1;
+      if (force64 < 0) { const char* e = getenv("TGP_GEMM64"); force64 = e ? atoi(e) : 0; }
+      if (force64 == 1 || (force64 == 0 && small8 * 10 < big * 8 * 7)) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
     }
   }
   const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
@@ -1109,15 +1111,35 @@ __global__ __launch_bounds__(256) void k_big_sum_slabs(const double* __restrict_
   dst[e] = s;
 }
 
-// C = beta C + sum of `ns` compact slabs [m][n]  (split-K reduction of an M x M product, fixed order)
+// C = beta C + sum of `ns` compact slabs [m][n]  (split-K reduction of an M x M product, fixed order), with the elementwise
+// step that follows the product in the backward chain applied on the way out (a launch and a pass over M x M less each):
+//   OP 1: C = -tril(u v^T + x)                (Lbar, k_big_lbar)
+//   OP 2: C = Phi(x) + Phi(x)^T               (k_big_phisym: the lower triangle mirrored; strictly-upper sums are not formed)
+template <int OP>
 __global__ __launch_bounds__(256) void k_big_sum_slabs2d(const double* __restrict__ src, int ns, int m, int n, double* __restrict__ C,
-                                                          int ldc, double beta) {
+                                                          int ldc, double beta, const double* __restrict__ u,
+                                                          const double* __restrict__ v) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, len = (size_t)m * n;
   if (e >= len) return;
+  const int i = (int)(e / n), j = (int)(e % n);
+  if (OP == 2 && j > i) return;
   double s = 0.0;
-  for (int z = 0; z < ns; ++z) s += src[(size_t)z * len + e];
-  double* c = C + (size_t)(e / n) * ldc + e % n;
-  *c = beta == 0.0 ? s : s + beta * *c;
+  for (int z0 = 0; z0 < ns; z0 += 8) {   // up to eight slabs requested together, added in slab order
+    double x[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) x[z] = z0 + z < ns ? src[(size_t)(z0 + z) * len + e] : 0.0;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) s += x[z];
+  }
+  double* c = C + (size_t)i * ldc + j;
+  if (OP == 1) {
+    *c = j <= i ? -(u[i] * v[j] + s) : 0.0;
+  } else if (OP == 2) {
+    *c = s;
+    if (j < i) C[(size_t)j * ldc + i] = s;
+  } else {
+    *c = beta == 0.0 ? s : s + beta * *c;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1154,45 +1176,94 @@ __global__ __launch_bounds__(256) void k_big_phisym(BigPlan p, double* __restric
   ws[p.Q + (size_t)j * p.MP + i] = ws[p.Q + e];
 }
 
-// parameter gradients and the scalars (single block)
-__global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_grads g, double* __restrict__ out,
-                                                    double* __restrict__ ws) {
-  __shared__ double red[17][256];
-  const int tid = threadIdx.x, M = p.M, D = p.D, DP = p.DP;
-  const double* hdr = ws + p.hdr;
-  const double s2 = hdr[H_S2];
-  double acc[17];
+// parameter gradients and the scalars (single block).  ONE workgroup on a cold instruction cache: its time is the number of
+// memory round trips on its critical path (operands written by other XCDs a moment ago) plus the code it has to fetch, so
+// the kernel is written for few of both -- one thread per (inducing point, dimension) element, four points in flight per
+// thread, a small loop body instead of the 16-way unrolled per-dimension code of the first version (2 600 instructions
+// fetched once each by a single workgroup: 39-50 us); the scalar partial sums are lane-parallel (a serial loop of global
+// loads is a round trip per term), the column sums go through a wave butterfly + one LDS hop.
+#define FINAL_THREADS 1024
+__global__ __launch_bounds__(FINAL_THREADS) void k_big_final(BigPlan p, tgp_model md, tgp_grads g, double* __restrict__ out,
+                                                              double* __restrict__ ws) {
+  constexpr int NWV = FINAL_THREADS / 64;
+  __shared__ double red[NWV][17];
+  __shared__ double sc[4];
+  static_assert(BIG_NKL <= 64, "one wave sums the KL partials");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, M = p.M, D = p.D, DP = p.DP;
+  const int sh = DP == 4 ? 2 : (DP == 8 ? 3 : 4), d = tid & (DP - 1), jl = tid >> sh, rows = FINAL_THREADS >> sh;
+  const bool vd = d < D;
+  const double* __restrict__ hdr = ws + p.hdr;
+  const double* __restrict__ Tm = ws + p.T;
+  const double* __restrict__ Um = ws + p.U;
+  const double* __restrict__ Zs = ws + p.Zs;
+  const double* __restrict__ lik = ws + p.likslot;
+  const double* __restrict__ svp = ws + p.sv;
+  const bool rbf = p.kernel == TGP_KERNEL_SCALE_RBF;
+  // ---- requests: scalars, this wave's partials ----
+  const double s2 = hdr[H_S2], sig_os = hdr[H_SIG_OS], svb = ws[p.svb];
+  const double ilsd = ws[p.ils + (vd ? d : 0)];
+  const double rawls = md.raw_ls[tid < D ? tid : 0];
+  double part = 0.0;
+  if (wave == 1) part = lane < BIG_NKL ? ws[p.klpart + lane] : 0.0;
+  if (wave == 2 || wave == 3)
+    for (int c = lane; c < p.nchunks; c += 64) part += lik[(size_t)c * p.LS + (wave - 2)];
+  double a = 0.0, aos = 0.0;
+  for (int j0 = 0; j0 < M; j0 += 4 * rows) {
+    double t1[4], t2[4], R[4], z[4], t0[4], cs[4], sv[4], mj[4], tk[4];
 #pragma unroll
-  for (int d = 0; d < 17; ++d) acc[d] = 0.0;
-  for (int j = tid; j < M; j += 256) {
-    const double* Tj = ws + p.T + (size_t)j * BIG_XW;
-    const double* Uj = ws + p.U + (size_t)j * BIG_XW;
-    const double t0 = Tj[2 * DP], cs = Uj[2 * DP];
-    // d/d outputscale needs sum (Kbar o K); for the RBF K_g = K and it is the same ones-column
-    acc[16] += p.kernel != TGP_KERNEL_SCALE_RBF ? ws[p.TK + (size_t)j * BIG_XW + 2 * DP] + ws[p.UK + (size_t)j * BIG_XW + 2 * DP]
-                                                : cs + t0;
-    for (int d = 0; d < D; ++d) {
-      const double zj = ws[p.Zs + (size_t)j * DP + d];
-      const double t1 = Tj[d], t2 = Tj[DP + d], R = Uj[d];
-      g.Z[(size_t)j * D + d] = (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d];
-      acc[d] += (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * rows + jl, jc = j < M ? j : M - 1;
+      const double* __restrict__ Tj = Tm + (size_t)jc * BIG_XW;
+      const double* __restrict__ Uj = Um + (size_t)jc * BIG_XW;
+      const int dc = vd ? d : 0;
+      t1[u] = Tj[dc]; t2[u] = Tj[DP + dc]; R[u] = Uj[dc]; z[u] = Zs[(size_t)jc * DP + dc];
+      t0[u] = Tj[2 * DP]; cs[u] = Uj[2 * DP];
+      sv[u] = svp[jc]; mj[u] = md.m[jc];
+      // d/d outputscale needs sum (Kbar o K); for the RBF K_g = K and it is the same ones-column
+      tk[u] = rbf ? 0.0 : ws[p.TK + (size_t)jc * BIG_XW + 2 * DP] + ws[p.UK + (size_t)jc * BIG_XW + 2 * DP];
     }
-    g.m[j] = ws[p.sv + j] - md.kl_scale * md.m[j];
-  }
 #pragma unroll
-  for (int d = 0; d < 17; ++d) red[d][tid] = acc[d];
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * rows + jl;
+      const bool vj = j < M;
+      const double gz = (t1[u] - z[u] * t0[u] + 2.0 * (R[u] - z[u] * cs[u])) * ilsd;
+      const double c = (t2[u] - 2.0 * z[u] * t1[u] + z[u] * z[u] * t0[u]) + 2.0 * z[u] * (z[u] * cs[u] - R[u]);
+      if (vj && vd) g.Z[(size_t)j * D + d] = gz;
+      a += (vj && vd) ? c : 0.0;
+      if (vj && d == 0) {
+        aos += rbf ? cs[u] + t0[u] : tk[u];
+        g.m[j] = sv[u] - md.kl_scale * mj[u];
+      }
+    }
+  }
+  if (g.theta != nullptr)
+    for (int i = tid; i < p.P; i += FINAL_THREADS) {
+      double s = 0.0;
+      for (int c0 = 0; c0 < p.nchunks; c0 += 8) {   // eight chunks' slots in flight
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = c0 + u < p.nchunks ? lik[(size_t)(c0 + u) * p.LS + 2 + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += x[u];
+      }
+      g.theta[i] = s;
+    }
+  part = wave_sum(part);
+  if (lane == 0 && wave < 4) sc[wave] = part;
+  for (int o = DP; o < 64; o <<= 1) a += __shfl_xor(a, o);   // over the lanes of this wave that hold dimension d
+  aos = wave_sum(aos);
+  if (lane < DP) red[wave][lane] = a;
+  if (lane == 0) red[wave][16] = aos;
   __syncthreads();
   if (tid < 17 && (tid < D || tid == 16)) {
     double s = 0.0;
-    for (int i = 0; i < 256; ++i) s += red[tid][i];
+    for (int w = 0; w < NWV; ++w) s += red[w][tid];
     if (tid < D) {
-      g.raw_ls[tid] = s * ws[p.ils + tid] * sigmoid_d(md.raw_ls[tid]);
+      g.raw_ls[tid] = s * ilsd * sigmoid_d(rawls);
     } else {
-      double ell = 0.0, etab = 0.0, kls = 0.0;
-      for (int c = 0; c < p.nchunks; ++c) { ell += ws[p.likslot + (size_t)c * p.LS]; etab += ws[p.likslot + (size_t)c * p.LS + 1]; }
-      for (int b = 0; b < BIG_NKL; ++b) kls += ws[p.klpart + b];
+      const double kls = sc[1], ell = sc[2], etab = sc[3];
       const double kl = 0.5 * (kls - (double)M);
-      g.raw_os[0] = (ws[p.svb] + s / s2) * hdr[H_SIG_OS];
+      g.raw_os[0] = (svb + s / s2) * sig_os;
       g.log_var_noise[0] = etab;
       out[0] = ell - kl;
       out[1] = ell;
@@ -1200,12 +1271,6 @@ __global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_
       out[3] = 0.0;
     }
   }
-  if (g.theta != nullptr)
-    for (int i = tid; i < p.P; i += 256) {
-      double s = 0.0;
-      for (int c = 0; c < p.nchunks; ++c) s += ws[p.likslot + (size_t)c * p.LS + 2 + i];
-      g.theta[i] = s;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1219,7 +1284,11 @@ __global__ __launch_bounds__(256) void k_big_final(BigPlan p, tgp_model md, tgp_
 // An M x M product has at most (MP/128)^2 <= 64 output tiles at M = 1000 -- a quarter of the CUs, each running the
 // whole k loop.  Split k so that about 256 workgroups run, partial sums into compact slabs, then one fixed-order
 // reduction into C (150 us -> ~50 us per product at MP = 1024).
-static int gemm_mm_on(bool ta, bool tb, GemmArgs g, double* scratch, size_t cap, hipStream_t st) {
+// `op`: elementwise step fused into the slab reduction (see k_big_sum_slabs2d); returns 0 with *fused = false when the
+// product was not split (the caller then runs the stand-alone elementwise kernel)
+static int gemm_mm_on(bool ta, bool tb, GemmArgs g, double* scratch, size_t cap, hipStream_t st, int op = 0,
+                      const double* u = nullptr, const double* v = nullptr, bool* fused = nullptr) {
+  if (fused) *fused = false;
   const int tiles = (g.m / 128) * (g.n / 128);
   int ks = 256 / (tiles > 0 ? tiles : 1);
   if (ks > 8) ks = 8;
@@ -1231,13 +1300,23 @@ static int gemm_mm_on(bool ta, bool tb, GemmArgs g, double* scratch, size_t cap,
   const double beta = g.beta;
   g.C = scratch; g.ldc = g.n; g.beta = 0.0; g.ksplit = ks; g.cz = slab;
   if (int rc = launch_gemm(ta, tb, g, st)) return rc;
-  hipLaunchKernelGGL(k_big_sum_slabs2d, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, scratch, ks, g.m, g.n, C, ldc, beta);
+  const dim3 grid((unsigned)((slab + 255) / 256));
+  if (op == 1 && beta == 0.0) {
+    hipLaunchKernelGGL(k_big_sum_slabs2d<1>, grid, dim3(256), 0, st, scratch, ks, g.m, g.n, C, ldc, beta, u, v);
+    if (fused) *fused = true;
+  } else if (op == 2 && beta == 0.0 && g.m == g.n) {
+    hipLaunchKernelGGL(k_big_sum_slabs2d<2>, grid, dim3(256), 0, st, scratch, ks, g.m, g.n, C, ldc, beta, u, v);
+    if (fused) *fused = true;
+  } else {
+    hipLaunchKernelGGL(k_big_sum_slabs2d<0>, grid, dim3(256), 0, st, scratch, ks, g.m, g.n, C, ldc, beta, u, v);
+  }
   LAUNCH_CHECK();
   return 0;
 }
-static int gemm_mm(bool ta, bool tb, const GemmArgs& g, const BigPlan& p, double* ws, hipStream_t st) {
+static int gemm_mm(bool ta, bool tb, const GemmArgs& g, const BigPlan& p, double* ws, hipStream_t st, int op = 0,
+                   const double* u = nullptr, const double* v = nullptr, bool* fused = nullptr) {
   const size_t cap = (size_t)8 * ((p.MP / 128) <= 4 ? (size_t)p.MP * p.MP : (size_t)p.MP * p.MP / 2);
-  return gemm_mm_on(ta, tb, g, ws + p.Sk, cap, st);
+  return gemm_mm_on(ta, tb, g, ws + p.Sk, cap, st, op, u, v, fused);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1390,8 +1469,13 @@ static int big_join(hipStream_t st) {
   BigFork& fk = big_fork();
   return fk.after(1, fk.aux, st);
 }
+static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, double* ws, bool train, hipStream_t st);
+
+// `X0` (training step that runs prepare and rows in one call): the first chunk's K' tiles need nothing of the
+// factorisation, only the scaled inducing points -- they are generated on the auxiliary stream under the first diagonal
+// blocks (one workgroup factorises there, 255 CUs idle) instead of in front of the first row product.
 static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_t* status, bool train, hipStream_t st,
-                       bool defer_hw = false) {
+                       bool defer_hw = false, const double* X0 = nullptr, int nrows0 = 0) {
   const int MP = p.MP;
   const size_t mm = (size_t)MP * MP;
   BigFork& fk = big_fork();
@@ -1416,6 +1500,8 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
       return rc;
     hipLaunchKernelGGL(k_big_sub_eye, dim3(MP / 256 + 1), dim3(256), 0, sx, ws + p.S_, MP);
     LAUNCH_CHECK();
+    if (X0 != nullptr)
+      if (int rc = big_chunk_kernel(p, X0, nrows0, ws, true, sx)) return rc;
   }
   if (int rc = big_factorise(p, ws, status, true, st)) return rc;
   if (int rc = fk.after(1, sx, st)) return rc;   // join
@@ -1439,9 +1525,8 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   return 0;
 }
 
-// forward part of one chunk: Kc, A, B, moments
-static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, double* ws, double* mu, double* v, bool train,
-                             hipStream_t st) {
+// K' tiles of one chunk (and, for a training step, its augmented coordinates)
+static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, double* ws, bool train, hipStream_t st) {
   const int MP = p.MP, NC = p.NC;
   if (train) {
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
@@ -1449,6 +1534,15 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
   }
   hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
   LAUNCH_CHECK();
+  return 0;
+}
+
+// forward part of one chunk: Kc (unless `have_k`: made during the factorisation), A, B, moments
+static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, double* ws, double* mu, double* v, bool train,
+                             hipStream_t st, bool have_k = false) {
+  const int MP = p.MP, NC = p.NC;
+  if (!have_k)
+    if (int rc = big_chunk_kernel(p, Xc, nrows, ws, train, st)) return rc;
   // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD
   GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
   a1.xcd = 1;
@@ -1484,8 +1578,11 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
   const int MP = p.MP, NC = p.NC;
   const size_t mm = (size_t)MP * MP;
   const bool defer_hw = (phases & TGP_PHASE_PREPARE) && (phases & TGP_PHASE_ROWS) && (phases & TGP_PHASE_BACKWARD);
-  if (phases & TGP_PHASE_PREPARE)
-    if (int rc = big_prepare(p, md, ws, status, true, st, defer_hw)) return rc;
+  const bool early_k = (phases & TGP_PHASE_PREPARE) && (phases & TGP_PHASE_ROWS);
+  if (phases & TGP_PHASE_PREPARE) {
+    const int n0 = p.N < NC ? p.N : NC;
+    if (int rc = big_prepare(p, md, ws, status, true, st, defer_hw, early_k ? X : nullptr, n0)) return rc;
+  }
   if (phases & TGP_PHASE_ROWS) {
     // Chunk pipeline.  With a second set of chunk buffers the forward half of chunk c+1 (K' tiles, A', B', moments,
     // likelihood -- a third of it bandwidth/latency-bound kernels that leave the matrix cores idle) runs on a helper
@@ -1504,7 +1601,7 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       const BigPlan pc = plan_parity(p, par);
       hipStream_t sf = aux ? aux->fwd : st;
       if (aux && ci >= 2) HIPCK(hipStreamWaitEvent(sf, aux->eB[par], 0));  // chunk ci-2 is done with these buffers
-      if (int rc = big_chunk_forward(pc, X + c0 * p.D, nrows, ws, ws + p.mu + c0, ws + p.v + c0, true, sf)) return rc;
+      if (int rc = big_chunk_forward(pc, X + c0 * p.D, nrows, ws, ws + p.mu + c0, ws + p.v + c0, true, sf, early_k && ci == 0)) return rc;
       // likelihood of the chunk: partial (scale*ELL, scale*eta_bar, theta_bar) into this chunk's slot
       double* slot = ws + p.likslot + (size_t)ci * p.LS;
       if (md.lik == TGP_LIK_FLOW) {
@@ -1582,13 +1679,22 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       LAUNCH_CHECK();
     }
     // Lbar = -tril(w s^T + 2 H' G)
-    GEMM_MM(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0));
-    hipLaunchKernelGGL(k_big_lbar, dim3(gmm), dim3(256), 0, st, p, ws);
-    LAUNCH_CHECK();
+    bool fused = false;
+    if (int rc = gemm_mm(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0), p, ws, st, 1,
+                         ws + p.w, ws + p.sv, &fused))
+      return rc;
+    if (!fused) {
+      hipLaunchKernelGGL(k_big_lbar, dim3(gmm), dim3(256), 0, st, p, ws);
+      LAUNCH_CHECK();
+    }
     // Q = Phi(L^T Lbar) + Phi(.)^T
-    GEMM_MM(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER));
-    hipLaunchKernelGGL(k_big_phisym, dim3(gmm), dim3(256), 0, st, p, ws);
-    LAUNCH_CHECK();
+    if (int rc = gemm_mm(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER),
+                         p, ws, st, 2, nullptr, nullptr, &fused))
+      return rc;
+    if (!fused) {
+      hipLaunchKernelGGL(k_big_phisym, dim3(gmm), dim3(256), 0, st, p, ws);
+      LAUNCH_CHECK();
+    }
     // Kbar_MM = 1/2 J^T Q J
     GEMM_MM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
     GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
@@ -1610,7 +1716,7 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                        (size_t)MP * BIG_XW, ws + p.U);
     LAUNCH_CHECK();
     if (int rc = big_join(st)) return rc;   // dLam
-    hipLaunchKernelGGL(k_big_final, dim3(1), dim3(256), 0, st, p, md, g, out, ws);
+    hipLaunchKernelGGL(k_big_final, dim3(1), dim3(FINAL_THREADS), 0, st, p, md, g, out, ws);
     LAUNCH_CHECK();
   }
   return 0;

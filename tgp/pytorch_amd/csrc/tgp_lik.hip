@@ -18,12 +18,13 @@ namespace tgp {
 // k_ell_flow: lanes per data row.  4 by default (64 rows per workgroup); 16 for small problems (16 rows per workgroup): a
 // rank's 1 250 rows of an 8-GPU minibatch were 20 workgroups, each lane walking 8 quadrature nodes through 30 tanh steps
 // and back -- 91 us of one dependent chain, whatever N; with 16 lanes per row a lane has 2 nodes and 79 workgroups run.
-static int ell_flow_lpr(int N) { return N <= 4096 ? 16 : 4; }
+#define ELL_LPR16_MAXN 12288
+static int ell_flow_lpr(int N) { return N <= ELL_LPR16_MAXN ? 16 : 4; }
 
 // Sized for ANY call with at most N rows: a caller that sizes once for its largest chunk (the general-M path) may
 // launch a ragged last chunk that falls into the 16-lanes-per-row mode and then has MORE workgroups than the largest one.
 size_t lik_workspace_doubles(int N, int P, int RP) {
-  const size_t nb16 = (size_t)((N < 4096 ? N : 4096) + 15) / 16, nb64 = (size_t)(N + 63) / 64;
+  const size_t nb16 = (size_t)((N < ELL_LPR16_MAXN ? N : ELL_LPR16_MAXN) + 15) / 16, nb64 = (size_t)(N + 63) / 64;
   const size_t nb = (nb16 > nb64 ? nb16 : nb64) + 1;  // k_ell_flow: one partial per workgroup
   return nb * (size_t)(2 + P) + 2 * (size_t)P + 64;
 }
