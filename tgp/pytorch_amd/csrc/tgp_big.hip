@@ -262,9 +262,7 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
       long small8 = (rows2 * per_row2 + 255) / 256;
       const long longest2 = 2 * (tri ? nj2 : 2 * kb);
       if (small8 < longest2) small8 = longest2;
-      static int force64 = -1;
-      if (force64 < 0) { const char* e = getenv("TGP_GEMM64"); force64 = e ? atoi(e) : 0; }
-      if (force64 == 1 || (force64 == 0 && small8 * 10 < big * 8 * 7)) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
+      if (small8 * 10 < big * 8 * 7) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
     }
   }
   const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
@@ -1621,6 +1619,9 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
         HIPCK(hipStreamWaitEvent(st, aux->eF[par], 0));
       }
       // ---- backward half, caller's stream ----
+      // (the G SYRK and s = A'^T mubar need only A', vbar, mubar and could run beside the chain Abar' -> Kbar' -> T on the
+      //  fork stream: measured, the two branches take exactly the sum of their solo times -- the launches are bound by
+      //  matrix throughput, not by idle CUs -- so they stay in line)
       // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T
       GemmArgs a3 = gemm_args(ws + pc.B, MP, ws + p.Lq, MP, ws + pc.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
       a3.add = ws + pc.A; a3.ldadd = MP; a3.gamma = -2.0;

@@ -540,6 +540,15 @@ __device__ __forceinline__ void lds_acc(double* p, double v) {
 // asinh exactly as the reference writes it (flow.py:904-905)
 __device__ __forceinline__ double asinh_ref(double f) { return log(f + sqrt(f * f + 1.0)); }
 
+// Parameter `poff` of a block: the shared value in LDS, or this row's value in global memory (`pr`).  Written as two
+// loads in two address spaces on purpose: `pr ? rp[poff] : F.tp[poff]` became a select of the two POINTERS followed by one
+// FLAT load -- LDS parameters fetched through the flat path, counted against vmcnt and lgkmcnt at once.
+__device__ __forceinline__ double flow_param(const FlowDev& F, const double* rp, int poff, bool pr) {
+  double a = F.tp[poff];
+  if (pr) a = *(const double __attribute__((address_space(1)))*)(rp + poff);
+  return a;
+}
+
 // Forward through all blocks (evaluation / prediction).  If dG != nullptr it receives dG/df.
 __device__ inline double flow_forward(const FlowDev& F, double f, const double* __restrict__ rp, double* stack,
                                       int sstride, double* dG) {
@@ -549,14 +558,14 @@ __device__ inline double flow_forward(const FlowDev& F, double f, const double* 
     const bool pr = flags & TGP_FLAG_PER_ROW;
     if (stack) stack[b * sstride] = f;
     if (kind == TGP_FLOW_AFFINE) {
-      double a = pr ? rp[poff] : F.tp[poff];
+      double a = flow_param(F, rp, poff, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
-      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double bb = flow_param(F, rp, poff + 1, pr);
       f = a * f + bb;
       der *= a;
     } else if (kind == TGP_FLOW_SAL) {
-      const double a = pr ? rp[poff] : F.tp[poff];
-      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double a = flow_param(F, rp, poff, pr);
+      double bb = flow_param(F, rp, poff + 1, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
       const double t = bb * asinh_ref(f) - a;
       double g = sinh(t);
@@ -595,9 +604,9 @@ __device__ inline void flow_forward_n(const FlowDev& F, double (&f)[NB], const d
     const bool pr = flags & TGP_FLAG_PER_ROW;
     if (kind == TGP_FLOW_AFFINE) {
       TGP_EACH(u, NB) {
-        double a = pr ? rp[u][poff] : F.tp[poff];
+        double a = flow_param(F, rp[u], poff, pr);
         if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
-        const double bb = pr ? rp[u][poff + 1] : F.tp[poff + 1];
+        const double bb = flow_param(F, rp[u], poff + 1, pr);
         f[u] = a * f[u] + bb;
         if (DER) der[u] *= a;
       }
@@ -605,8 +614,8 @@ __device__ inline void flow_forward_n(const FlowDev& F, double (&f)[NB], const d
       const bool addf = flags & TGP_FLAG_ADD_F0;
       double a[NB], bb[NB], q1[NB], isf[NB], sf[NB], uu[NB], e[NB], ei[NB], t[NB];
       TGP_EACH(u, NB) {
-        a[u] = pr ? rp[u][poff] : F.tp[poff];
-        bb[u] = pr ? rp[u][poff + 1] : F.tp[poff + 1];
+        a[u] = flow_param(F, rp[u], poff, pr);
+        bb[u] = flow_param(F, rp[u], poff + 1, pr);
         if (pr && (flags & TGP_FLAG_RESTRICT)) bb[u] = softplus_d(bb[u]);
       }
       TGP_EACH(u, NB) q1[u] = f[u] * f[u] + 1.0;
@@ -678,9 +687,9 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
     nx = flow_blk(F.prog, b + 1 < F.nblk ? b + 1 : b);
     const bool pr = flags & TGP_FLAG_PER_ROW;
     if (kind == TGP_FLOW_AFFINE) {
-      double a = pr ? rp[poff] : F.tp[poff];
+      double a = flow_param(F, rp, poff, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
-      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double bb = flow_param(F, rp, poff + 1, pr);
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         stack[(sl * NB + u) * sstride] = f[u];
@@ -688,8 +697,8 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       }
       sl += 1;
     } else if (kind == TGP_FLOW_SAL) {
-      const double a = pr ? rp[poff] : F.tp[poff];
-      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double a = flow_param(F, rp, poff, pr);
+      double bb = flow_param(F, rp, poff + 1, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
       const bool addf = flags & TGP_FLAG_ADD_F0;
       // sqrt(f^2+1) and its reciprocal from one v_rsq_f64 + Newton (1/sf is needed anyway); asinh keeps the
@@ -870,14 +879,14 @@ __device__ inline void flow_forward_ckpt(const FlowDev& F, double (&f)[NB], cons
 #pragma unroll
     for (int u = 0; u < NB; ++u) stack[(b * NB + u) * sstride] = f[u];
     if (kind == TGP_FLOW_AFFINE) {
-      double a = pr ? rp[poff] : F.tp[poff];
+      double a = flow_param(F, rp, poff, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) a = softplus_d(a);
-      const double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double bb = flow_param(F, rp, poff + 1, pr);
 #pragma unroll
       for (int u = 0; u < NB; ++u) f[u] = a * f[u] + bb;
     } else if (kind == TGP_FLOW_SAL) {
-      const double a = pr ? rp[poff] : F.tp[poff];
-      double bb = pr ? rp[poff + 1] : F.tp[poff + 1];
+      const double a = flow_param(F, rp, poff, pr);
+      double bb = flow_param(F, rp, poff + 1, pr);
       if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
       const bool addf = flags & TGP_FLAG_ADD_F0;
 #pragma unroll
@@ -940,8 +949,8 @@ __device__ inline void flow_backward_ckpt(const FlowDev& F, double (&c)[NB], con
         if (lane0) { accw[poff + 0] += pa; accw[poff + 1] += pb; }
       }
     } else if (kind == TGP_FLOW_SAL) {
-      const double a = pr ? rp[poff] : F.tp[poff];
-      double bb = pr ? rp[poff + 1] : F.tp[poff + 1], fb = pr ? 1.0 : F.tg[poff + 1];
+      const double a = flow_param(F, rp, poff, pr);
+      double bb = flow_param(F, rp, poff + 1, pr), fb = pr ? 1.0 : F.tg[poff + 1];
       if (pr && (flags & TGP_FLAG_RESTRICT)) { fb = sigmoid_d(bb); bb = softplus_d(bb); }
       const bool addf = flags & TGP_FLAG_ADD_F0;
       double pa = 0.0, pb = 0.0;

@@ -76,6 +76,18 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// Global-memory accesses of gemm_tile, with the address space spelled out.  The tile function re-reads its arguments from
+// the kernarg segment, so the operand pointers are plain (generic) pointers to the compiler and it emitted FLAT loads --
+// which count against lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` in front of an MFMA batch (meant for the
+// LDS fragment reads) also waited for the NEXT stage's operand loads, i.e. the global latency the double buffering is
+// there to hide was paid in every stage.  global_load / global_store only touch vmcnt.
+typedef const d2 __attribute__((address_space(1)))* gemm_gp2;
+typedef const double __attribute__((address_space(1)))* gemm_gp1;
+typedef double __attribute__((address_space(1)))* gemm_gpw;
+__device__ __forceinline__ d2 gemm_ld2(const double* p) { return *(gemm_gp2)(p); }
+__device__ __forceinline__ double gemm_ld1(const double* p) { return *(gemm_gp1)(p); }
+__device__ __forceinline__ void gemm_st1(double* p, double x) { *(gemm_gpw)(p) = x; }
+
 // One operand stage (16 k x 128 x) global -> registers -> LDS.  KMAJ: stored [k][x] in memory (coalesced 1 KB rows);
 // else stored [x][k] (128-byte row segments, 8 rows per wave load).  16-byte loads throughout.  Addresses are
 // (uniform base of the stage) + (per-thread 32-bit offset that never changes): one VGPR per operand, the rest SGPRs.
@@ -88,7 +100,7 @@ __device__ __forceinline__ void gemm_load(const double* __restrict__ G, int ld, 
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const double* __restrict__ b = KMAJ ? G + (size_t)(k0 + 4 * u) * ld + x0 : G + (size_t)(x0 + 32 * u) * ld + k0;
-    s[u] = *reinterpret_cast<const d2*>(b + voff);
+    s[u] = gemm_ld2(b + voff);
   }
 }
 // modifier values of the same stage (raw; multiplied in at LDS-store time so that the loads stay in flight
@@ -105,8 +117,8 @@ __device__ __forceinline__ void gemm_load_mod(const double* __restrict__ mul, co
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     if (ksc) {
-      if (KMAJ) { const double t = ksc[k0 + (tid >> 6) + 4 * u]; sk[u] = d2{t, t}; }
-      else sk[u] = *reinterpret_cast<const d2*>(ksc + k0 + 2 * (tid & 7));
+      if (KMAJ) { const double t = gemm_ld1(ksc + k0 + (tid >> 6) + 4 * u); sk[u] = d2{t, t}; }
+      else sk[u] = gemm_ld2(ksc + k0 + 2 * (tid & 7));
     } else {
       sk[u] = one;
     }
@@ -223,7 +235,7 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr];
+            gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r, g.alpha * acc[a][b][rr]);
     } else {
       const bool ha = g.add != nullptr;
       const double* __restrict__ E = ha ? g.add : C;
@@ -235,20 +247,20 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = i0 + wi + 16 * a + q + 4 * rr;
-          rs[a][rr] = g.row_scale ? g.row_scale[row] : 1.0;
-          rv[a][rr] = g.rowv ? g.rowv[row] : 0.0;
+          rs[a][rr] = g.row_scale ? gemm_ld1(g.row_scale + row) : 1.0;
+          rv[a][rr] = g.rowv ? gemm_ld1(g.rowv + row) : 0.0;
         }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int col = j0 + wj + 16 * b + r;
-        const double cs = g.col_scale ? g.col_scale[col] : 1.0;
-        const double cv = g.colv ? g.colv[col] : 0.0;
+        const double cs = g.col_scale ? gemm_ld1(g.col_scale + col) : 1.0;
+        const double cv = g.colv ? gemm_ld1(g.colv + col) : 0.0;
         double ein[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
-            ein[a][rr] = he ? E[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * lde + col] : 0.0;
+            ein[a][rr] = he ? gemm_ld1(E + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * lde + col) : 0.0;
         const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -256,7 +268,7 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
           for (int rr = 0; rr < 4; ++rr) {
             double x = g.alpha * acc[a][b][rr] + ca * ein[a][rr];
             x = x * cs * rs[a][rr] + rv[a][rr] * cv + cb * ein[a][rr];
-            C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + col] = x;
+            gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + col, x);
           }
       }
     }

@@ -1,6 +1,7 @@
 // standalone timing of tgp::k_gemm variants
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../tgp/pytorch_amd/csrc/tgp_gemm.hpp"
 using namespace tgp;
@@ -18,7 +19,7 @@ float runl(bool ta, bool tb, GemmArgs g, int reps) {
 template <bool TA, bool TB>
 float run(GemmArgs g, int reps) { return runl(TA, TB, g, reps); }
 
-int main() {
+int main(int argc, char** argv) {
   const int n = 4096;  // buffers: 4096^2 doubles = 16.7M >= 15744*1024
   double *A, *B, *C, *V;
   CK(hipMalloc(&A, (size_t)n * n * 8)); CK(hipMalloc(&B, (size_t)n * n * 8)); CK(hipMalloc(&C, (size_t)n * n * 8 * 2));
@@ -30,7 +31,7 @@ int main() {
   CK(hipMemcpy(V, h.data(), n * 8, hipMemcpyHostToDevice));
   {
     // pipeline shapes: NC x MP x MP triangular (n-major layout), SYRK and T
-    const int NC = 15744, MP = 1024;
+    const int NC = argc > 1 ? atoi(argv[1]) : 15744, MP = 1024;
     struct { const char* name; bool ta, tb; int tri, xcd; } cs[] = {
       {"NT full        ", false, true, 0, 0}, {"NT full xcd1   ", false, true, 0, 1},
       {"NT triBU       ", false, true, TRI_B_UPPER, 0}, {"NT triBU xcd1  ", false, true, TRI_B_UPPER, 1},
