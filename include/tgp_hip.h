@@ -69,6 +69,7 @@ extern "C" {
 /* likelihood selector */
 #define TGP_LIK_GAUSS 0 /* GaussianLinearMean.expected_log_prob, likelihoods/GaussianLinearMean.py:60-87       */
 #define TGP_LIK_FLOW 1  /* GaussianNonLinearMean.expected_log_prob, likelihoods/GaussianNonLinearMean.py:64-150 */
+#define TGP_LIK_ADJOINT 2 /* internal to tgp_qf_moments_bwd_f64: no likelihood, the adjoints of mu, v are inputs */
 
 /* covariance function: instance_kernel(name, ...) of models/utils_models.py:145-204 (gpytorch kernels, ARD, softplus
  * parameters).  RBF: s2 exp(-r^2/2);  MATERN32: s2 (1 + sqrt3 r) exp(-sqrt3 r), r = sqrt(max(r^2, 1e-30)) as gpytorch's
@@ -177,6 +178,16 @@ int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double
 
 /* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
  * whitened, diagonal=True).  mu, v: (N). */
+/* Adjoint of tgp_qf_moments_f64 (what autograd replays for models/sparse_MF_SP.py:274-396 when a caller differentiates
+ * the q(f) marginals outside ELBO(): predictive moments with respect to the inducing points, hyper-parameters or q(u)).
+ * Given mu_bar, v_bar (N) it writes d(sum_n mu_bar_n mu_n + v_bar_n v_n)/d{Z, raw_ls, raw_os, m, Lam} into `grads`
+ * (grads->log_var_noise receives 0; theta / rowp are not touched).  Same kernels as the training step -- the row
+ * kernel takes the adjoints instead of forming them from a likelihood, the M x M chain runs with KL weight 0 -- on
+ * either path (fused for M <= 128, general-M above); workspace as tgp_workspace_bytes for S = 1, no flow. */
+int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double* mu_bar, const double* v_bar,
+                           const tgp_grads* grads, int32_t* status, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
                        void* workspace, size_t workspace_bytes, void* stream);
 

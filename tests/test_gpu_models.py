@@ -831,3 +831,61 @@ def test_fused_flow_logdet_matches_elementwise_and_autograd(flowname, S, N):
     Ga = orc.flow_forward(fa, prob["program"], theta, rowp)
     (dGa,) = torch.autograd.grad(Ga.sum(), fa)
     assert rel_err(G.cpu(), Ga.detach()) < 1e-12 and rel_err(tot.cpu(), torch.log(dGa).sum()) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,M,kernel", [(300, 5, 40, "scale_rbf"), (777, 4, 100, "scale_rbf"), (64, 13, 5, "scale_rbf"),
+                                           (700, 6, 200, "scale_rbf"), (500, 3, 150, "scale_matern32")])
+def test_qf_moments_adjoint_matches_oracle_autograd(N, D, M, kernel):
+    """tgp_qf_moments_bwd_f64 (fused path for M <= 128, general-M above) against autograd through the oracle's restatement of
+    models/sparse_MF_SP.py:274-396, for random adjoints of (mu, v); then the same through the autograd Function and through
+    the model's (now differentiable) marginal_variational_qf_parameters / KLD."""
+    from tgp.pytorch_amd import ops
+    prob = orc.synthetic_problem(N, D, M, seed=11, flow=None)
+    pc = {k: v.clone().requires_grad_(True) for k, v in prob["params"].items() if k in ("Z", "raw_lengthscale", "raw_outputscale", "m", "Lam")}
+    gen = torch.Generator().manual_seed(5)
+    mub, vb = torch.randn(N, generator=gen, dtype=torch.float64), torch.randn(N, generator=gen, dtype=torch.float64)
+    mo, vo = orc.qf_moments(prob["X"], pc["Z"], pc["raw_lengthscale"], pc["raw_outputscale"], pc["m"], pc["Lam"], kernel=kernel)
+    ((mo * mub).sum() + (vo * vb).sum()).backward()
+    p = {k: v.detach().to(DEV) for k, v in pc.items()}
+    X = prob["X"].to(DEV)
+    g = ops.qf_moments_bwd(X, p["Z"], p["raw_lengthscale"], p["raw_outputscale"], p["m"], p["Lam"], mub.to(DEV), vb.to(DEV),
+                           kernel=kernel)
+    names = {"Z": "Z", "raw_ls": "raw_lengthscale", "raw_os": "raw_outputscale", "m": "m", "Lam": "Lam"}
+    for k, kk in names.items():
+        assert rel_err(g[k].cpu().reshape(pc[kk].shape), pc[kk].grad) < 1e-7, k       # tolerance of the gradient fixtures
+    assert float(torch.triu(g["Lam"].cpu().reshape(M, M), 1).abs().max()) == 0.0     # tril mask applied at use (:344-345)
+    # the autograd Function: same numbers through torch's engine, X without gradient
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    mu, v = ops.QfMomentsFunction.apply(X, q["Z"], q["raw_lengthscale"], q["raw_outputscale"], q["m"], q["Lam"], kernel)
+    assert rel_err(mu.detach().cpu(), mo.detach()) < 1e-9 and rel_err(v.detach().cpu(), vo.detach()) < 1e-8
+    ((mu * mub.to(DEV)).sum() + (v * vb.to(DEV)).sum()).backward()
+    for k, kk in names.items():
+        assert torch.equal(q[kk].grad.reshape(-1), g[k].reshape(-1)), k
+
+
+@pytest.mark.gpu
+def test_model_moments_and_kl_are_differentiable_like_the_references():
+    """marginal_variational_qf_parameters / KLD called under autograd outside ELBO() (the reference's are plain torch code):
+    gradients reach Z, the kernel hyper-parameters and q(u), and equal the oracle's."""
+    from tgp.pytorch_amd import ops
+    g = load_golden("power_sal2")
+    model = build_model(g, "sal2")
+    X = g["X"].to(DEV)
+    X3 = X[:512].unsqueeze(0)
+    mu, cov = model.marginal_variational_qf_parameters(X3, diagonal=True, is_duvenaud=False)
+    assert mu.requires_grad and cov.requires_grad and mu.shape == (1, 512, 1)
+    loss = (mu ** 2).sum() + cov.sum() + 0.5 * model.KLD().sum()
+    loss.backward()
+    Z, rl, ro, m, Lam, _ = model._gp_params()
+    pc = [t.detach().cpu().clone().requires_grad_(True) for t in (Z, rl, ro, m, Lam)]
+    mo, vo = orc.qf_moments(X[:512].cpu(), *pc)
+    ((mo ** 2).sum() + vo.sum() + 0.5 * orc.kld_whitened(pc[3], pc[4])).backward()
+    got = [model.Z.grad[0], model.covariance_function.base_kernel.raw_lengthscale.grad.reshape(-1),
+           model.covariance_function.raw_outputscale.grad.reshape(-1), model.q_U.variational_mean.grad[0],
+           model.q_U.chol_variational_covar.grad[0]]
+    for a, b in zip(got, pc):
+        assert rel_err(a.cpu().reshape(b.shape), b.grad) < 1e-7
+    with torch.no_grad():
+        mu2, _ = model.marginal_variational_qf_parameters(X3, diagonal=True, is_duvenaud=False)
+    assert not mu2.requires_grad and torch.equal(mu2, mu.detach())

@@ -188,6 +188,39 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   return launch_rows(p, md, fp, X, nullptr, nullptr, nullptr, mu, v, ws, false, st);
 }
 
+int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double* mu_bar, const double* v_bar,
+                           const tgp_grads* grads, int32_t* status, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (int rc = check_model(model, false)) return rc;
+  if (!X) return -2;
+  if (!mu_bar) return -3;
+  if (!v_bar) return -4;
+  if (!grads || !grads->Z || !grads->raw_ls || !grads->raw_os || !grads->m || !grads->Lam || !grads->log_var_noise) return -5;
+  if (!status) return -6;
+  if (!workspace) return -7;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* ws = static_cast<double*>(workspace);
+  tgp_model md = *model;
+  md.nblk = 0; md.P = 0; md.RP = 0; md.S = 1; md.lik = TGP_LIK_ADJOINT; md.program = nullptr;
+  md.scale = 1.0; md.kl_scale = 0.0;
+  tgp_grads g = *grads;
+  g.theta = nullptr; g.rowp = nullptr;
+  FlowProg fp;
+  fp.nblk = 0; fp.nslots = 0;
+  const uint32_t all = TGP_PHASE_PREPARE | TGP_PHASE_ROWS | TGP_PHASE_BACKWARD;
+  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) {
+    // (the scalars of the step go to the header words the general-M plan reserves as well: its hdr is the first block)
+    return launch_big_step(md, fp, X, mu_bar, v_bar, ws + H_OUT, g, nullptr, nullptr, status, ws, workspace_bytes / sizeof(double),
+                           all, st);
+  }
+  Plan p;
+  if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_ADJOINT)) return rc;
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
+  if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
+  if (int rc = launch_rows(p, md, fp, X, mu_bar, v_bar, nullptr, nullptr, nullptr, ws, true, st)) return rc;
+  return launch_backward_mm(p, md, g, ws + p.hdr + H_OUT, ws, st);
+}
+
 int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,
                 double* K, void* stream) {
   if (!Z) return -1;

@@ -1609,6 +1609,12 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                                      ws + p.mub + c0, ws + p.vb + c0, slot + 2, g.rowp ? g.rowp + c0 * md.RP : nullptr,
                                      ws + p.likws, sf))
           return rc;
+      } else if (md.lik == TGP_LIK_ADJOINT) {
+        // tgp_qf_moments_bwd_f64: the adjoints are the caller's (mu_bar in the Y slot, v_bar in the rowp slot)
+        hipError_t e = hipMemcpyAsync(ws + p.mub + c0, Y + c0, (size_t)nrows * sizeof(double), hipMemcpyDeviceToDevice, sf);
+        if (e == hipSuccess) e = hipMemcpyAsync(ws + p.vb + c0, rowp + c0, (size_t)nrows * sizeof(double), hipMemcpyDeviceToDevice, sf);
+        if (e == hipSuccess) e = hipMemsetAsync(slot, 0, (size_t)p.LS * sizeof(double), sf);
+        if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
       } else {
         if (int rc = launch_ell_gauss(Y + c0, ws + p.mu + c0, ws + p.v + c0, nrows, md.log_var_noise, md.scale, slot,
                                       ws + p.mub + c0, ws + p.vb + c0, ws + p.likws, sf))

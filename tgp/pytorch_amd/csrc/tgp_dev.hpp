@@ -61,7 +61,8 @@ struct Plan {
 };
 
 // hdr slots
-enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_STAMP = 8, H_PSTAMP = 32, H_N = 64 };
+enum { H_S2 = 0, H_KL = 1, H_ETA = 2, H_EINV = 3, H_SIG_OS = 4, H_STEP = 5, H_STAMP = 8, H_PSTAMP = 32, H_OUT = 60, H_N = 64 };
+// (H_OUT .. H_OUT+3: where tgp_qf_moments_bwd_f64 lets the backward chain put its four ELBO scalars -- it has no `out`)
 // slab scalar slots
 enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 

@@ -328,12 +328,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       ellp = -0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * (r * r + v);
       etap = -0.5 + 0.5 * einv * (r * r + v);
     }
+  } else if (p.lik == TGP_LIK_ADJOINT) {
+    // tgp_qf_moments_bwd_f64: the adjoints of (mu, v) are the caller's (mu_bar in the Y slot, v_bar in the rowp slot)
+    mub = y;
+    vb = a.rowp[nc];
   } else {
     // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): this lane takes the
     // quadrature nodes s = q, q+4, q+8, ... of its row
     FlowDev F{progL, p.nblk, tpL, tgL, tiL};
     const double sq = sqrt(2.0 * v);
-    const double* rp = a.rowp != nullptr ? a.rowp + (size_t)nc * RP : nullptr;
+    const double* rp = (a.rowp != nullptr && RP > 0) ? a.rowp + (size_t)nc * RP : nullptr;
     double cm = 0.0, cv = 0.0;
     {
       // NB nodes in flight per lane (independent dependency chains); every lane runs the same trip count

@@ -173,13 +173,20 @@ class sparse_MF_SP(nn.Module):
         assert diagonal and not is_duvenaud, "diagonal=True, is_duvenaud=False on this path"
         X2 = X[0] if X.dim() == 3 else X
         self._require_gpu(X2)
-        Z, rl, ro, m, Lam, _ = (t.detach() for t in self._gp_params())
-        mu, v = ops.qf_moments(X2, Z, rl, ro, m, Lam, kernel=self.covariance_function.hip_kernel)
+        Z, rl, ro, m, Lam, _ = self._gp_params()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (Z, rl, ro, m, Lam)):
+            # differentiable like the reference's (autograd through :274-396): tgp_qf_moments_bwd_f64 in the backward
+            mu, v = ops.QfMomentsFunction.apply(X2.detach(), Z, rl, ro, m, Lam, self.covariance_function.hip_kernel)
+        else:
+            mu, v = ops.qf_moments(X2, *(t.detach() for t in (Z, rl, ro, m, Lam)), kernel=self.covariance_function.hip_kernel)
         return mu.reshape(1, -1, 1), v.reshape(1, -1, 1)
 
     def KLD(self):
-        """Whitened KL (sparse_MF_SP.py:406-431), shape (Dy,)."""
-        kl, _, _ = ops.kl_whitened(self.q_U.variational_mean[0].detach(), self.q_U.chol_variational_covar[0].detach())
+        """Whitened KL (sparse_MF_SP.py:406-431), shape (Dy,); differentiable in (m, L_q) like the reference's."""
+        m, Lam = self.q_U.variational_mean[0], self.q_U.chol_variational_covar[0]
+        if torch.is_grad_enabled() and (m.requires_grad or Lam.requires_grad):
+            return ops.KlFunction.apply(m, Lam).reshape(1)
+        kl, _, _ = ops.kl_whitened(m.detach(), Lam.detach())
         return kl.reshape(1)
 
     def ELBO(self, X, Y):

@@ -223,8 +223,9 @@ class ElboFunction(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------
 # stand-alone operators
 # ---------------------------------------------------------------------------------------------------
-def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="scale_rbf"):
-    """q(f) marginals (models/sparse_MF_SP.py:274-396): returns mu, v of shape (N,)."""
+def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="scale_rbf", info=None):
+    """q(f) marginals (models/sparse_MF_SP.py:274-396): returns mu, v of shape (N,).  `info` (a dict) receives the
+    jitter the factorisation ended with (info["jitter"]: the ladder of psd_safe_cholesky may have raised it)."""
     lib = L.load()
     X = _c(X, "X")
     Z, raw_ls, raw_os, m, Lam = (_c(t, "param") for t in (Z, raw_ls, raw_os, m, Lam))
@@ -238,6 +239,8 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="sca
     rc = lib.tgp_qf_moments_f64(md, L.ptr(X), L.ptr(mu), L.ptr(v), L.ptr(status), L.ptr(ws), ws.numel() * 8,
                                 L.stream_ptr())
     L.check(rc, "tgp_qf_moments_f64")
+    if info is not None:
+        info["jitter"] = float(jitter)
     if check and raise_for_status(status.cpu()):
         for jit in jitter_ladder():
             md.jitter = jit
@@ -245,9 +248,79 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="sca
                                            ws.numel() * 8, L.stream_ptr()), "tgp_qf_moments_f64")
             if not raise_for_status(status.cpu()):
                 warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
+                if info is not None:
+                    info["jitter"] = float(jit)
                 return mu, v
         raise NotPSDError("K_MM not positive definite")
     return mu, v
+
+
+def qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, mu_bar, v_bar, jitter=0.0, kernel="scale_rbf"):
+    """Adjoint of qf_moments (tgp_qf_moments_bwd_f64): d(sum mu_bar*mu + v_bar*v)/d{Z, raw_ls, raw_os, m, Lam} as a dict."""
+    lib = L.load()
+    X = _c(X, "X")
+    Z, raw_ls, raw_os, m, Lam = (_c(t, "param") for t in (Z, raw_ls, raw_os, m, Lam))
+    mu_bar, v_bar = _c(mu_bar.reshape(-1), "mu_bar"), _c(v_bar.reshape(-1), "v_bar")
+    if mu_bar.numel() != X.shape[0] or v_bar.numel() != X.shape[0]:
+        raise ValueError("mu_bar / v_bar must have one entry per row of X")
+    dev = X.device
+    lvn = torch.zeros(1, dtype=torch.float64, device=dev)
+    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 0.0, None, None, None, kernel)
+    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel)
+    g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
+         "m": torch.empty_like(m), "Lam": torch.empty_like(Lam)}
+    glvn = torch.empty_like(lvn)
+    gs = L.TgpGrads()
+    gs.Z, gs.raw_ls, gs.raw_os, gs.m, gs.Lam = (L.ptr(g[k]) for k in ("Z", "raw_ls", "raw_os", "m", "Lam"))
+    gs.log_var_noise = L.ptr(glvn)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    rc = lib.tgp_qf_moments_bwd_f64(md, L.ptr(X), L.ptr(mu_bar), L.ptr(v_bar), gs, L.ptr(status), L.ptr(ws), ws.numel() * 8,
+                                    L.stream_ptr())
+    L.check(rc, "tgp_qf_moments_bwd_f64")
+    return g
+
+
+class QfMomentsFunction(torch.autograd.Function):
+    """(mu, v) = q(f) marginals with autograd in Z, raw_ls, raw_os, m, Lam (what differentiating the reference's
+    marginal_variational_qf_parameters, models/sparse_MF_SP.py:274-396, gives outside ELBO()); X gets no gradient.
+    Forward tgp_qf_moments_f64 (with psd_safe_cholesky's jitter ladder), backward tgp_qf_moments_bwd_f64 at the jitter
+    the forward ended with."""
+
+    @staticmethod
+    def forward(ctx, X, Z, raw_ls, raw_os, m, Lam, kernel):
+        info = {}
+        mu, v = qf_moments(X, Z, raw_ls, raw_os, m, Lam, kernel=kernel, info=info)
+        ctx.save_for_backward(X, Z, raw_ls, raw_os, m, Lam)
+        ctx.kernel = kernel
+        ctx.jitter = info["jitter"]
+        return mu, v
+
+    @staticmethod
+    def backward(ctx, g_mu, g_v):
+        X, Z, raw_ls, raw_os, m, Lam = ctx.saved_tensors
+        if g_mu is None:
+            g_mu = torch.zeros(X.shape[0], dtype=torch.float64, device=X.device)
+        if g_v is None:
+            g_v = torch.zeros(X.shape[0], dtype=torch.float64, device=X.device)
+        g = qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, g_mu, g_v, jitter=ctx.jitter, kernel=ctx.kernel)
+        return (None, g["Z"].reshape(Z.shape), g["raw_ls"].reshape(raw_ls.shape), g["raw_os"].reshape(raw_os.shape),
+                g["m"].reshape(m.shape), g["Lam"].reshape(Lam.shape), None)
+
+
+class KlFunction(torch.autograd.Function):
+    """Whitened KL with autograd in (m, Lam): tgp_kl_whitened_f64 returns the value and both gradients in one launch."""
+
+    @staticmethod
+    def forward(ctx, m, Lam):
+        kl, gm, gL = kl_whitened(m, Lam)
+        ctx.save_for_backward(gm, gL)
+        ctx.shapes = (m.shape, Lam.shape)
+        return kl.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        gm, gL = ctx.saved_tensors
+        return (g * gm).reshape(ctx.shapes[0]), (g * gL).reshape(ctx.shapes[1])
 
 
 def kernel_matrix(X1, X2, raw_ls, raw_os, kernel="scale_rbf", jitter=0.0):
