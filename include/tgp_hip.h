@@ -178,6 +178,16 @@ int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double
 
 /* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
  * whitened, diagonal=True).  mu, v: (N). */
+/* Adjoint of tgp_cholesky_f64 (what autograd replays for torch.cholesky inside psd_safe_cholesky, dsp/utils.py:239, when a
+ * caller differentiates through the factor outside ELBO()): given L, Linv = L^-1 (both as tgp_cholesky_f64 returns them)
+ * and L_bar (M x M; its part on and below the diagonal counts) it writes the SYMMETRIC
+ *   A_bar = 1/2 L^-T (Phi(L^T L_bar) + Phi(L^T L_bar)^T) L^-1,   Phi = lower triangle with the diagonal halved
+ * -- torch's cholesky backward.  Any M <= TGP_BIG_MAX_M: operands are padded to a multiple of 128 and run through the
+ * three products of the general-M backward chain; workspace tgp_cholesky_bwd_workspace_bytes(M). */
+size_t tgp_cholesky_bwd_workspace_bytes(int32_t M);
+int tgp_cholesky_bwd_f64(const double* L, const double* Linv, const double* L_bar, int32_t M, double* A_bar, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Adjoint of tgp_qf_moments_f64 (what autograd replays for models/sparse_MF_SP.py:274-396 when a caller differentiates
  * the q(f) marginals outside ELBO(): predictive moments with respect to the inducing points, hyper-parameters or q(u)).
  * Given mu_bar, v_bar (N) it writes d(sum_n mu_bar_n mu_n + v_bar_n v_n)/d{Z, raw_ls, raw_os, m, Lam} into `grads`

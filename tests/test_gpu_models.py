@@ -889,3 +889,32 @@ def test_model_moments_and_kl_are_differentiable_like_the_references():
     with torch.no_grad():
         mu2, _ = model.marginal_variational_qf_parameters(X3, diagonal=True, is_duvenaud=False)
     assert not mu2.requires_grad and torch.equal(mu2, mu.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [5, 40, 128, 300, 1000])
+def test_cholesky_adjoint_matches_torch(M):
+    """tgp_cholesky_bwd_f64 against torch.linalg.cholesky's backward (what the reference's psd_safe_cholesky replays,
+    dsp/utils.py:239), for a dense factor adjoint whose strictly-upper part must be ignored; then through the autograd Function
+    and through ops.psd_safe_cholesky."""
+    from tgp.pytorch_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    B = torch.randn(M, M + 3, generator=gen, dtype=torch.float64)
+    A = (B @ B.T / M + 0.5 * torch.eye(M, dtype=torch.float64)).requires_grad_(True)
+    Lbar = torch.randn(M, M, generator=gen, dtype=torch.float64)
+    Lc = torch.linalg.cholesky(A)
+    (Lc * Lbar.tril()).sum().backward()
+    Lo, Li, st = ops.cholesky(A.detach().to(DEV), want_inverse=True)
+    assert int(st[0]) == 0
+    Ab = ops.cholesky_bwd(Lo, Li, Lbar.to(DEV)).cpu()
+    assert rel_err(Ab, A.grad) < 1e-9
+    assert float((Ab - Ab.T).abs().max()) <= 1e-12 * float(Ab.abs().max())
+    Ad = A.detach().to(DEV).requires_grad_(True)
+    L2 = ops.CholeskyFunction.apply(Ad)
+    (L2 * Lbar.to(DEV).tril()).sum().backward()
+    assert torch.equal(Ad.grad.cpu(), Ab)
+    Ad.grad = None
+    L3, used = ops.psd_safe_cholesky(Ad)
+    assert L3.requires_grad and used is Ad
+    (L3 * Lbar.to(DEV).tril()).sum().backward()
+    assert torch.equal(Ad.grad.cpu(), Ab)

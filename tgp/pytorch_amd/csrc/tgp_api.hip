@@ -283,6 +283,21 @@ int tgp_cholesky_f64(const double* A, int32_t M, double* L, double* Linv, int32_
   return launch_cholesky(A, M, L, Linv, status, static_cast<hipStream_t>(stream));
 }
 
+int tgp_cholesky_bwd_f64(const double* L, const double* Linv, const double* L_bar, int32_t M, double* A_bar, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!L) return -1;
+  if (!Linv) return -2;
+  if (!L_bar) return -3;
+  if (M < 1) return -4;
+  if (M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
+  if (!A_bar) return -5;
+  if (!workspace) return -6;
+  return launch_big_cholesky_bwd(L, Linv, L_bar, M, A_bar, static_cast<double*>(workspace), workspace_bytes / sizeof(double),
+                                 static_cast<hipStream_t>(stream));
+}
+
+size_t tgp_cholesky_bwd_workspace_bytes(int32_t M) { return big_cholesky_workspace_doubles(M) * sizeof(double); }
+
 int tgp_gemm_f64(int32_t trans_a, int32_t trans_b, int32_t tri, int32_t m, int32_t n, int32_t k, double alpha,
                  const double* A, int32_t lda, const double* B, int32_t ldb, double beta, double* C, int32_t ldc,
                  void* stream) {

@@ -1775,6 +1775,51 @@ int launch_big_cholesky(const double* A, int M, double* Lo, double* Jo, int32_t*
   return 0;
 }
 
+// ---- adjoint of the Cholesky factorisation (tgp_cholesky_bwd_f64), any M: pad, the backward chain's three products, unpad ----
+//   Abar = 1/2 J^T (Phi(L^T Lbar) + Phi(.)^T) J,   J = L^-1     (symmetric: what torch's cholesky backward returns)
+__global__ __launch_bounds__(256) void k_big_cholbwd_in(BigPlan p, const double* __restrict__ L, const double* __restrict__ Li,
+                                                        const double* __restrict__ Lbar, double* __restrict__ ws) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int MP = p.MP, M = p.M;
+  const int row = (int)(e / MP), col = (int)(e % MP);
+  const bool in = row < M && col < M && col <= row;
+  const size_t s = (size_t)row * M + col;
+  ws[p.Lm + e] = in ? L[s] : (row == col ? 1.0 : 0.0);   // identity on the padding: L^T Lbar and J stay block diagonal there
+  ws[p.J + e] = in ? Li[s] : (row == col ? 1.0 : 0.0);
+  ws[p.R1 + e] = in ? Lbar[s] : 0.0;                      // the factor's adjoint counts on and below the diagonal only
+}
+__global__ __launch_bounds__(256) void k_big_cholbwd_out(BigPlan p, const double* __restrict__ ws, double* __restrict__ Abar) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int M = p.M;
+  if (e >= (size_t)M * M) return;
+  Abar[e] = ws[p.R1 + (size_t)(e / M) * p.MP + e % M];
+}
+
+int launch_big_cholesky_bwd(const double* L, const double* Linv, const double* Lbar, int M, double* Abar, double* ws,
+                            size_t ws_doubles, hipStream_t st) {
+  BigPlan p;
+  if (int rc = make_big_plan(p, 128, 1, M, 1, 0, 0, 0, TGP_LIK_GAUSS, TGP_KERNEL_SCALE_MATERN32)) return rc;
+  if (ws_doubles < p.total) return TGP_E_WORKSPACE;
+  const int MP = p.MP;
+  const size_t mm = (size_t)MP * MP;
+  const unsigned gmm = (unsigned)(mm / 256);
+  hipLaunchKernelGGL(k_big_cholbwd_in, dim3(gmm), dim3(256), 0, st, p, L, Linv, Lbar, ws);
+  LAUNCH_CHECK();
+  bool fused = false;
+  if (int rc = gemm_mm(true, false, gemm_args(ws + p.Lm, MP, ws + p.R1, MP, ws + p.Q, MP, MP, MP, MP, 1.0, 0.0, TRI_A_UPPER | TRI_B_LOWER),
+                       p, ws, st, 2, nullptr, nullptr, &fused))
+    return rc;
+  if (!fused) {
+    hipLaunchKernelGGL(k_big_phisym, dim3(gmm), dim3(256), 0, st, p, ws);
+    LAUNCH_CHECK();
+  }
+  GEMM_MM(false, false, gemm_args(ws + p.Q, MP, ws + p.J, MP, ws + p.S_, MP, MP, MP, MP, 1.0, 0.0, TRI_B_LOWER));
+  GEMM_MM(true, false, gemm_args(ws + p.J, MP, ws + p.S_, MP, ws + p.R1, MP, MP, MP, MP, 0.5, 0.0, TRI_A_UPPER));
+  hipLaunchKernelGGL(k_big_cholbwd_out, dim3((unsigned)(((size_t)M * M + 255) / 256)), dim3(256), 0, st, p, ws, Abar);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // diagnostic / test entry: plain GEMM on padded operands
 int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                       int ldb, double beta, double* C, int ldc, hipStream_t st) {

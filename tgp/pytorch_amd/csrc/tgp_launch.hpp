@@ -55,6 +55,8 @@ int launch_big_moments(const tgp_model& md, const double* X, double* mu, double*
 size_t big_cholesky_workspace_doubles(int M);
 int launch_big_cholesky(const double* A, int M, double* Lo, double* Jo, int32_t* status, double* ws, size_t ws_doubles,
                         hipStream_t st);
+int launch_big_cholesky_bwd(const double* L, const double* Linv, const double* Lbar, int M, double* Abar, double* ws,
+                            size_t ws_doubles, hipStream_t st);
 int launch_gemm_plain(bool ta, bool tb, int tri, int m, int n, int k, double alpha, const double* A, int lda, const double* B,
                       int ldb, double beta, double* C, int ldc, hipStream_t st);
 

@@ -75,6 +75,8 @@ _SIGS = {
     "tgp_gemm_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, _dp, C.c_int32,
                                _dp, C.c_int32, C.c_double, _dp, C.c_int32, _dp]),
     "tgp_cholesky_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "tgp_cholesky_bwd_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "tgp_cholesky_bwd_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, _dp, _dp, C.c_size_t, _dp]),
     "tgp_ell_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "tgp_kl_whitened_f64": (C.c_int, [_dp, _dp, C.c_int32, _dp, _dp, _dp, _dp]),
     "tgp_ell_gauss_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, _dp, C.c_double, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),

@@ -372,18 +372,61 @@ def cholesky(A, want_inverse=False):
     return Lo, Li, status
 
 
+def cholesky_bwd(Lo, Li, L_bar):
+    """Adjoint of `cholesky` (tgp_cholesky_bwd_f64): the symmetric A_bar for a factor adjoint L_bar, given L and L^-1."""
+    lib = L.load()
+    Lo, Li, L_bar = _c(Lo, "L"), _c(Li, "Linv"), _c(L_bar, "L_bar")
+    M = Lo.shape[0]
+    A_bar = torch.empty_like(Lo)
+    ws = torch.empty(lib.tgp_cholesky_bwd_workspace_bytes(M) // 8 + 16, dtype=torch.float64, device=Lo.device)
+    L.check(lib.tgp_cholesky_bwd_f64(L.ptr(Lo), L.ptr(Li), L.ptr(L_bar), M, L.ptr(A_bar), L.ptr(ws), ws.numel() * 8,
+                                     L.stream_ptr()), "tgp_cholesky_bwd_f64")
+    return A_bar
+
+
+class CholeskyFunction(torch.autograd.Function):
+    """L = chol(A) with autograd (torch.cholesky inside psd_safe_cholesky, dsp/utils.py:239, is differentiable in the
+    reference): forward tgp_cholesky_f64 (L and L^-1 in one call), backward tgp_cholesky_bwd_f64.  Raises NotPSDError on a
+    non-positive pivot (the jitter ladder is psd_safe_cholesky's)."""
+
+    @staticmethod
+    def forward(ctx, A):
+        Lo, Li, status = cholesky(A, want_inverse=True)
+        if raise_for_status(status.cpu()):
+            raise NotPSDError("matrix not positive definite (pivot %d)" % int(status[0]))
+        ctx.save_for_backward(Lo, Li)
+        return Lo
+
+    @staticmethod
+    def backward(ctx, g):
+        Lo, Li = ctx.saved_tensors
+        return cholesky_bwd(Lo, Li, g)
+
+
 def psd_safe_cholesky(A, jitter=None):
-    """dsp/utils.py:222-270 on the GPU: returns (L, A_used)."""
-    Lo, _, status = cholesky(A)
-    if not raise_for_status(status.cpu()):
+    """dsp/utils.py:222-270 on the GPU: returns (L, A_used).  With autograd on and A requiring grad the factor carries a
+    gradient to A (CholeskyFunction), as the reference's torch.cholesky does."""
+    diff = torch.is_grad_enabled() and A.requires_grad
+
+    def attempt(Ax):
+        if diff:
+            try:
+                return CholeskyFunction.apply(Ax), False
+            except NotPSDError:
+                return None, True
+        Lo, _, status = cholesky(Ax)
+        return Lo, raise_for_status(status.cpu())
+
+    Lo, bad = attempt(A)
+    if not bad:
         return Lo, A
-    Ap = A.clone()
+    Ap = A.clone()          # (a non-leaf copy: the in-place diagonal updates below are autograd-safe)
     prev = 0.0
     for jit in jitter_ladder(A.dtype, jitter):
         Ap.diagonal().add_(jit - prev)
         prev = jit
-        Lo, _, status = cholesky(Ap)
-        if not raise_for_status(status.cpu()):
+        Lo, bad = attempt(Ap)
+        if not bad:
             warnings.warn("A not p.d., added jitter of %g to the diagonal" % jit, NumericalWarning)
             return Lo, Ap
     raise NotPSDError("matrix not positive definite even with jitter %g" % prev)
