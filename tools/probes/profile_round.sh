@@ -83,5 +83,15 @@ python tools/probes/time_bayes_eval.py 2>&1 | grep -v amdgpu > $O/bayes_eval_tim
 python tools/probes/stamp_prep.py 2>&1 | grep -v amdgpu > $O/prep_phase_stamps.txt; head -12 $O/prep_phase_stamps.txt
 python tools/probes/stamp_run.py 2>&1 | grep -v amdgpu > $O/rows_phase_stamps.txt; tail -4 $O/rows_phase_stamps.txt
 ./tools/probes/potrf_panel_rate > $O/potrf_panel_rate.txt 2>&1; cat $O/potrf_panel_rate.txt
+# ---- kernel timelines of one replayed step (tools/probes/timeline.py): start offset, duration, queue, gap per kernel ----
+cd /tmp
+for w in tgp_airline_mb10k tgp_airline_mb10k_rank8 idtgp_power_sal3 tgp_power_tanh3x2; do
+  T=$(fresh tl_$w)
+  rocprofv3 --kernel-trace --output-format csv -d $T -- python3 $R/bench.py --workload $w --steps 40 --warmup 10 --repeats 1 --no-cpu-baseline > $D/tl_$w.log 2>&1
+  f=$(find $T -name "*kernel_trace.csv" | head -1)
+  python3 $R/tools/probes/timeline.py "$f" > $D/timeline_$w.txt 2>&1
+  head -3 $D/timeline_$w.txt
+done
+cd $R
 find $O -name "*kernel_trace.csv" -size +8M -delete
 find $O -name "*counter_collection.csv" -size +30M -delete
