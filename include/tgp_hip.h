@@ -178,6 +178,9 @@ int tgp_elbo_step_adam_f64(const tgp_model* model, const double* X, const double
 
 /* q(f) marginals only: sparse_MF_SP.marginal_variational_qf_parameters (models/sparse_MF_SP.py:274-396,
  * whitened, diagonal=True).  mu, v: (N). */
+int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Adjoint of tgp_cholesky_f64 (what autograd replays for torch.cholesky inside psd_safe_cholesky, dsp/utils.py:239, when a
  * caller differentiates through the factor outside ELBO()): given L, Linv = L^-1 (both as tgp_cholesky_f64 returns them)
  * and L_bar (M x M; its part on and below the diagonal counts) it writes the SYMMETRIC
@@ -197,9 +200,6 @@ int tgp_cholesky_bwd_f64(const double* L, const double* Linv, const double* L_ba
 int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double* mu_bar, const double* v_bar,
                            const tgp_grads* grads, int32_t* status, void* workspace, size_t workspace_bytes,
                            void* stream);
-
-int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, double* v, int32_t* status,
-                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* K_MM assembly: gpytorch ScaleKernel(RBFKernel(ard)) as built by instance_kernel('scale_rbf'),
  * models/utils_models.py:188-193, called at models/sparse_MF_SP.py:316.  K (M,M). */
@@ -308,6 +308,15 @@ int tgp_mlp_forward_f64(const tgp_mlp* mlp, const double* X, const double* W, co
 /* g_W (nnets * weights_per_net) = d(objective)/dW given g_out (N, nnets) (= g_rowp of tgp_elbo_step_f64). */
 int tgp_mlp_backward_f64(const tgp_mlp* mlp, const double* X, const double* W, const int32_t* step_dev,
                          const double* g_out, double* g_W, void* workspace, size_t workspace_bytes, void* stream);
+/* The same followed by the Adam update of the network weights (the reference's second parameter group: names containing
+ * 'NNets', weight decay 1e-5, main.py:276-288; torch.optim.Adam, dsp/trainers/optimizers.py:12) in the launch that
+ * reduces the weight gradients: adam->params must be W, adam->grads g_W, adam->n the number of weights; adam->step_dev is
+ * the group's device step counter (bumped by this call; adam->phases is ignored).  `step_dev` (the dropout masks' step
+ * word) may be the same counter: it is read before the bump.  Same arithmetic as tgp_mlp_backward_f64 +
+ * tgp_adam_dev_f64(weight_decay). */
+int tgp_mlp_backward_adam_f64(const tgp_mlp* mlp, const double* X, double* W, const int32_t* step_dev, const double* g_out,
+                              double* g_W, void* workspace, size_t workspace_bytes, const tgp_adam_args* adam,
+                              double weight_decay, void* stream);
 
 /* Minibatch rows of a data set resident in HBM -- replaces the per-step host collation + H2D copy of the reference's
  * DataLoader (dsp/data/data.py:86-88, trainers/trainer_base.py:330): Xb[r] = X[index[cursor + offset + r]] and Yb

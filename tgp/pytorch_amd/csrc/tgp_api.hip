@@ -524,4 +524,23 @@ int tgp_mlp_backward_f64(const tgp_mlp* mlp, const double* X, const double* W, c
                              workspace_bytes / sizeof(double), static_cast<hipStream_t>(stream));
 }
 
+int tgp_mlp_backward_adam_f64(const tgp_mlp* mlp, const double* X, double* W, const int32_t* step_dev, const double* g_out,
+                              double* g_W, void* workspace, size_t workspace_bytes, const tgp_adam_args* adam,
+                              double weight_decay, void* stream) {
+  if (!mlp) return -1;
+  if (!X) return -2;
+  if (!W) return -3;
+  if (!g_out) return -5;
+  if (!g_W) return -6;
+  if (!workspace) return -7;
+  if (!adam || adam->params != W || adam->grads != g_W || !adam->exp_avg || !adam->exp_avg_sq || !adam->step_dev) return -9;
+  AdamDev ad;
+  ad.p = adam->params; ad.g = adam->grads; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.n = (long)adam->n;
+  ad.lr = adam->lr; ad.b1 = adam->beta1; ad.b2 = adam->beta2; ad.eps = adam->eps;
+  ad.ln_b1 = log(adam->beta1); ad.ln_b2 = log(adam->beta2); ad.sign = adam->maximize ? -1.0 : 1.0;
+  ad.step_dev = adam->step_dev;
+  return launch_mlp_backward(*mlp, X, W, step_dev, g_out, g_W, static_cast<double*>(workspace),
+                             workspace_bytes / sizeof(double), static_cast<hipStream_t>(stream), &ad, weight_decay);
+}
+
 }  // extern "C"

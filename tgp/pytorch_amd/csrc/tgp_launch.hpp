@@ -70,7 +70,8 @@ int launch_kmeans_pp(const double* X, int N, int D, const int64_t* cand, int T, 
 size_t mlp_workspace_doubles(int N, int D, int H, int L, int nnets);
 int launch_mlp_forward(const tgp_mlp& d, const double* X, const double* W, const int32_t* step_dev, double* out, hipStream_t st);
 int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, const int32_t* step_dev, const double* g_out,
-                        double* g_W, double* ws, size_t ws_doubles, hipStream_t st);
+                        double* g_W, double* ws, size_t ws_doubles, hipStream_t st, const AdamDev* adam = nullptr,
+                        double weight_decay = 0.0);
 
 // tgp_lik.hip
 int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, const double* log_var_noise,

@@ -473,8 +473,13 @@ __global__ __launch_bounds__(MLP_NT, 2) void k_mlp_bwd(MlpArgs m, const double* 
 // of the row blocks (a wave per quarter); 16 partials are requested before the first add -- with two loads in flight per
 // thread the 135 partials of a Power-sized step were 67 dependent L2 round trips (21 us on the critical path of the
 // ID_TGP step); the four quarter sums meet in LDS and are added in a fixed order.
-__global__ __launch_bounds__(256) void k_mlp_reduce(const double* __restrict__ part, int nblk, size_t len, double* __restrict__ g_W) {
+// `ad` (tgp_mlp_backward_adam_f64): the thread that forms a weight's gradient applies torch.optim.Adam to it (k_adam_dev's
+// arithmetic, weight decay `wd` on every entry: these are the reference's 'NNets' group, main.py:276-288) and the last
+// workgroup bumps the group's device step counter -- the update no longer costs the ID_TGP side chain a launch of its own.
+__global__ __launch_bounds__(256) void k_mlp_reduce(const double* __restrict__ part, int nblk, size_t len, double* __restrict__ g_W,
+                                                     AdamDev ad, double wd) {
   __shared__ double q4[4][64];
+  const double step = ad.p != nullptr ? (double)(ad.step_dev[0] + 1) : 1.0;   // (read before any workgroup's ticket)
   const int el = threadIdx.x & 63, qt = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + el;
   const int b0 = (int)((long long)nblk * qt / 4), b1 = (int)((long long)nblk * (qt + 1) / 4);
@@ -496,7 +501,30 @@ __global__ __launch_bounds__(256) void k_mlp_reduce(const double* __restrict__ p
   }
   q4[qt][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (qt == 0 && e < len) g_W[e] = (q4[0][el] + q4[1][el]) + (q4[2][el] + q4[3][el]);
+  if (qt == 0 && e < len) {
+    const double g = (q4[0][el] + q4[1][el]) + (q4[2][el] + q4[3][el]);
+    g_W[e] = g;
+    if (ad.p != nullptr) {
+      const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
+      double gi = ad.sign * g;
+      if (wd != 0.0) gi += wd * ad.p[e];
+      const double mi = ad.b1 * ad.m[e] + (1.0 - ad.b1) * gi;
+      const double vi = ad.b2 * ad.v[e] + (1.0 - ad.b2) * gi * gi;
+      ad.m[e] = mi;
+      ad.v[e] = vi;
+      ad.p[e] -= (ad.lr / bc1) * mi / (sqrt(vi) / bc2s + ad.eps);
+    }
+  }
+  if (ad.p != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(&ad.step_dev[1], 1);
+      if (t == (int)gridDim.x - 1) {
+        ad.step_dev[1] = 0;
+        atomicAdd(&ad.step_dev[0], 1);
+      }
+    }
+  }
 }
 
 static size_t mlp_lds_bytes(int D, int H, int L, bool bwd) { return (size_t)mlp_lds(D, H, L, bwd).total * sizeof(double); }
@@ -549,7 +577,7 @@ int launch_mlp_forward(const tgp_mlp& d, const double* X, const double* W, const
 }
 
 int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, const int32_t* step_dev, const double* g_out,
-                        double* g_W, double* ws, size_t ws_doubles, hipStream_t st) {
+                        double* g_W, double* ws, size_t ws_doubles, hipStream_t st, const AdamDev* adam, double weight_decay) {
   if (int rc = mlp_check(d)) return rc;
   if (ws_doubles < mlp_workspace_doubles(d.N, d.D, d.H, d.L, d.nnets)) return TGP_E_WORKSPACE;
   const size_t lds = mlp_lds_bytes(d.D, d.H, d.L, true);
@@ -561,7 +589,12 @@ int launch_mlp_backward(const tgp_mlp& d, const double* X, const double* W, cons
   hipLaunchKernelGGL(k, dim3(nblk, d.nnets), dim3(MLP_NT), lds, st, mlp_args(d, X, W, step_dev), g_out, ws);
   LAUNCH_CHECK();
   const size_t len = (size_t)d.nnets * mlp_weights_per_net(d.D, d.H, d.L);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((len + 63) / 64)), dim3(256), 0, st, ws, nblk, len, g_W);
+  AdamDev ad;
+  if (adam != nullptr) {
+    if ((size_t)adam->n != len) return -9;   // the update covers exactly the weights whose gradients this call forms
+    ad = *adam;
+  }
+  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((len + 63) / 64)), dim3(256), 0, st, ws, nblk, len, g_W, ad, weight_decay);
   LAUNCH_CHECK();
   return 0;
 }

@@ -223,6 +223,22 @@ class ElboEngine:
                                                   L.ptr(self.fp.gview("nn")), L.ptr(self.mlp_ws), self.mlp_ws.numel() * 8,
                                                   L.stream_ptr()), "tgp_mlp_backward_f64")
 
+    def mlp_backward_adam(self, step):
+        """MLP backward + Adam on the network weights (their own group: weight decay, own step counter) in the launch that
+        reduces the weight gradients (tgp_mlp_backward_adam_f64): one launch less on the side chain of the rotated unit."""
+        fp = self.fp
+        lo, hi = fp.offsets["nn"], fp.n
+        ad = L.TgpAdamArgs()
+        ad.params, ad.grads = L.ptr(fp.data[lo:hi]), L.ptr(fp.grad[lo:hi])
+        ad.exp_avg, ad.exp_avg_sq = L.ptr(fp.exp_avg[lo:hi]), L.ptr(fp.exp_avg_sq[lo:hi])
+        ad.n = hi - lo
+        ad.lr, ad.beta1, ad.beta2, ad.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        ad.step_dev, ad.maximize, ad.phases = L.ptr(step), 1, 0
+        d = self.mlp.struct(self.N, self.mlp_training)
+        L.check(self.lib.tgp_mlp_backward_adam_f64(d, L.ptr(self.X), L.ptr(fp.data[lo:hi]), L.ptr(step), L.ptr(self.g_rowp),
+                                                   L.ptr(fp.grad[lo:hi]), L.ptr(self.mlp_ws), self.mlp_ws.numel() * 8, ad,
+                                                   float(self.nn_wd), L.stream_ptr()), "tgp_mlp_backward_adam_f64")
+
     def _adam_segment(self, lo, hi, weight_decay, step):
         fp = self.fp
         rc = self.lib.tgp_adam_dev_f64(L.ptr(fp.data[lo:hi]), L.ptr(fp.grad[lo:hi]), L.ptr(fp.exp_avg[lo:hi]),
@@ -314,8 +330,11 @@ class ElboEngine:
                 self.elbo(1)
                 side.wait_event(forked)
                 with torch.cuda.stream(side):
-                    self.mlp_backward(self.step_nn)
-                    self._adam_segment(n_plain, self.fp.n, self.nn_wd, self.step_nn)
+                    if os.environ.get("TGP_FUSED_ADAM", "1") != "0":
+                        self.mlp_backward_adam(self.step_nn)     # backward + Adam on the network weights, one launch less
+                    else:
+                        self.mlp_backward(self.step_nn)
+                        self._adam_segment(n_plain, self.fp.n, self.nn_wd, self.step_nn)
                     self.mlp_forward(self.step_nn)
                 main.wait_stream(side)
             self.g1 = torch.cuda.CUDAGraph()

@@ -68,6 +68,8 @@ _SIGS = {
     "tgp_elbo_step_adam_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
                                          C.c_size_t, C.POINTER(TgpAdamArgs), _dp]),
     "tgp_qf_moments_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
+    "tgp_mlp_backward_adam_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, C.POINTER(TgpAdamArgs),
+                                            C.c_double, _dp]),
     "tgp_qf_moments_bwd_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, C.c_size_t, _dp]),
     "tgp_kmm_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _dp]),
     "tgp_knm_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
