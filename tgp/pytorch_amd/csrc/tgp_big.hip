@@ -116,6 +116,9 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   {
     const int nb = p.MP / 128, ntiles = nb * (nb + 1) / 2;
     p.ksg = 512 / ntiles;  // one resident round: two workgroups per CU
+    // ... but no thinner than 256 rows per slab: a rank's 1 250 rows of an 8-GPU minibatch cut 14 ways were 90-row slabs
+    // whose partials (14 x M^2) cost k_big_reduce more than the SYRK itself (29 -> 19 us)
+    if (p.ksg > p.NC / 256) p.ksg = p.NC / 256;
     if (p.ksg < 1) p.ksg = 1;
     if (p.ksg > 32) p.ksg = 32;
   }
@@ -1485,8 +1488,18 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
   LAUNCH_CHECK();
-  // ---- fork: what needs only the variational parameters (KL, S = Lq Lq^T - I) runs beside the factorisation ----
-  if (int rc = fk.after(0, st, sx)) return rc;
+  // ---- fork: what needs only the variational parameters (KL, S = Lq Lq^T - I) runs beside the factorisation.  The
+  //      factorisation is ISSUED FIRST: a captured graph keeps the first-created successor of a fork on the parent's
+  //      hardware queue and moves the later ones to another -- with the auxiliary branch created first the critical
+  //      chain hopped queues behind k_big_kmm and again in front of the row phase, ~10 us of dependency latency each
+  //      time (q1 -> q4 -> q1 -> q4 in the kernel timeline; now one hop, where the row phase meets the early K') ----
+  if (hipError_t e = hipEventRecord(fk.ev[0], st); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+  if (int rc = big_factorise(p, ws, status, true, st)) return rc;
+  if (md.jitter_ladder > 0.0) {  // the device-side retry ladder: returns at once unless the factorisation failed
+    hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
+    LAUNCH_CHECK();
+  }
+  if (hipError_t e = hipStreamWaitEvent(sx, fk.ev[0], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   if (train) {
     hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, sx, p, md, ws);
     LAUNCH_CHECK();
@@ -1501,12 +1514,7 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
     if (X0 != nullptr)
       if (int rc = big_chunk_kernel(p, X0, nrows0, ws, true, sx)) return rc;
   }
-  if (int rc = big_factorise(p, ws, status, true, st)) return rc;
   if (int rc = fk.after(1, sx, st)) return rc;   // join
-  if (md.jitter_ladder > 0.0) {  // the device-side retry ladder: returns at once unless the factorisation failed
-    hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
-    LAUNCH_CHECK();
-  }
   if (!train) return 0;
   // H' = J^T S (after the ladder: a retry rewrites J)
   hipStream_t sh = st;
@@ -1673,18 +1681,10 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
     if (int rc = fk.init()) return rc;
     if (defer_hw)
       if (int rc = big_join(st)) return rc;   // H', w
-    // dLam = tril(2 G Lq) - ... needs G only: on the auxiliary stream, beside the chain Lbar -> Q -> Kbar_MM -> U (product
-    // and split-k slabs in the row phase's G partials, reduced into G by now)
-    if (int rc = fk.after(0, st, fk.aux)) return rc;
-    {
-      double* dl = ws + p.Gpart;
-      const size_t cap = p.ksg > 1 ? (size_t)(p.ksg - 1) * mm : 0;
-      if (int rc = gemm_mm_on(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, dl, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER), dl + mm, cap,
-                              fk.aux))
-        return rc;
-      hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, fk.aux, p, md, g.Lam, dl);
-      LAUNCH_CHECK();
-    }
+    // dLam = tril(2 G Lq) - ... needs G only: on the auxiliary stream, beside the chain Lbar -> Q -> Kbar_MM -> U.  The fork
+    // point is recorded here, the auxiliary branch is ISSUED AFTER the chain (see big_prepare: the first-created successor
+    // of a fork keeps the parent's hardware queue under graph replay, and that must be the critical chain).
+    if (hipError_t e = hipEventRecord(fk.ev[0], st); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
     // Lbar = -tril(w s^T + 2 H' G)
     bool fused = false;
     if (int rc = gemm_mm(false, false, gemm_args(ws + p.Hp, MP, ws + p.G, MP, ws + p.R1, MP, MP, MP, MP, 2.0, 0.0), p, ws, st, 1,
@@ -1722,6 +1722,17 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
     hipLaunchKernelGGL(k_big_sum_slabs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, ws + p.Tpart, 8,
                        (size_t)MP * BIG_XW, ws + p.U);
     LAUNCH_CHECK();
+    if (hipError_t e = hipStreamWaitEvent(fk.aux, fk.ev[0], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
+    {
+      // (product and split-k slabs in the row phase's G partials, reduced into G by now)
+      double* dl = ws + p.Gpart;
+      const size_t cap = p.ksg > 1 ? (size_t)(p.ksg - 1) * mm : 0;
+      if (int rc = gemm_mm_on(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, dl, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER), dl + mm, cap,
+                              fk.aux))
+        return rc;
+      hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, fk.aux, p, md, g.Lam, dl);
+      LAUNCH_CHECK();
+    }
     if (int rc = big_join(st)) return rc;   // dLam
     hipLaunchKernelGGL(k_big_final, dim3(1), dim3(FINAL_THREADS), 0, st, p, md, g, out, ws);
     LAUNCH_CHECK();
