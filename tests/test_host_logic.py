@@ -198,3 +198,25 @@ def test_bench_metric_label_follows_what_is_stepped():
     assert weak != bench.BASELINE_METRIC and "8 shards of 8611 rows" in weak
     a = bench.WORKLOADS["tgp_airline_tanh5x6"]
     assert "2000000-row" in bench.metric_name("tgp_airline_tanh5x6", a, 8 * 250000)
+
+
+def test_timeline_tool_reads_a_kernel_trace(tmp_path):
+    """tools/probes/timeline.py (how the general-M step was read off a rocprofv3 --kernel-trace CSV): one steady-state step,
+    gaps per queue, union of busy intervals."""
+    import os
+    import subprocess
+    import sys
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    t = 1000
+    for step in range(5):
+        for name, q, dur, gap in (("tgp::k_prep_a(tgp::Plan)", 1, 3000, 0), ("void tgp::k_rows<7, 4, 1>(tgp::RowArgs)", 1, 5000, 0),
+                                  ("tgp::k_mlp_fwd(x)", 3, 2000, -4000), ("tgp::k_reduce(tgp::Plan, double*)", 1, 500, 1000)):
+            s = t + gap
+            rows.append(f"KERNEL_DISPATCH,1,{q},1,\"{name}\",1,{s},{s + dur}")
+            t = max(t, s + dur)
+    f = tmp_path / "trace.csv"
+    f.write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "timeline.py"), str(f)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "step = 4 kernels" in out.stdout and "k_rows<7, 4, 1>" in out.stdout and "union of kernel intervals" in out.stdout
