@@ -216,6 +216,9 @@ def main():
                     help="default: strong for the Power / Boston workloads (north_star: the same problem on 1/2/4/8 GPUs), "
                          "weak for the airline workloads (a rank's 250 k rows are 1/8 of configs[4])")
     ap.add_argument("--capture-allreduce", action="store_true", help="capture the collective inside the HIP graph")
+    ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
+                    help="torch: torch.distributed.all_reduce between two graphs (default); abi: the C ABI's tgp_allreduce_f64 "
+                         "(RCCL on the compute stream, inside the captured step, U steps per graph launch); needs backend nccl")
     ap.add_argument("--replicas", type=int, default=1, help="(1 GPU only) K independent training runs of the workload on K "
                     "streams, value = their aggregate steps/s: how the chip is filled when several UCI splits train at once")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
@@ -274,7 +277,8 @@ def main():
         Xr, Yr, n_global = prob["X"][lo:hi], prob["Y"][lo:hi], w["N"]
     eng = ElboEngine(Xr, Yr, params, N_total=float(n_global), flow_blocks=prob["program"],
                      S=w["S"], device=dev, world_size=world, rank=rank, mb_global=n_global,
-                     mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None)
+                     mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None,
+                     collective=args.collective if world > 1 else "torch")
 
     def barrier():
         if world > 1:
@@ -317,7 +321,7 @@ def main():
                     (ek.step if args.no_graph else ek.replay)()
     # K steps: single-rank graph runs go through the engine's unrolled graph (U steps per graph launch, the remainder one
     # by one -- engine.replay_many; `config.launch` names U); everything else step by step
-    many = (not args.no_graph) and not extra and world == 1 and getattr(eng, "gU", None) is not None
+    many = (not args.no_graph) and not extra and (world == 1 or eng.comm is not None) and getattr(eng, "gU", None) is not None
 
     def run_steps(k):
         if many:
@@ -386,6 +390,7 @@ def main():
               "backend": torch.distributed.get_backend() if world > 1 else None,
               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
               "allreduce": ("none" if world == 1 else ("in-graph" if eng.graph == "full" else "between two graphs")),
+              "collective": ("tgp_allreduce_f64 (C ABI, compute stream)" if eng.comm is not None else "torch.distributed"),
               "allreduce_doubles": eng.fp.n + eng.fp.extra}
         result = {
             # BASELINE.json's metric string for the configuration it is quoted on; other workloads say what they are

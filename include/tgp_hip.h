@@ -46,6 +46,7 @@ extern "C" {
 #define TGP_E_WORKSPACE (-101)   /* workspace too small                                        */
 #define TGP_E_LDS (-102)         /* flow program too large for one CU's LDS                    */
 #define TGP_E_LAUNCH (-103)      /* hipLaunchKernel failed; see tgp_last_error()               */
+#define TGP_E_COMM (-104)        /* RCCL not loaded / an RCCL call failed; see tgp_last_error() */
 
 /* ---- flow program (models/flow.py CompositeFlow.forward :155-158) -------------------------------
  * A flow is a sequence of `nblk` blocks; block b is four int32: {kind, K, poff, flags}.
@@ -346,6 +347,22 @@ int tgp_adam_dev_f64(double* params, const double* grads, double* exp_avg, doubl
 int tgp_adam_dev_groups_f64(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n,
                             double lr, double beta1, double beta2, double eps, int64_t n_plain, double weight_decay_tail,
                             int32_t* step_dev, int32_t maximize, void* stream);
+
+/* ---- the collective of the data-parallel step (ONE sum all-reduce of the flat [gradients | ELBO, ELL, KL]
+ * buffer per step over RCCL / xGMI; the reference itself is single-device, trainers/trainer_base.py:329-349) ----
+ * One process per GPU, one communicator per process.  RCCL is bound at run time: tgp_comm_load(path) dlopens it
+ * (NULL = "librccl.so" by the loader's rules; a process that imported torch already holds torch/lib/librccl.so), every
+ * other entry point of this library works without it.  Rank 0 draws a 128-byte id (tgp_comm_unique_id), the host
+ * distributes it (any channel: a file, MPI, torch.distributed's store), every rank calls tgp_comm_init on its device;
+ * tgp_allreduce_f64 sums `buf` (n doubles, device memory) in place across the ranks ON `stream` -- stream-ordered like
+ * the kernels, valid under stream capture, so the step [kernels -> all-reduce -> Adam] can be ONE captured graph with
+ * no side stream.  The C ABI's counterpart of engine.allreduce_flat (torch.distributed, backend nccl = RCCL), which
+ * stays the default of the Python engine.  Errors: TGP_E_COMM + tgp_last_error(). */
+int tgp_comm_load(const char* rccl_path);
+int tgp_comm_unique_id(void* id128);
+int tgp_comm_init(const void* id128, int32_t nranks, int32_t rank, void** comm);
+int tgp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream);
+int tgp_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

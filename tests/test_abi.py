@@ -29,7 +29,8 @@ def test_header_declares_the_documented_surface():
                  "tgp_ell_gauss_f64", "tgp_ell_flow_f64", "tgp_flow_eval_f64", "tgp_predict_f64", "tgp_adam_f64",
                  "tgp_workspace_bytes", "tgp_version",
                  # SURVEY 8(b)'s minimum export set: the two stand-alone adjoints (round 3)
-                 "tgp_qf_moments_bwd_f64", "tgp_cholesky_bwd_f64", "tgp_elbo_step_adam_f64", "tgp_mlp_backward_adam_f64"):
+                 "tgp_qf_moments_bwd_f64", "tgp_cholesky_bwd_f64", "tgp_elbo_step_adam_f64", "tgp_mlp_backward_adam_f64",
+                 "tgp_comm_load", "tgp_comm_unique_id", "tgp_comm_init", "tgp_allreduce_f64", "tgp_comm_destroy"):
         assert must in syms
 
 

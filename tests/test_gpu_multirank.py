@@ -86,3 +86,47 @@ def test_bench_starts_its_own_ranks():
     pg = res["config"]["process_group"]
     assert pg["world_size"] == 2 and pg["backend"] == "gloo" and pg["allreduce"] == "between two graphs"
     assert res["value"] > 0 and res["config"]["final_elbo"] == res["config"]["final_elbo"]
+
+
+@pytest.mark.gpu
+def test_abi_collective_one_rank_eager_and_in_graph():
+    """tgp_comm_* / tgp_allreduce_f64 (RCCL bound at run time, on the caller's stream): a 1-rank communicator -- what one
+    GPU can reach -- sums a buffer to itself, eagerly and as a node of a captured graph; an engine built with
+    collective='abi' runs pre-division, the ABI's all-reduce and the ELBO fix-up INSIDE its (unrolled) graph and walks the
+    same Adam trajectory as the plain single-rank engine, bit for bit."""
+    import torch
+    from tgp.pytorch_amd.engine import CAPTURE_MODE, ElboEngine, RcclComm
+    from oracle import tgp_oracle as orc
+    comm = RcclComm(1, 0)
+    x = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+    comm.allreduce(x, 1000)
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+            x.mul_(2.0)
+            comm.allreduce(x, 1000)
+            x.add_(1.0)
+        for _ in range(3):
+            g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64) * 8 + 7)
+    prob = orc.synthetic_problem(700, 4, 40, seed=2, flow="tanh2x2", S=16)
+    hist = {}
+    for name, kw in (("plain", {}), ("abi", {"collective": comm})):
+        eng = ElboEngine(prob["X"], prob["Y"], prob["params"], N_total=700.0, flow_blocks=prob["program"], S=16, **kw)
+        h = []
+        for _ in range(3):
+            eng.step()
+            h.append(eng.scalars())
+        eng.capture(unroll=4)
+        assert eng.graph == "full" and eng.gU is not None
+        out = torch.zeros(9, 3, dtype=torch.float64, device="cuda:0")
+        eng.replay_many(9, out)
+        torch.cuda.synchronize()
+        hist[name] = (h, out.cpu(), eng.fp.data.clone().cpu())
+    assert hist["plain"][0] == hist["abi"][0]
+    assert torch.equal(hist["plain"][1], hist["abi"][1]) and torch.equal(hist["plain"][2], hist["abi"][2])
+    comm.close()

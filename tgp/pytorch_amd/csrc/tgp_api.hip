@@ -2,6 +2,7 @@
 // Argument checking, plan/workspace bookkeeping and the launch sequence of one ELBO step:
 //   M <= 128 : k_prep_a -> k_rows<MT,DP,MODE> -> k_reduce -> k_bwd12 -> k_bwd34 -> k_bwd5   (6 launches, no host sync)
 //   M  > 128 : the chunked GEMM pipeline of tgp_big.hip (same entry points, chosen by M / kernel)
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include "tgp_dev.hpp"
@@ -14,6 +15,13 @@ static thread_local char g_err[256] = "";
 int set_error(hipError_t e, const char* file, int line) {
   snprintf(g_err, sizeof(g_err), "%s:%d: %s", file, line, hipGetErrorString(e));
   return TGP_E_LAUNCH;
+}
+
+void set_error_text(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
 }
 
 static int check_model(const tgp_model* m, bool need_lik) {
@@ -541,6 +549,33 @@ int tgp_mlp_backward_adam_f64(const tgp_mlp* mlp, const double* X, double* W, co
   ad.step_dev = adam->step_dev;
   return launch_mlp_backward(*mlp, X, W, step_dev, g_out, g_W, static_cast<double*>(workspace),
                              workspace_bytes / sizeof(double), static_cast<hipStream_t>(stream), &ad, weight_decay);
+}
+
+int tgp_comm_load(const char* rccl_path) { return comm_load(rccl_path); }
+
+int tgp_comm_unique_id(void* id128) {
+  if (!id128) return -1;
+  return comm_unique_id(id128);
+}
+
+int tgp_comm_init(const void* id128, int32_t nranks, int32_t rank, void** comm) {
+  if (!id128) return -1;
+  if (nranks < 1) return -2;
+  if (rank < 0 || rank >= nranks) return -3;
+  if (!comm) return -4;
+  return comm_init(id128, nranks, rank, comm);
+}
+
+int tgp_allreduce_f64(void* comm, double* buf, int64_t n, void* stream) {
+  if (!comm) return -1;
+  if (!buf) return -2;
+  if (n < 1) return -3;
+  return comm_allreduce(comm, buf, n, static_cast<hipStream_t>(stream));
+}
+
+int tgp_comm_destroy(void* comm) {
+  if (!comm) return -1;
+  return comm_destroy(comm);
 }
 
 }  // extern "C"

@@ -5,6 +5,14 @@
 namespace tgp {
 
 int set_error(hipError_t e, const char* file, int line);  // records tgp_last_error(), returns TGP_E_LAUNCH
+void set_error_text(const char* fmt, ...);                // records tgp_last_error()
+
+// tgp_comm.hip (RCCL bound at run time)
+int comm_load(const char* path);
+int comm_unique_id(void* id128);
+int comm_init(const void* id128, int nranks, int rank, void** comm);
+int comm_allreduce(void* comm, double* buf, int64_t n, hipStream_t st);
+int comm_destroy(void* comm);
 
 // Raise a kernel's dynamic-LDS ceiling when a launch needs more than the 64 KiB default (gfx950: 160 KiB/CU).
 // `cur` is the caller's per-kernel high-water mark.  Returns 0 or TGP_E_LDS.

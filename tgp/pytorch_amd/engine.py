@@ -43,6 +43,39 @@ def allreduce_flat(grad, n, world_size, group=None):
     return grad
 
 
+class RcclComm:
+    """The C ABI's collective (tgp_comm_* / tgp_allreduce_f64: RCCL bound at run time, all-reduce on the CALLER's stream).
+    One per process.  Rank 0 draws the 128-byte id; with more than one rank it travels through torch.distributed's
+    object broadcast (any backend: it is a host-side exchange), so the bootstrap needs no second rendezvous."""
+
+    def __init__(self, world_size=1, rank=0, group=None):
+        import ctypes as C
+        self.lib = L.load()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")   # the RCCL this process already holds
+        L.check(self.lib.tgp_comm_load(path.encode() if os.path.exists(path) else None), "tgp_comm_load")
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            L.check(self.lib.tgp_comm_unique_id(C.cast(uid, C.c_void_p)), "tgp_comm_unique_id")
+        if world_size > 1:
+            box = [bytes(uid.raw)]
+            torch.distributed.broadcast_object_list(box, src=0, group=group)
+            uid.raw = box[0]
+        self.comm = C.c_void_p()
+        L.check(self.lib.tgp_comm_init(C.cast(uid, C.c_void_p), int(world_size), int(rank), C.byref(self.comm)), "tgp_comm_init")
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def allreduce(self, buf, n=None):
+        """In-place sum of the first n doubles of `buf` over the ranks, on the current stream (capturable)."""
+        n = buf.numel() if n is None else int(n)
+        L.check(self.lib.tgp_allreduce_f64(self.comm, L.ptr(buf), n, L.stream_ptr()), "tgp_allreduce_f64")
+        return buf
+
+    def close(self):
+        if self.comm:
+            L.check(self.lib.tgp_comm_destroy(self.comm), "tgp_comm_destroy")
+            self.comm = None
+
+
 def pre_reduce(grad, n, world_size):
     """KL is identical on every rank: pre-divide so that the sum restores it."""
     grad[n + 2].div_(world_size)
@@ -96,7 +129,7 @@ class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
                  eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
                  kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True,
-                 jitter_ladder=1e-8, share=None):
+                 jitter_ladder=1e-8, share=None, collective=None):
         """`mlp` (ops.MlpSpec) + `mlp_weights` (packed, nnets * weights_per_net): input-dependent flow (ID_TGP) whose
         per-row parameters come from the HIP MLP kernels inside the step; `nn_weight_decay` is the reference's Adam
         group for the 'NNets' parameters (main.py:276-288).  `share` = another ElboEngine of the same model whose flat
@@ -104,6 +137,18 @@ class ElboEngine:
         self.lib = L.load()
         self.device = torch.device(device)
         self.world_size, self.rank, self.pg = int(world_size), int(rank), process_group
+        # `collective`: "torch" (default) = torch.distributed.all_reduce between two graphs; "abi" = tgp_allreduce_f64 on the
+        # compute stream, INSIDE the captured step (one graph, U steps per launch like a single rank's) -- an RcclComm or
+        # the string (a communicator is then created here; torch.distributed only carries its 128-byte id).  With "abi" a
+        # 1-rank engine runs the collective too (sum over one rank): the path the GPU tests can reach on one GPU.
+        collective = collective if collective is not None else os.environ.get("TGP_COLLECTIVE", "torch")
+        self.comm = None
+        if isinstance(collective, RcclComm):
+            self.comm = collective
+        elif collective == "abi":
+            self.comm = RcclComm(self.world_size, self.rank, process_group)
+        elif collective != "torch":
+            raise ValueError("collective must be 'torch', 'abi' or an RcclComm")
         self.X = X.to(self.device, torch.float64).contiguous()
         self.Y = Y.reshape(-1).to(self.device, torch.float64).contiguous()
         self.N, self.D = self.X.shape
@@ -159,7 +204,8 @@ class ElboEngine:
             self.mlp_ws = torch.empty(self.lib.tgp_mlp_workspace_bytes(d) // 8 + 16, dtype=torch.float64, device=self.device)
         # One rank, shared flow parameters only: ELBO step + Adam in ONE C-ABI call (tgp_elbo_step_adam_f64: on the fused
         # path the update rides in the last two backward launches -- one launch and one pass over the buffers less)
-        self.fused_adam = self.world_size == 1 and self.mlp is None and os.environ.get("TGP_FUSED_ADAM", "1") != "0"
+        self.fused_adam = (self.world_size == 1 and self.comm is None and self.mlp is None
+                           and os.environ.get("TGP_FUSED_ADAM", "1") != "0")
         self.ad = L.TgpAdamArgs()
         self.ad.params, self.ad.grads = L.ptr(fp.data), L.ptr(fp.grad)
         self.ad.exp_avg, self.ad.exp_avg_sq = L.ptr(fp.exp_avg), L.ptr(fp.exp_avg_sq)
@@ -198,6 +244,11 @@ class ElboEngine:
         self._warm = True
 
     def allreduce(self):
+        if self.comm is not None:
+            pre_reduce(self.fp.grad, self.fp.n, self.world_size)
+            self.comm.allreduce(self.fp.grad, self.fp.n + self.fp.extra)
+            post_reduce(self.fp.grad, self.fp.n)
+            return
         allreduce_flat(self.fp.grad, self.fp.n, self.world_size, self.pg)
 
     def adam(self):
@@ -300,7 +351,8 @@ class ElboEngine:
         torch.cuda.synchronize()
         pre = self.pre_step if self.pre_step is not None else (lambda: None)
         post = self.post_step if self.post_step is not None else (lambda: None)
-        if self.mlp is not None and self.world_size == 1 and self.pipeline_steps and self.pre_step is None:
+        if (self.mlp is not None and self.world_size == 1 and self.comm is None and self.pipeline_steps
+                and self.pre_step is None):
             # Rotated unit.  The long pole of an ID_TGP step is the MLP backward (97 us), and nothing of step t depends on it
             # except the network weights' own Adam update and the NEXT step's MLP forward.  So the captured unit starts
             # at the row kernel:   main: rows(t) -> M x M adjoint(t) -> Adam(GP params) -> prepare(t+1)
@@ -343,7 +395,7 @@ class ElboEngine:
             self._capture_unrolled(unit, unroll)
             self.graph = "rotated"
             return
-        if self.world_size > 1 and not with_allreduce:
+        if self.world_size > 1 and not with_allreduce and self.comm is None:
             # [graph 1: step kernels + KL pre-division] -> RCCL all-reduce -> [graph 2: ELBO fix-up + Adam]
             self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
@@ -368,7 +420,7 @@ class ElboEngine:
             self.g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g1, capture_error_mode=CAPTURE_MODE):
                 unit()
-            if self.world_size == 1:
+            if self.world_size == 1 or self.comm is not None:   # (the ABI's all-reduce is a node of the graph like any kernel)
                 self._capture_unrolled(unit, unroll)
             self.graph = "full"
 

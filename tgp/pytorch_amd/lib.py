@@ -70,6 +70,11 @@ _SIGS = {
     "tgp_qf_moments_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, _dp, C.c_size_t, _dp]),
     "tgp_mlp_backward_adam_f64": (C.c_int, [C.POINTER(TgpMlp), _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, C.POINTER(TgpAdamArgs),
                                             C.c_double, _dp]),
+    "tgp_comm_load": (C.c_int, [C.c_char_p]),
+    "tgp_comm_unique_id": (C.c_int, [_dp]),
+    "tgp_comm_init": (C.c_int, [_dp, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "tgp_allreduce_f64": (C.c_int, [_dp, _dp, C.c_int64, _dp]),
+    "tgp_comm_destroy": (C.c_int, [_dp]),
     "tgp_qf_moments_bwd_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, C.c_size_t, _dp]),
     "tgp_kmm_f64": (C.c_int, [_dp, _dp, _dp, C.c_int32, C.c_int32, C.c_double, _dp, _dp]),
     "tgp_knm_f64": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]),
