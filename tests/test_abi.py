@@ -100,3 +100,19 @@ def test_host_only_queries_of_the_newer_entry_points(lib):
     m1, m2 = ops.mlp_keep_mask(7, 3, 0, 1, 2000, 50, 0.25), ops.mlp_keep_mask(7, 3, 0, 1, 2000, 50, 0.25)
     assert (m1 == m2).all() and abs(m1.mean() - 0.75) < 0.01
     assert (ops.mlp_keep_mask(7, 4, 0, 1, 2000, 50, 0.25) != m1).mean() > 0.2
+
+
+def test_collective_entry_points_fail_cleanly_without_rccl(lib):
+    """RCCL is bound at run time: before tgp_comm_load (or when the path does not exist) the collective entries return
+    TGP_E_COMM with a message -- no crash, no GPU call, and nothing else of the library depends on it."""
+    import ctypes as C
+    lib.tgp_comm_unique_id.restype = C.c_int
+    lib.tgp_comm_unique_id.argtypes = [C.c_void_p]
+    lib.tgp_comm_load.restype = C.c_int
+    lib.tgp_comm_load.argtypes = [C.c_char_p]
+    lib.tgp_last_error.restype = C.c_char_p
+    buf = (C.c_char * 128)()
+    assert lib.tgp_comm_unique_id(C.cast(buf, C.c_void_p)) == -104          # TGP_E_COMM: not loaded
+    assert lib.tgp_comm_load(b"/nonexistent/librccl.so") == -104
+    assert b"librccl.so" in lib.tgp_last_error()
+    assert lib.tgp_comm_unique_id(None) == -1
