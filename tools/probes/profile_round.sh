@@ -10,7 +10,7 @@ D="$R/$O"                       # every rocprofv3 output directory below is a fr
 fresh() { mkdir -p "$D/$1.new" && mv "$D/$1.new" "$D/$1.$$" 2>/dev/null; echo "$D/$1.$$"; }
 SH=$(python -c "from tgp.pytorch_amd import lib; print(lib.source_hash())")
 echo "source hash $SH"
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $O/tests.log
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error|warnings summary" | tail -4 > $O/tests.log   # (RCCL prints its banner after pytest's summary)
 cat $O/tests.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 # ---- per-launch HBM bytes of the dominant kernel (separate FETCH_SIZE / WRITE_SIZE passes), keyed by the source hash ----
