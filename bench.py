@@ -412,6 +412,9 @@ def main():
             result["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds, mlp=mlp)
     if world > 1:
         torch.distributed.barrier()
+        if eng.comm is not None:
+            torch.cuda.synchronize()
+            eng.comm.close()
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
