@@ -51,7 +51,8 @@ struct Plan {
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
   // workspace offsets (doubles)
   size_t hdr, ils, ls, Zs, mpad, w, tp, tg;
-  size_t Kmm, L, J, JT, Lq, LqT, S_, HpT, Q;
+  size_t Kmm, L, J, LT, Lq, LqT, S_, HpT, Q;
+  size_t nD;     // MT x 256: minus the inverses of the diagonal tiles of L (row-major 16 x 16, zero above the diagonal)
   size_t Gp;     // TGP_RSPLIT partial sums of G, each expanded to a full symmetric MP x MP matrix
   size_t redp;   // TGP_RSPLIT partial sums of the slab tail (T, s, scalars); slab layout, G part unused
   size_t PP;     // MT x MP x PPW per-row-block partials of (Kbar_MM o K_MM) [Zs, 1]
@@ -93,8 +94,9 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.w = o; o += p.MP;
   p.tp = o; o += rup(P + 1, 16);
   p.tg = o; o += rup(P + 1, 16);
-  p.Kmm = o; o += mm; p.L = o; o += mm; p.J = o; o += mm; p.JT = o; o += mm;
+  p.Kmm = o; o += mm; p.L = o; o += mm; p.J = o; o += mm; p.LT = o; o += mm;
   p.Lq = o; o += mm; p.LqT = o; o += mm; p.S_ = o; o += mm; p.HpT = o; o += mm; p.Q = o; o += mm;
+  p.nD = o; o += (size_t)p.MT * 256;
   p.Gp = o; o += TGP_RSPLIT * mm;
   p.redp = o; o += TGP_RSPLIT * p.slab_len;
   p.PPW = p.DP + 2;

@@ -53,10 +53,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       ws[p.Lq + (size_t)row * MP + col] = lq;
       ws[p.LqT + (size_t)col * MP + row] = lq;
       ws[p.Kmm + (size_t)row * MP + col] = k;
-      if (tj > ti) {  // strictly-upper tile: zero in L and J; its mirror (tj, ti) is zero in J^T
+      if (tj > ti) {  // strictly-upper tile: zero in L and in J = L^-1 (formed by the row kernel's passenger blocks)
         ws[p.L + (size_t)row * MP + col] = 0.0;
         ws[p.J + (size_t)row * MP + col] = 0.0;
-        ws[p.JT + (size_t)col * MP + row] = 0.0;
       }
     }
     if (wave == 4) {  // S tile on a wave that did no copy work
@@ -150,9 +149,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // rounds 1-2 (10 k cycles per block column measured).
   constexpr int NW = PREP_THREADS / 64;
   const int LD = MP + 1;
-  double* A = sm;                            // MP x LD: lower = K_MM -> L ; strict-upper TILES hold J^T tiles
-  double* Dt = sm + (size_t)MP * LD;         // MT x 256: inverses of the diagonal tiles (row-major, zero above diag)
-  double* zs = Dt + (size_t)MT * 256;        // MP x DP scaled inducing points, present when p.zs_lds (LDS budget allows)
+  double* A = sm;                            // MP x LD: lower = K_MM -> L
+  double* zs = sm + (size_t)MP * LD;         // MP x DP scaled inducing points, present when p.zs_lds (LDS budget allows)
   __shared__ int s_info, s_nan, s_next;
   __shared__ double s_ils[16];
   if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; }
@@ -205,42 +203,32 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
                      kend, acc);
   };
-  // inverse tile (j, c), c < j:  J_jc = -Dinv_j sum_{c<=kb<j} L_j,kb J_kb,c   (stored transposed in the upper tile (c, j))
-  auto inv_tile = [&](int j, int c) {
-    const int j0 = 16 * j, c0 = 16 * c;
-    d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; }, [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; },
-                    0, 16, acc);                                                       // kb == c: J_cc = Dinv_c
-    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
-                    c0 + 16, j0, acc);                                                 // kb > c: transposed upper tiles
-    double dj[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) dj[s4] = Dt[j * 256 + r * 16 + 4 * s4 + q];
-    d4 out = {0, 0, 0, 0};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) out = TGP_MFMA(dj[s4], acc[s4], out);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
-  };
-  // Write-out of lower tile (ti, tj): L, J and the J^T tile (tj, ti), by one wave, 128-byte row segments.  A single CU
-  // stores at ~30-50 GB/s, so block 0 writes only what is non-zero (the structurally-zero tiles are written by the
-  // otherwise idle tile blocks of this launch) and it does so DURING the factorisation, in the shadow of the chain.
-  // (A retry of the jitter ladder simply stores again.)
+  // Write-out of lower tile (ti, tj) of L and of the tile (tj, ti) of L^T, by one wave, 128-byte row segments.  A single
+  // CU stores at ~30-50 GB/s, so the chain blocks write only what is non-zero (the structurally-zero tiles of L are
+  // written by the otherwise idle tile blocks of this launch) and they do so DURING the factorisation, in the shadow of
+  // the chain.  (A retry of the jitter ladder simply stores again.)
   auto write_L = [&](int ti, int tj) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
       ws[p.L + (size_t)rr * MP + cc] = (ti != tj || cc <= rr) ? A[rr * LD + cc] : 0.0;
+      // L^T tile (tj, ti): element [16 tj + q+4u][16 ti + r] = L[16 ti + r][16 tj + q+4u]
+      const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
+      ws[p.LT + (size_t)rt * MP + ct] = (ti != tj || rt <= ct) ? A[ct * LD + rt] : 0.0;
     }
   };
-  auto write_J = [&](int ti, int tj) {
+  // minus the inverse of the finished diagonal tile jt -> workspace (the row kernel closes every substitution step with
+  // it, tgp_rows.hpp): one wave, trtri16 on its own copy of L_jj, one window behind the factorisation and off its chain
+  auto inv_diag = [&](int jt) {
+    const int li = lane & 15;
+    double dgv[16], xv[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      ws[p.J + (size_t)rr * MP + cc] = (ti == tj) ? Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)] : A[cc * LD + rr];
-      // J^T tile (tj, ti), rows = cols of the J tile: element [16 tj + q+4u][16 ti + r] = J[16 ti + r][16 tj + q+4u]
-      const int rt = 16 * tj + q + 4 * u, ct = 16 * ti + r;
-      ws[p.JT + (size_t)rt * MP + ct] = (ti == tj) ? Dt[ti * 256 + (ct & 15) * 16 + (rt & 15)] : A[rt * LD + ct];
+    for (int c = 0; c < 16; ++c) dgv[c] = A[(16 * jt + li) * LD + 16 * jt + c];
+    trtri16(dgv, xv, li);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // xv[c] = Dinv[c][li]; the four 16-lane rows hold the same values: row q stores columns 4u + q
+      const double xv4 = q == 0 ? xv[4 * u] : (q == 1 ? xv[4 * u + 1] : (q == 2 ? xv[4 * u + 2] : xv[4 * u + 3]));
+      ws[p.nD + jt * 256 + (4 * u + q) * 16 + li] = -xv4;
     }
   };
   // tile (i, c) -= L[i rows, k0 .. k0+15] L[c rows, k0 .. k0+15]^T : one block column's contribution, 4 MFMAs
@@ -304,14 +292,15 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
       bool did_diag = false;
       // ---- phase P ----
       if (wave < npw || (npw == 0 && wave == 0)) {
-        // block column j of L: this wave's own copy of the diagonal tile + 64 rows of the panel below it; wave 0 also
-        // carries the tile's inverse in the pass's shadow (4.3 k cycles against 3.4 k without it -- and one 4.6 k-cycle
-        // task less for the other waves, which are bound by instruction issue) and owns L_jj and Dinv_j
+        // block column j of L: this wave's own copy of the diagonal tile + 64 rows of the panel below it; wave 0 owns L_jj.
+        // (Round 4: the tile's inverse is no longer carried in this pass -- nothing on the chain needs it any more, a task
+        //  wave forms it one window later (inv_diag) -- so the pass is 3.4 k cycles instead of 4.3 k, and the 48 live
+        //  doubles of the three-array form no longer spill inside the chain.)
         __builtin_amdgcn_s_setprio(3);   // the chain: wins instruction issue against its SIMD partner's task work
         const int li = lane & 15, l0 = wave * 64 + lane;
         const bool has = l0 < npan;
         const int prow = j0 + (npan > 0 ? 16 : 0) + (has ? l0 : 0);
-        double dg[16], a[16], x[16];
+        double dg[16], a[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
         if (npan > 0) {
@@ -323,12 +312,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #endif
         PSTAMP(1);
         int bad = 0;
-        if (wave == 0) {
-          if (npan > 0) bad = potrf_panel16<true, true>(dg, a, x, li);
-          else bad = potrf_panel16<false, true>(dg, a, x, li);
-        } else {
-          (void)potrf_panel16<true>(dg, a);
-        }
+        if (npan > 0) bad = potrf_panel16<true>(dg, a);
+        else bad = potrf_panel16<false>(dg, a);
 #ifdef TGP_STAMPS
         asm volatile("" ::"v"(dg[15]), "v"(a[15]));
 #endif
@@ -339,11 +324,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         }
         if (wave == 0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {  // the four 16-lane rows hold the same dg[], x[]: row q keeps the columns 4u + q
+          for (int u = 0; u < 4; ++u)   // the four 16-lane rows hold the same dg[]: row q keeps the columns 4u + q
             ltile[u] = q == 0 ? dg[4 * u] : (q == 1 ? dg[4 * u + 1] : (q == 2 ? dg[4 * u + 2] : dg[4 * u + 3]));
-            const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-            Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;  // x[c] = Dinv[c][li]
-          }
           did_diag = true;   // L_jj goes to LDS after the window's barrier: the other panel wave reads the tile's input
           if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
         }
@@ -362,30 +344,29 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         // the last barrier and the tasks of one window are independent of each other, so any wave may run any of them;
         // dealt round-robin the windows were as long as the unluckiest wave's share):
         //   tile (i, j+2)  = K_MM - block columns 0 .. j-1 (its first value)       i = j+2 .. MT-1   [j = 0: columns 1, 2]
-        //   tiles (j-1, c), c < j-1, of J = L^-1    (Dinv_{j-1}: last window's)
-        //   write-out of J / J^T row j-2
         //   tile (i, j+1) -= block column j-1                                      i = j+1 .. MT-1
-        //   write-out of L row j-1
+        //   write-out of L / L^T row j-1
+        // (round 4: no tile of J = L^-1 is formed here any more -- the row kernel solves with L itself, and J for the
+        //  backward M x M chain comes from its passenger blocks)
         const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
         // (tile columns of this block's parity: c = 2 t + cb below `n` -> (n + 1 - cb) / 2 of them)
-        const int nf = j == 0 ? n1 + n2 : n2, ni = j >= 1 ? (j - cb) / 2 : 0, nwj = j >= 2 ? (j - cb) / 2 : 0;
+        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;   // inverse of diagonal tile j-1 (tile column of this block's parity)
+        const int nf = j == 0 ? n1 + n2 : n2;
         const int ns = j >= 1 ? n1 : 0, nwl = (j + 1 - cb) / 2;
-        const int ntask = nf + ni + nwj + ns + nwl;
+        const int ntask = nt + nf + ns + nwl;
         for (;;) {
           int t = 0;
           if (lane == 0) t = atomicAdd(&s_next, 1);
           t = __builtin_amdgcn_readfirstlane(t) - tbase;
           if (t >= ntask) break;
+          if (t < nt) { inv_diag(j - 1); continue; }
+          t -= nt;
           if (t < nf) {
             if (j == 0) { if (t < n1) fill_tile(1 + t, 1, 0); else fill_tile(2 + (t - n1), 2, 0); }
             else fill_tile(j + 2 + t, j + 2, j);
             continue;
           }
           t -= nf;
-          if (t < ni) { inv_tile(j - 1, 2 * t + cb); continue; }
-          t -= ni;
-          if (t < nwj) { write_J(j - 2, 2 * t + cb); continue; }
-          t -= nwj;
           if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
           t -= ns;
           write_L(j - 1, 2 * t + cb);
@@ -395,8 +376,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         if (j == 0) PSTAMP(7); else PSTAMP(8);
 #endif
       }
-      tbase += (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) + (j >= 1 ? (j - cb) / 2 : 0) +
-               (j >= 2 ? (j - cb) / 2 : 0) + (j >= 1 ? MT - 1 - j : 0) + (j + 1 - cb) / 2 +
+      tbase += ((j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0) + (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) +
+               (j >= 1 ? MT - 1 - j : 0) + (j + 1 - cb) / 2 +
                (NW - 1 - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
       PREP_BARRIER();
       PSTAMP(4);
@@ -423,19 +404,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     jit = md.jitter + md.jitter_ladder * (attempt == 0 ? 1.0 : (attempt == 1 ? 10.0 : 100.0));
     __syncthreads();
   }
-  // ---- tail: J row MT-1 (Dinv_{MT-1} came with the last window), the last write-outs ----
-  {
-    // (tile columns c = 2 t + cb: of the n columns [0, n) this block owns (n + 1 - cb) / 2)
-    const int ni = (MT - cb) / 2, nwl = (MT + 1 - cb) / 2, nwj = MT >= 2 ? (MT - cb) / 2 : 0;
-    const int ntask = ni + nwl + nwj;
-    for (int t = wave; t < ntask; t += NW) {
-      if (t < ni) inv_tile(MT - 1, 2 * t + cb);
-      else if (t < ni + nwl) write_L(MT - 1, 2 * (t - ni) + cb);
-      else write_J(MT - 2, 2 * (t - (ni + nwl)) + cb);
-    }
-    PREP_BARRIER();
-    for (int t = wave; t < (MT + 1 - cb) / 2; t += NW) write_J(MT - 1, 2 * t + cb);
-  }
+  // ---- tail: the last diagonal tile's inverse, the last tile row of L / L^T (tile columns c = 2 t + cb: of the MT columns
+  //      this block owns (MT + 1 - cb) / 2) ----
+  if (((MT - 1) & 1) == cb && wave == NW - 1) inv_diag(MT - 1);
+  for (int t = wave; t < (MT + 1 - cb) / 2; t += NW) write_L(MT - 1, 2 * t + cb);
   PSTAMP(9);
 #ifdef TGP_STAMPS
   if (lane == 0) {
@@ -455,7 +427,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 }
 
 size_t prep_a_lds_bytes(const Plan& p) {
-  return ((size_t)p.MP * (p.MP + 1) + (size_t)p.MT * 256 + (p.zs_lds ? (size_t)p.MP * p.DP : 0) + 16) * sizeof(double);
+  return ((size_t)p.MP * (p.MP + 1) + (p.zs_lds ? (size_t)p.MP * p.DP : 0) + 16) * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -4,11 +4,16 @@
 // Replaces, per minibatch row n (reference: models/sparse_MF_SP.py:313-396, likelihoods/*.py,
 // models/flow.py and the autograd replay of all of it, trainers/trainer_base.py:341):
 //   K_n  = sigma^2 exp(-1/2 |xs_n - zs_j|^2)                 never written to HBM
-//   A    = L^-1 K_MN      (J K, lower-triangular MFMA GEMM)  reference: triangular_solve :380
+//   A    = L^-1 K_MN      (forward substitution on MFMA)     reference: triangular_solve :380
 //   B    = L_q^T A        (upper-triangular MFMA GEMM)       reference: S = LqLq^T, matmul(S, rhs) :346,382
 //   mu   = m^T A ;  v = sigma^2 - sum A^2 + sum B^2          reference: :354-355, :376-382
 //   ell_n, d ell/d mu, d ell/d v, d ell/d theta, d ell/d eta  Gauss-Hermite through the flow (or closed form)
-//   Abar = m mubar^T - 2 A vbar + 2 L_q (B vbar) ; Kbar = L^-T Abar   (two more triangular MFMA GEMMs)
+//   Abar = m mubar^T - 2 A vbar + 2 L_q (B vbar) ; Kbar = L^-T Abar   (triangular MFMA GEMM + back substitution)
+// The two solves with L are SUBSTITUTIONS over 16-row tiles (round 4): A_i = Dinv_i (K_i - sum_{kb<i} L_i,kb A_kb) and
+// Kbar_i = Dinv_i^T (Abar_i - sum_{kb>i} L_kb,i^T Kbar_kb), the same MT (MT+1)/2 tile products as a product with an
+// explicit J = L^-1 and the reference's own solve shape -- so the prepare launch hands over only L, L^T and the
+// inverses of the 16 x 16 diagonal tiles, and J (which only the backward M x M chain still wants) is formed by this
+// launch's passenger blocks on CUs the row tiles leave idle.
 //   row statistics  G = A diag(vbar) A^T, s = A mubar, T = (Kbar o K) [xs, xs^2, 1]   (MFMA, via LDS transpose)
 // One workgroup = 4 waves = 64 rows; one wave owns 16 rows and keeps K, A, B, Abar, Kbar in registers:
 // the accumulator layout of v_mfma_f64_16x16x4 is directly the B-operand layout of the next product.
@@ -108,6 +113,35 @@ __device__ __forceinline__ d4 mfma_chain(const double* a0, int step0, int nsteps
   return c;
 }
 
+// One tile of a substitution with L (forward or backward): the running right-hand side `c` (accumulator layout) first
+// collects nsum k-steps  c += panel[fa(s)] * fb(s)  (fb = register r of an earlier result tile: the accumulator layout
+// IS the B-operand layout), then the tile closes with the four k-steps of the diagonal block at panel k-step dstep0,
+// whose B operand is c itself:  out = Dblock * c.  With c = -(rhs tile), the panel holding +L and the diagonal block
+// holding -Dinv this is out = Dinv (rhs - sum L x).  Operand reads batched eight ahead of their MFMAs as in mfma_chain.
+template <int MAXSTEPS, class FA, class FB>
+__device__ __forceinline__ d4 subst_chain(const double* a0, int nsum, int dstep0, d4 c, FA fa, FB fb) {
+  d4 out = {0, 0, 0, 0};
+#pragma unroll
+  for (int s0 = 0; s0 < MAXSTEPS; s0 += 8) {
+    double av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u;
+      if (s < nsum) av[u] = a0[fa(s) * 64];
+      else if (s < nsum + 4) av[u] = a0[(dstep0 + s - nsum) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u;
+      if (s < nsum) c = TGP_MFMA(av[u], fb(s), c);
+      else if (s < nsum + 4) out = TGP_MFMA(av[u], c[s - nsum], out);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  }
+  return out;
+}
+
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
 // scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
 template <int MT, int DP, int MODE>
@@ -142,28 +176,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
 
   if (TRAIN && (int)blockIdx.x >= p.nblocks) {
-    // ---- passenger blocks: H'^T = (J^T (S - I))^T tiles and w = J^T m, needed only by the backward M x M chain;
-    //      they run on CUs the row tiles leave idle instead of costing a launch of their own ----
-    const int t = blockIdx.x - p.nblocks;
-    const double* __restrict__ Jg = ws + p.J;
-    if (t == MT * MT) {
-      for (int i = tid; i < MP; i += 256) {
-        double s = 0.0;
-        for (int k = i; k < MP; ++k) s += Jg[(size_t)k * MP + i] * ws[p.mpad + k];
-        a.ws[p.w + i] = s;
-      }
-      return;
-    }
-    if (wave != 0) return;
-    const int ti = t / MT, tj = t % MT;
+    // ---- passenger blocks (one per 16-column block c of J): what only the backward M x M chain needs -- J = L^-1
+    //      (k_bwd34), H'^T = (J^T (S - I))^T (k_bwd12) and w = J^T m -- formed on CUs the row tiles leave idle instead
+    //      of on the prepare launch's critical chain.  Column block c of J is the forward substitution with the unit
+    //      columns 16c .. 16c+15 as right-hand side, J_cc = Dinv_c, J_ic = -Dinv_i sum_{c<=kb<i} L_i,kb J_kb,c : the same
+    //      register chain as the row waves' (a finished tile IS the next product's B operand), every L fragment it
+    //      needs requested up front.  All four waves run the chain (nothing to exchange); wave 0 stores the column of
+    //      J, wave w the tiles (c, w), (c, w+4) of H' -- whose A operand is again the accumulator layout of the J tiles,
+    //      now read as J^T -- and wave 3 the 16 entries of w.
+    const int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x - p.nblocks);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const double* __restrict__ LTg = ws + p.LT;
+    const double* __restrict__ nDg = ws + p.nD;
     const double* __restrict__ Sg = ws + p.S_;
-    d4 hacc = {0, 0, 0, 0};
-    hacc = tile_mm_f<TGP_GBATCH>([&](int k) { return Jg[(size_t)(k + q) * MP + 16 * ti + nl]; },
-                    [&](int k) { return Sg[(size_t)(k + q) * MP + 16 * tj + nl]; }, 16 * ti, MP, hacc);  // (J^T)[i,k]=0, k<i
+    constexpr int NLF = MT > 1 ? MT * (MT - 1) / 2 : 1;
+    double lf[NLF][4], df[MT][4];
+    d4 Jt[MT];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 16 * ti + q + 4 * rr, col = 16 * tj + nl;
-      a.ws[p.HpT + (size_t)col * MP + row] = hacc[rr] - Jg[(size_t)col * MP + row];
+    for (int i = 0; i < MT; ++i) {
+      if (i < c) continue;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) df[i][s4] = nDg[i * 256 + nl * 16 + 4 * s4 + q];   // A operand of -Dinv_i
+#pragma unroll
+      for (int kb = 0; kb < i; ++kb) {
+        if (kb < c) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) lf[i * (i - 1) / 2 + kb][s4] = LTg[(size_t)(16 * kb + 4 * s4 + q) * MP + 16 * i + nl];
+      }
+    }
+    d4 dc;  // Dinv_c in accumulator layout
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) dc[rr] = -nDg[c * 256 + (4 * rr + q) * 16 + nl];
+    double mf[MT][4];  // this lane's entries of m (for w)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) mf[i][rr] = ws[p.mpad + 16 * i + 4 * rr + q];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      Jt[i] = d4{0, 0, 0, 0};
+      if (i < c) continue;
+      if (i == c) { Jt[i] = dc; continue; }
+      d4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < i; ++kb) {
+        if (kb < c) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(lf[i * (i - 1) / 2 + kb][s4], Jt[kb][s4], acc);
+      }
+      d4 o = {0, 0, 0, 0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) o = TGP_MFMA(df[i][s4], acc[s4], o);
+      Jt[i] = o;
+    }
+    if (wv == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < c) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) a.ws[p.J + (size_t)(16 * i + 4 * rr + q) * MP + 16 * c + nl] = Jt[i][rr];
+      }
+    }
+    for (int jj = wv; jj < MT; jj += 4) {
+      double bf[MT][4];
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) {
+        if (kb < c) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int kk = 16 * kb + 4 * s4 + q;
+          bf[kb][s4] = Sg[(size_t)kk * MP + 16 * jj + nl] - (kk == 16 * jj + nl ? 1.0 : 0.0);
+        }
+      }
+      d4 h = {0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < MT; ++kb) {
+        if (kb < c) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) h = TGP_MFMA(Jt[kb][s4], bf[kb][s4], h);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) a.ws[p.HpT + (size_t)(16 * jj + nl) * MP + 16 * c + 4 * rr + q] = h[rr];
+    }
+    if (wv == 3) {
+      double sw = 0.0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < c) continue;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sw += Jt[i][rr] * mf[i][rr];
+      }
+      sw = quad_sum(sw);
+      if (q == 0) a.ws[p.w + 16 * c + nl] = sw;
     }
     return;
   }
@@ -183,42 +287,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const double y = TRAIN ? a.Y[nc] : 0.0;
   const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
 
-  // ---- operand panels: the A operands of the four triangular GEMMs (16 columns x up to MP rows of J^T, Lq, Lq^T, J)
+  // ---- operand panels: the A operands of the four triangular products (16 columns x up to MP rows of L^T, Lq, Lq^T, L)
   //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
-  //      only used after the GEMMs): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out.
+  //      only used after the products): coalesced 128-byte row segments in, conflict-free 512-byte wave reads out.
   //      Panels are prefetched TWO ahead through two register sets (the early panels feed only 4-8 MFMAs, far less
   //      than one L2 round trip), and the first two are requested here, at the top of the kernel: the K tile takes
   //      about 1 us, far less than their round trip.
-  const double* __restrict__ JT = ws + p.JT;
-  const double* __restrict__ Jm = ws + p.J;
+  //      Panel kinds:  0 = lower-type panel i of L^T (rows [0, 16 i)) closed by -Dinv_i^T as row block i   (A = L^-1 K)
+  //                    1 = upper-type panel i of Lq  (rows [16 i, MP))                                      (B = Lq^T A)
+  //                    2 = lower-type panel i of Lq^T (rows [0, 16 (i+1)))                                  (C = Lq (B vbar))
+  //                    3 = upper-type panel i of L (rows [16 (i+1), MP)) headed by -Dinv_i as row block i   (Kbar = L^-T Abar)
+  const double* __restrict__ LTm = ws + p.LT;
+  const double* __restrict__ Lm = ws + p.L;
+  const double* __restrict__ nD = ws + p.nD;
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ LqT = ws + p.LqT;
   double* pan = tile;  // 2 x (MP x 16)
   double stg[2][MT];
-  // panel sequence of one phase: pp < MT -> lower-type panel pp of matrix M1 (rows [0, 16(pp+1)));
-  //                              pp >= MT -> upper-type panel pp-MT of matrix M2 (rows [16 (pp-MT), MP))
   // (row-block u of a panel exists iff u < nb with nb = i+1 (lower) / MT-i (upper): a compile-time predicate once the
   //  tile loops are unrolled -- a `row < r1` test would cost an exec-mask branch around every load and store)
-  auto issue = [&](const double* __restrict__ M1, const double* __restrict__ M2, int pp, double (&st)[MT]) {
-    const bool lower = pp < MT;
-    const int i = lower ? pp : pp - MT;
-    const double* __restrict__ Mt = (lower ? M1 : M2) + (size_t)((lower ? 0 : 16 * i) + (tid >> 4)) * MP + 16 * i + (tid & 15);
+  auto issue = [&](int kind, int i, double (&st)[MT]) {
+    const bool lower = kind == 0 || kind == 2;
+    const double* __restrict__ Mt = (kind == 0 ? LTm : (kind == 1 ? Lq : (kind == 2 ? LqT : Lm))) +
+                                    (size_t)((lower ? 0 : 16 * i) + (tid >> 4)) * MP + 16 * i + (tid & 15);
     const int nb = lower ? i + 1 : MT - i;
 #pragma unroll
     for (int u = 0; u < MT; ++u)
-      if (u < nb) st[u] = Mt[(size_t)16 * u * MP];
+      if (u < nb) {
+        if (kind == 0 && u == i) st[u] = nD[i * 256 + (tid & 15) * 16 + (tid >> 4)];        // (-Dinv_i)^T
+        else if (kind == 3 && u == 0) st[u] = nD[i * 256 + (tid >> 4) * 16 + (tid & 15)];   // -Dinv_i
+        else st[u] = Mt[(size_t)16 * u * MP];
+      }
   };
-  auto commit = [&](int pp, const double (&st)[MT]) {
-    const bool lower = pp < MT;
-    const int i = lower ? pp : pp - MT;
+  auto commit = [&](int par, bool lower, int i, const double (&st)[MT]) {
     const int nb = lower ? i + 1 : MT - i;
-    double* buf = pan + (pp & 1) * (MP * 16) + ((lower ? 0 : 16 * i) + (tid >> 4)) * 16 + (tid & 15);
+    double* buf = pan + par * (MP * 16) + ((lower ? 0 : 16 * i) + (tid >> 4)) * 16 + (tid & 15);
 #pragma unroll
     for (int u = 0; u < MT; ++u)
       if (u < nb) buf[16 * u * 16] = st[u];
   };
-  issue(JT, Lq, 0, stg[0]);
-  if (MT * 2 > 1) issue(JT, Lq, 1, stg[1]);
+  // panel sequences of the two phases (pp = 0 .. 2 MT - 1; buffer and register set = pp & 1)
+  auto issue1 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(0, pp, st); else issue(1, pp - MT, st); };
+  auto issue2 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(2, pp, st); else issue(3, 2 * MT - 1 - pp, st); };
+  issue1(0, stg[0]);
+  if (MT * 2 > 1) issue1(1, stg[1]);
   // ---- stage the small shared operands ----
   // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
   //  paid one L2 round trip each)
@@ -281,23 +393,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   TGP_STAMP(a.ws, p, 2);
   d4 Aa[MT], Ba[MT];
-  // ---- A = J K : A_i = sum_{kb <= i} J[i,kb] K_kb  (A operand = rows of J^T) ----
+  // ---- A = L^-1 K by forward substitution: A_i = Dinv_i (K_i - sum_{kb < i} L[i,kb] A_kb)  (A operand = rows of L^T,
+  //      then of -Dinv_i^T; the running right-hand side starts as -K_i, which already sits in accumulator layout) ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + (i & 1) * (MP * 16);
-    commit(i, stg[i & 1]);
+    commit(i & 1, true, i, stg[i & 1]);
     lds_barrier();
-    if (i + 2 < 2 * MT) issue(JT, Lq, i + 2, stg[i & 1]);
-    Aa[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Kr[st]; });
+    if (i + 2 < 2 * MT) issue1(i + 2, stg[i & 1]);
+    const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
+    Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
+                                [&](int st) { return Aa[st / 4][st % 4]; });
   }
   TGP_STAMP(a.ws, p, 3);
   // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + ((MT + i) & 1) * (MP * 16);
-    commit(MT + i, stg[(MT + i) & 1]);
+    commit((MT + i) & 1, false, i, stg[(MT + i) & 1]);
     lds_barrier();
-    if (MT + i + 2 < 2 * MT) issue(JT, Lq, MT + i + 2, stg[(MT + i) & 1]);
+    if (MT + i + 2 < 2 * MT) issue1(MT + i + 2, stg[(MT + i) & 1]);
     Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Aa[i + st / 4][st % 4]; });
   }
   TGP_STAMP(a.ws, p, 4);
@@ -378,32 +493,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
 
   TGP_STAMP(a.ws, p, 6);
-  // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = J^T Abar ----
+  // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = L^-T Abar ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) Ba[i] *= vb;
   d4 Ca[MT];
   lds_barrier();  // every wave is done with the flow stack / forward panels before the region is overwritten
-  issue(LqT, Jm, 0, stg[0]);
-  issue(LqT, Jm, 1, stg[1]);
+  issue2(0, stg[0]);
+  issue2(1, stg[1]);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const double* buf = pan + (i & 1) * (MP * 16);
-    commit(i, stg[i & 1]);
+    commit(i & 1, true, i, stg[i & 1]);
     lds_barrier();
-    if (i + 2 < 2 * MT) issue(LqT, Jm, i + 2, stg[i & 1]);
+    if (i + 2 < 2 * MT) issue2(i + 2, stg[i & 1]);
     Ca[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 0, 4 * (i + 1), [&](int st) { return Ba[st / 4][st % 4]; });
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) Ca[i][r] = mv[16 * i + 4 * r + q] * mub - 2.0 * Aa[i][r] * vb + 2.0 * Ca[i][r];
+  // back substitution, last tile first: Kbar_i = Dinv_i^T (Abar_i - sum_{kb > i} L[kb,i]^T Kbar_kb), the finished tiles
+  // taken in the order kb = MT-1 .. i+1 so that the freshest one is the last operand
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const double* buf = pan + ((MT + i) & 1) * (MP * 16);
-    commit(MT + i, stg[(MT + i) & 1]);
+  for (int t = 0; t < MT; ++t) {
+    const int i = MT - 1 - t, pp = MT + t;
+    const double* buf = pan + (pp & 1) * (MP * 16);
+    commit(pp & 1, false, i, stg[pp & 1]);
     lds_barrier();
-    if (MT + i + 2 < 2 * MT) issue(LqT, Jm, MT + i + 2, stg[(MT + i) & 1]);
-    Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Ca[i + st / 4][st % 4]; });  // Kbar
+    if (pp + 2 < 2 * MT) issue2(pp + 2, stg[pp & 1]);
+    Ba[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * (MT - 1 - i), 4 * i, -Ca[i],
+                                [&](int st) { return 4 * (MT - 1 - st / 4) + st % 4; },
+                                [&](int st) { return Ba[MT - 1 - st / 4][st % 4]; });  // Kbar
   }
   lds_barrier();  // panels dead: the region becomes the transposition tile
 

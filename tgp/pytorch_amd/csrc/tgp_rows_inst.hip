@@ -17,7 +17,7 @@ static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
   auto kern = k_rows<TGP_MT, DP, MODE>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.p.nblocks + (TRAIN ? a.p.MT * a.p.MT + 1 : 0)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.p.nblocks + (TRAIN ? a.p.MT : 0)), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   return 0;
