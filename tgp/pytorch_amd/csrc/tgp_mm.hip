@@ -22,6 +22,9 @@ namespace tgp {
 //   block 2 + t  : 16x16 tile t of {Lq, Lq^T, K_MM -> HBM} and the S = Lq Lq^T tile (one MFMA chain)
 // ---------------------------------------------------------------------------------------------------
 #define PREP_THREADS 512
+#ifndef TGP_W4_WINDOWS
+#define TGP_W4_WINDOWS 2 /* wave 4 (the chain wave's SIMD partner) takes tasks only in the first windows, the ones with the most fills */
+#endif
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, FlowProg fp, double* __restrict__ ws,
                                                          int32_t* __restrict__ status) {
@@ -246,11 +249,37 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
     for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] = cur[rr] - acc[rr];
   };
   // tile (i, c) of K_MM minus the contributions of the block columns [0, ncol) (all final): the tile's first value
-  // in LDS (C/D layout: rows q + 4u, column r); four independent exponential chains per lane
+  // in LDS (C/D layout: rows q + 4u, column r).  The four exponentials of a lane are written stage by stage
+  // (exp_fast_n: independent chains for the scheduler; called element by element they came out back to back)
   auto fill_tile = [&](int i, int c, int ncol) {
     double kv[4];
+    if (zl) {
+      const int cc = 16 * c + r;
+      double e[4];
+      TGP_EACH(u, 4) {
+        const int rr = 16 * i + q + 4 * u;
+        double d2 = 0.0;
+        // DP is 4, 8 or 16 and the rows are 32-byte aligned: two 16-byte reads per operand and four dimensions per trip
+        for (int d = 0; d < DP; d += 4) {
+          const double2 a0 = *reinterpret_cast<const double2*>(zs + rr * DP + d), a1 = *reinterpret_cast<const double2*>(zs + rr * DP + d + 2);
+          const double2 b0 = *reinterpret_cast<const double2*>(zs + cc * DP + d), b1 = *reinterpret_cast<const double2*>(zs + cc * DP + d + 2);
+          const double t0 = a0.x - b0.x, t1 = a0.y - b0.y, t2 = a1.x - b1.x, t3 = a1.y - b1.y;
+          d2 += t0 * t0; d2 += t1 * t1; d2 += t2 * t2; d2 += t3 * t3;
+        }
+        e[u] = -0.5 * d2;
+      }
+      exp_fast_n<4>(e);
+      TGP_EACH(u, 4) {
+        const int rr = 16 * i + q + 4 * u;
+        double k = s2 * e[u];
+        has_nan |= (rr < M) && (k != k);
+        if (rr == cc) k += jit;
+        kv[u] = rr < M ? k : (rr == cc ? 1.0 : 0.0);   // identity on the padding
+      }
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) kv[u] = kmm_elem(16 * i + q + 4 * u, 16 * c + r);
+      for (int u = 0; u < 4; ++u) kv[u] = kmm_elem(16 * i + q + 4 * u, 16 * c + r);
+    }
     if (ncol > 0) {
       const d4 upd = ll_sum(16 * i, 16 * c, 0, 16 * ncol);
 #pragma unroll
@@ -277,11 +306,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   int attempt = 0;
   PSTAMP0();
   for (;; ++attempt) {
-    // block column 0 of K_MM by everybody (it heads the chain); the other columns are filled under potrf(0)
-    for (int e = tid; e < MP * 16; e += PREP_THREADS) {
-      const int rr = e >> 4, cc = e & 15;
-      if (cc <= rr) A[rr * LD + cc] = kmm_elem(rr, cc);
-    }
+    // block column 0 of K_MM heads the chain: one tile per wave (MT <= 8 waves); column j + 1 is filled under potrf(j)
+    if (wave < MT) fill_tile(wave, 0, 0);
     PREP_BARRIER();
     PSTAMP(0);
     for (int j = 0; j < MT; ++j) {
@@ -337,23 +363,23 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #ifdef TGP_STAMPS
         if (wave != 0) { tph[j == 0 ? 7 : 8] += tph[1] + tph[2] + tph[3]; tph[1] = tph[2] = tph[3] = 0.0; }
 #endif
-      } else if (wave != 4) {
+      } else if (wave != 4 || j < TGP_W4_WINDOWS) {
         // (wave 4 shares wave 0's SIMD -- a workgroup's waves go to the SIMDs cyclically -- and stays out of the windows:
         //  the chain wave is bound by instruction issue and gets the SIMD to itself)
         // The other waves take this window's tasks from a counter in LDS, heaviest first (all operands are final since
         // the last barrier and the tasks of one window are independent of each other, so any wave may run any of them;
         // dealt round-robin the windows were as long as the unluckiest wave's share):
-        //   tile (i, j+2)  = K_MM - block columns 0 .. j-1 (its first value)       i = j+2 .. MT-1   [j = 0: columns 1, 2]
-        //   tile (i, j+1) -= block column j-1                                      i = j+1 .. MT-1
+        //   the inverse of diagonal tile j-1 (its L_jj has been in LDS since the last barrier)
+        //   tile (i, j+1)  = K_MM - block columns 0 .. j-1 (its first and only catch-up value: what is left for the
+        //                    chain is phase U, - block column j)                        i = j+1 .. MT-1
         //   write-out of L / L^T row j-1
         // (round 4: no tile of J = L^-1 is formed here any more -- the row kernel solves with L itself, and J for the
-        //  backward M x M chain comes from its passenger blocks)
-        const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
-        // (tile columns of this block's parity: c = 2 t + cb below `n` -> (n + 1 - cb) / 2 of them)
-        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;   // inverse of diagonal tile j-1 (tile column of this block's parity)
-        const int nf = j == 0 ? n1 + n2 : n2;
-        const int ns = j >= 1 ? n1 : 0, nwl = (j + 1 - cb) / 2;
-        const int ntask = nt + nf + ns + nwl;
+        //  backward M x M chain comes from its passenger blocks; and a column is filled ONE window before it is due,
+        //  6, 5, 4 ... tiles per window, instead of two columns under potrf(0): that first window was twice the chain's)
+        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;   // tile column j-1 of this block's parity
+        const int nf = MT - 1 - j;
+        const int nwl = (j + 1 - cb) / 2;                         // (tile columns c = 2 t + cb below j)
+        const int ntask = nt + nf + nwl;
         for (;;) {
           int t = 0;
           if (lane == 0) t = atomicAdd(&s_next, 1);
@@ -361,14 +387,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
           if (t >= ntask) break;
           if (t < nt) { inv_diag(j - 1); continue; }
           t -= nt;
-          if (t < nf) {
-            if (j == 0) { if (t < n1) fill_tile(1 + t, 1, 0); else fill_tile(2 + (t - n1), 2, 0); }
-            else fill_tile(j + 2 + t, j + 2, j);
-            continue;
-          }
+          if (t < nf) { fill_tile(j + 1 + t, j + 1, j); continue; }
           t -= nf;
-          if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
-          t -= ns;
           write_L(j - 1, 2 * t + cb);
         }
 #ifdef TGP_STAMPS
@@ -376,9 +396,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
         if (j == 0) PSTAMP(7); else PSTAMP(8);
 #endif
       }
-      tbase += ((j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0) + (j == 0 ? (MT - 1) + (MT - 2 > 0 ? MT - 2 : 0) : (MT - 2 - j > 0 ? MT - 2 - j : 0)) +
-               (j >= 1 ? MT - 1 - j : 0) + (j + 1 - cb) / 2 +
-               (NW - 1 - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
+      tbase += ((j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0) + (MT - 1 - j) + (j + 1 - cb) / 2 +
+               (NW - (j < TGP_W4_WINDOWS ? 0 : 1) - (npw > 0 ? npw : 1));   // the tasks + one over-grab per task wave
       PREP_BARRIER();
       PSTAMP(4);
       if (did_diag) {
