@@ -21,9 +21,14 @@
  *     valid under capture of `stream`, where they become parallel branches of the graph) -- make a thread's first
  *     call outside a capture; the helper streams and events are per host thread, so threads never share them;
  *   - return value: 0 = launched; <0 = -(index of the offending argument) or TGP_E_*;
- *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[4]):
- *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive),
+ *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[8], ZERO before its first use):
+ *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive;
+ *                   TGP_STATUS_SYNC_TIMEOUT = -77: a block of the fused step launch gave up waiting, results invalid),
  *       status[1] = 1 if K_MM contained a NaN (the reference raises NanError, dsp/utils.py:241-254),
+ *       status[2] = level of the on-device jitter ladder that succeeded (tgp_model.jitter_ladder), status[3] reserved,
+ *       status[4..7] = hand-off words of the fused step launch (M <= 128: the factorisation's blocks run in the same
+ *                   launch as the row blocks and publish the panels of L through these words); the library leaves
+ *                   them zero at the end of every call, the caller must not touch them while a call is in flight,
  *     so the host can replay with the reference's jitter ladder (dsp/utils.py:256-269) without a
  *     device sync per step.  No exception crosses the ABI.
  */
@@ -37,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TGP_VERSION 101
+#define TGP_VERSION 102
 #define TGP_FUSED_MAX_M 128 /* up to here the whole step is 7 fused kernels (operators resident in LDS/registers) */
 #define TGP_BIG_MAX_M 4096  /* above: chunked path built on a tiled float64 MFMA GEMM                             */
 

@@ -4,6 +4,7 @@
 //   M  > 128 : the chunked GEMM pipeline of tgp_big.hip (same entry points, chosen by M / kernel)
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "tgp_dev.hpp"
 #include "tgp_launch.hpp"
@@ -22,6 +23,12 @@ void set_error_text(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// TGP_FUSED_LAUNCH=0 keeps prepare and rows as two launches (diagnostics; read once)
+static bool fused_launch_enabled() {
+  static const bool on = [] { const char* e = getenv("TGP_FUSED_LAUNCH"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 static int check_model(const tgp_model* m, bool need_lik) {
@@ -149,10 +156,12 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   p.nslots = fp.nslots;
-  if (phases & TGP_PHASE_PREPARE)
+  // PREPARE and ROWS asked for together: ONE launch, the factorisation's blocks in front of the row blocks
+  const bool fuse = (phases & TGP_PHASE_PREPARE) && (phases & TGP_PHASE_ROWS) && fused_launch_enabled();
+  if ((phases & TGP_PHASE_PREPARE) && !fuse)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (phases & TGP_PHASE_ROWS)
-    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
+    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st, fuse ? status : nullptr)) return rc;
   if (phases & TGP_PHASE_BACKWARD)
     if (int rc = launch_backward_mm(p, md, *grads, out, ws, st, adam != nullptr ? &ad : nullptr)) return rc;
   return 0;

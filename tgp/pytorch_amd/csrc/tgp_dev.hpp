@@ -57,6 +57,7 @@ struct Plan {
   size_t redp;   // TGP_RSPLIT partial sums of the slab tail (T, s, scalars); slab layout, G part unused
   size_t PP;     // MT x MP x PPW per-row-block partials of (Kbar_MM o K_MM) [Zs, 1]
   int PPW;
+  size_t dbg;    // 256 doubles for the diagnostic (-DTGP_STAMPS) builds
   size_t slabs;  // nblocks * slab_len
   size_t total;  // doubles
 };
@@ -101,6 +102,7 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.redp = o; o += TGP_RSPLIT * p.slab_len;
   p.PPW = p.DP + 2;
   p.PP = o; o += (size_t)p.MT * p.MP * p.PPW;
+  p.dbg = o; o += 256;
   p.slabs = o; o += (size_t)p.nblocks * p.slab_len;
   p.total = o;
   return 0;

@@ -20,6 +20,7 @@
 // Per-block statistics go to a slab in HBM (deterministic two-pass reduction, no atomics).
 #pragma once
 #include "tgp_dev.hpp"
+#include "tgp_prep.hpp"
 
 namespace tgp {
 
@@ -44,6 +45,9 @@ struct RowArgs {
   const double* xs;
   const double* wn;
   double scale;
+  // fused launch only (k_rows<..., FUSED = true>): the model for the prepare roles and the status / hand-off words
+  tgp_model md;
+  int32_t* status;
 };
 
 // LDS carve-up (offsets in doubles)
@@ -142,10 +146,28 @@ __device__ __forceinline__ d4 subst_chain(const double* a0, int nsum, int dstep0
   return out;
 }
 
+#ifdef TGP_STAMPS
+#define ROW_STAMP(wsp, plan, i)                                                                       \
+  do {                                                                                                \
+    if (bid == 0 && threadIdx.x == 0)                                                                 \
+      (wsp)[(plan).hdr + tgp::H_STAMP + (i)] = (double)__builtin_amdgcn_s_memrealtime();              \
+  } while (0)
+#else
+#define ROW_STAMP(wsp, plan, i) \
+  do {                          \
+  } while (0)
+#endif
+
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
 // scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
-template <int MT, int DP, int MODE>
+// FUSED (training modes only): the launch carries the prepare roles in front of the row blocks -- block 0 the
+// factorisation chain, block 1 the parameter transforms, blocks 2 .. 1 + MT^2 the tile blocks (tgp_prep.hpp) -- and the
+// row blocks wait on the hand-off words for what they need instead of on a kernel boundary: staging and the K tile run
+// under the factorisation, the forward substitution follows it panel by panel, and what is left after the last panel is
+// B = Lq^T A onwards.
+template <int MT, int DP, int MODE, bool FUSED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_rows(RowArgs a) {
+  static_assert(!FUSED || MODE != 0, "the fused launch is a training launch");
   constexpr bool TRAIN = MODE != 0;
   constexpr int MP = MT * 16;
   constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
@@ -174,8 +196,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, q = lane >> 4;
   const double* __restrict__ ws = a.ws;
   const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
+  int32_t* sy = FUSED ? a.status + 4 : nullptr;
+  const int nb_total = 2 + MT * MT + p.nblocks + MT;   // blocks of a fused launch
+  int bid = blockIdx.x;                                // index among the row blocks, then the passengers
+  if constexpr (FUSED) {
+    if (blockIdx.x == 0) {
+      fused_chain_role<MT>(p, a.md, a.ws, a.status, sm);
+      sync_leave(sy, nb_total);
+      return;
+    }
+    if (blockIdx.x == 1) {
+      prep_xform_role<256, true>(p, a.md, a.prog, a.ws, sy);   // (publishes SY_XF itself, ahead of the KL)
+      sync_leave(sy, nb_total);
+      return;
+    }
+    if ((int)blockIdx.x < 2 + MT * MT) {
+      prep_tile_role<256, true>(p, a.md, a.ws, (int)blockIdx.x - 2, sy);   // (counts itself in SY_TILES)
+      sync_leave(sy, nb_total);
+      return;
+    }
+    bid = (int)blockIdx.x - (2 + MT * MT);
+  }
+  // block-uniform wait on a hand-off word: thread 0 polls, the workgroup learns the value through LDS
+  int* sync_box = reinterpret_cast<int*>(red + 30);
+  auto block_wait = [&](int word, auto pred) {
+    if (tid == 0) {
+      const int v = sync_wait(sy + word, pred);
+      if (v == (int)0x80000000) a.status[0] = TGP_STATUS_SYNC_TIMEOUT;
+      sync_box[0] = v;
+    }
+    lds_barrier();
+    const int v = sync_box[0];
+    lds_barrier();
+    return v;
+  };
 
-  if (TRAIN && (int)blockIdx.x >= p.nblocks) {
+  if (TRAIN && bid >= p.nblocks) {
     // ---- passenger blocks (one per 16-column block c of J): what only the backward M x M chain needs -- J = L^-1
     //      (k_bwd34), H'^T = (J^T (S - I))^T (k_bwd12) and w = J^T m -- formed on CUs the row tiles leave idle instead
     //      of on the prepare launch's critical chain.  Column block c of J is the forward substitution with the unit
@@ -184,8 +240,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //      needs requested up front.  All four waves run the chain (nothing to exchange); wave 0 stores the column of
     //      J, wave w the tiles (c, w), (c, w+4) of H' -- whose A operand is again the accumulator layout of the J tiles,
     //      now read as J^T -- and wave 3 the 16 entries of w.
-    const int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x - p.nblocks);
+    const int c = __builtin_amdgcn_readfirstlane(bid - p.nblocks);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    if constexpr (FUSED) {   // everything of the prepare roles: padded m, S, all of L^T and the tile inverses
+      block_wait(SY_XF, [](int x) { return x != 0; });
+      block_wait(SY_TILES, [&](int x) { return (x >> 16) >= MT * MT; });   // (the S tiles: the high half)
+      block_wait(SY_COLS, [&](int x) { return (x & 15) >= MT; });
+    }
     const double* __restrict__ LTg = ws + p.LT;
     const double* __restrict__ nDg = ws + p.nD;
     const double* __restrict__ Sg = ws + p.S_;
@@ -196,22 +257,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < MT; ++i) {
       if (i < c) continue;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) df[i][s4] = nDg[i * 256 + nl * 16 + 4 * s4 + q];   // A operand of -Dinv_i
+      for (int s4 = 0; s4 < 4; ++s4) df[i][s4] = ld_maybe<FUSED>(nDg + i * 256 + nl * 16 + 4 * s4 + q);   // A operand of -Dinv_i
 #pragma unroll
       for (int kb = 0; kb < i; ++kb) {
         if (kb < c) continue;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) lf[i * (i - 1) / 2 + kb][s4] = LTg[(size_t)(16 * kb + 4 * s4 + q) * MP + 16 * i + nl];
+        for (int s4 = 0; s4 < 4; ++s4) lf[i * (i - 1) / 2 + kb][s4] = ld_maybe<FUSED>(LTg + (size_t)(16 * kb + 4 * s4 + q) * MP + 16 * i + nl);
       }
     }
     d4 dc;  // Dinv_c in accumulator layout
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) dc[rr] = -nDg[c * 256 + (4 * rr + q) * 16 + nl];
+    for (int rr = 0; rr < 4; ++rr) dc[rr] = -ld_maybe<FUSED>(nDg + c * 256 + (4 * rr + q) * 16 + nl);
     double mf[MT][4];  // this lane's entries of m (for w)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) mf[i][rr] = ws[p.mpad + 16 * i + 4 * rr + q];
+      for (int rr = 0; rr < 4; ++rr) mf[i][rr] = ld_maybe<FUSED>(ws + p.mpad + 16 * i + 4 * rr + q);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       Jt[i] = d4{0, 0, 0, 0};
@@ -245,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const int kk = 16 * kb + 4 * s4 + q;
-          bf[kb][s4] = Sg[(size_t)kk * MP + 16 * jj + nl] - (kk == 16 * jj + nl ? 1.0 : 0.0);
+          bf[kb][s4] = ld_maybe<FUSED>(Sg + (size_t)kk * MP + 16 * jj + nl) - (kk == 16 * jj + nl ? 1.0 : 0.0);
         }
       }
       d4 h = {0, 0, 0, 0};
@@ -269,23 +330,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sw = quad_sum(sw);
       if (q == 0) a.ws[p.w + 16 * c + nl] = sw;
     }
+    if constexpr (FUSED) sync_leave(sy, nb_total);
     return;
   }
 
-  TGP_STAMP(a.ws, p, 0);
+  ROW_STAMP(a.ws, p, 0);
 #ifdef TGP_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 11] = (double)clock64();
+  if (bid == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 11] = (double)clock64();
 #endif
   // this lane's data row and the step header: requested with the first staging loads (they need nothing from LDS;
   // behind the staging barrier they cost a memory round trip of their own)
-  const int n = blockIdx.x * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
+  const int n = bid * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
   const bool valid = n < N;
   const int nc = valid ? n : N - 1;
   double xraw[DP];
 #pragma unroll
   for (int d = 0; d < DP; ++d) xraw[d] = d < D ? a.X[(size_t)nc * D + d] : 0.0;
   const double y = TRAIN ? a.Y[nc] : 0.0;
-  const double s2 = ws[p.hdr + H_S2], eta = ws[p.hdr + H_ETA], einv = ws[p.hdr + H_EINV];
+  if constexpr (FUSED) block_wait(SY_XF, [](int x) { return x != 0; });   // header, Zs, 1/l, m, flow parameter transforms
+  // (fused: written by another block of this launch a moment ago -- not through the scalar cache)
+  const double s2 = ld_maybe<FUSED>(ws + p.hdr + H_S2), eta = ld_maybe<FUSED>(ws + p.hdr + H_ETA),
+               einv = ld_maybe<FUSED>(ws + p.hdr + H_EINV);
 
   // ---- operand panels: the A operands of the four triangular products (16 columns x up to MP rows of L^T, Lq, Lq^T, L)
   //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
@@ -314,9 +379,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int u = 0; u < MT; ++u)
       if (u < nb) {
-        if (kind == 0 && u == i) st[u] = nD[i * 256 + (tid & 15) * 16 + (tid >> 4)];        // (-Dinv_i)^T
-        else if (kind == 3 && u == 0) st[u] = nD[i * 256 + (tid >> 4) * 16 + (tid & 15)];   // -Dinv_i
-        else st[u] = Mt[(size_t)16 * u * MP];
+        if (kind == 0 && u == i) st[u] = ld_maybe<FUSED>(nD + i * 256 + (tid & 15) * 16 + (tid >> 4));        // (-Dinv_i)^T
+        else if (kind == 3 && u == 0) st[u] = ld_maybe<FUSED>(nD + i * 256 + (tid >> 4) * 16 + (tid & 15));   // -Dinv_i
+        else st[u] = ld_maybe<FUSED>(Mt + (size_t)16 * u * MP);
       }
   };
   auto commit = [&](int par, bool lower, int i, const double (&st)[MT]) {
@@ -329,8 +394,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // panel sequences of the two phases (pp = 0 .. 2 MT - 1; buffer and register set = pp & 1)
   auto issue1 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(0, pp, st); else issue(1, pp - MT, st); };
   auto issue2 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(2, pp, st); else issue(3, 2 * MT - 1 - pp, st); };
-  issue1(0, stg[0]);
-  if (MT * 2 > 1) issue1(1, stg[1]);
+  if constexpr (!FUSED) {
+    issue1(0, stg[0]);
+    if (MT * 2 > 1) issue1(1, stg[1]);
+  }
   // ---- stage the small shared operands ----
   // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
   //  paid one L2 round trip each)
@@ -338,11 +405,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NZ = (MP * DP + 255) / 256;
     double zv[NZ];
 #pragma unroll
-    for (int u = 0; u < NZ; ++u) zv[u] = tid + 256 * u < MP * DP ? ws[p.Zs + tid + 256 * u] : 0.0;
-    const double mv0 = tid < MP ? ws[p.mpad + tid] : 0.0;
-    const double il0 = tid < 16 ? ws[p.ils + tid] : 0.0;
+    for (int u = 0; u < NZ; ++u) zv[u] = tid + 256 * u < MP * DP ? ld_maybe<FUSED>(ws + p.Zs + tid + 256 * u) : 0.0;
+    const double mv0 = tid < MP ? ld_maybe<FUSED>(ws + p.mpad + tid) : 0.0;
+    const double il0 = tid < 16 ? ld_maybe<FUSED>(ws + p.ils + tid) : 0.0;
     const bool fl = p.lik == TGP_LIK_FLOW;
-    const double tp0 = (fl && tid < P) ? ws[p.tp + tid] : 0.0, tg0 = (fl && tid < P) ? ws[p.tg + tid] : 0.0;
+    const double tp0 = (fl && tid < P) ? ld_maybe<FUSED>(ws + p.tp + tid) : 0.0, tg0 = (fl && tid < P) ? ld_maybe<FUSED>(ws + p.tg + tid) : 0.0;
     const double xs0 = (fl && tid < p.S) ? a.xs[tid] : 0.0, wn0 = (fl && tid < p.S) ? a.wn[tid] : 0.0;
 #pragma unroll
     for (int u = 0; u < NZ; ++u)
@@ -352,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (fl) {
       if (tid < P) { tpL[tid] = tp0; tgL[tid] = tg0; tiL[tid] = rcp_fast(tp0); }
       if (tid < p.S) { xsL[tid] = xs0; wnL[tid] = wn0; }
-      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ws[p.tp + i]; tgL[i] = ws[p.tg + i]; tiL[i] = rcp_fast(tpL[i]); }
+      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ld_maybe<FUSED>(ws + p.tp + i); tgL[i] = ld_maybe<FUSED>(ws + p.tg + i); tiL[i] = rcp_fast(tpL[i]); }
       for (int i = tid + 256; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
       for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
     }
@@ -363,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   lds_barrier();
 
-  TGP_STAMP(a.ws, p, 1);
+  ROW_STAMP(a.ws, p, 1);
   double x[DP];
 #pragma unroll
   for (int d = 0; d < DP; ++d) x[d] = d < D ? xraw[d] * ils[d] : 0.0;
@@ -391,21 +458,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     TGP_EACH(u, 4) Kr[k0 + u] = (4 * (k0 + u) + q < M ? s2 : 0.0) * e[u];
   }
 
-  TGP_STAMP(a.ws, p, 2);
+  ROW_STAMP(a.ws, p, 2);
   d4 Aa[MT], Ba[MT];
   // ---- A = L^-1 K by forward substitution: A_i = Dinv_i (K_i - sum_{kb < i} L[i,kb] A_kb)  (A operand = rows of L^T,
   //      then of -Dinv_i^T; the running right-hand side starts as -K_i, which already sits in accumulator layout) ----
+  if constexpr (FUSED) {
+    // The factorisation runs beside this block: tile i waits for panel i (SY_COLS), stages it and closes -- nothing to
+    // prefetch, the chain is the slower side.  SY_COLS also carries the jitter-ladder attempt: panels of an attempt that
+    // died (a pivot failed further down) are worthless, and since the terminal count MT is only ever published for the
+    // attempt that ended the factorisation, a block that sees the attempt change simply starts the substitution again.
+    int att = 0;
+    bool redo;
+    do {
+      redo = false;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const double* buf = pan + (i & 1) * (MP * 16);
-    commit(i & 1, true, i, stg[i & 1]);
-    lds_barrier();
-    if (i + 2 < 2 * MT) issue1(i + 2, stg[i & 1]);
-    const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
-    Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
-                                [&](int st) { return Aa[st / 4][st % 4]; });
+      for (int i = 0; i < MT; ++i) {
+        if (redo) continue;
+        const int v = block_wait(SY_COLS, [&](int x) { return (x >> 4) > att || ((x >> 4) == att && (x & 15) > i); });
+        if (v != (int)0x80000000 && (v >> 4) != att) { att = v >> 4; redo = true; continue; }
+        double* buf = pan + (i & 1) * (MP * 16);
+        issue(0, i, stg[i & 1]);
+        commit(i & 1, true, i, stg[i & 1]);
+        lds_barrier();
+        const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
+        Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
+                                    [&](int st) { return Aa[st / 4][st % 4]; });
+      }
+    } while (redo);
+    block_wait(SY_TILES, [&](int x) { return (x & 0xffff) >= MT * MT; });   // Lq, Lq^T (long since there)
+    issue1(MT, stg[MT & 1]);
+    if (MT > 1) issue1(MT + 1, stg[(MT + 1) & 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const double* buf = pan + (i & 1) * (MP * 16);
+      commit(i & 1, true, i, stg[i & 1]);
+      lds_barrier();
+      if (i + 2 < 2 * MT) issue1(i + 2, stg[i & 1]);
+      const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
+      Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
+                                  [&](int st) { return Aa[st / 4][st % 4]; });
+    }
   }
-  TGP_STAMP(a.ws, p, 3);
+  ROW_STAMP(a.ws, p, 3);
   // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -415,7 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (MT + i + 2 < 2 * MT) issue1(MT + i + 2, stg[(MT + i) & 1]);
     Ba[i] = mfma_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * (MT - i), [&](int st) { return Aa[i + st / 4][st % 4]; });
   }
-  TGP_STAMP(a.ws, p, 4);
+  ROW_STAMP(a.ws, p, 4);
   // ---- mu, v ----
   double pm = 0.0, pa = 0.0, pb = 0.0;
 #pragma unroll
@@ -431,7 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (a.mu != nullptr && q == 0 && valid) { a.mu[n] = mu; a.v[n] = v; }
   if (!TRAIN) return;
 
-  TGP_STAMP(a.ws, p, 5);
+  ROW_STAMP(a.ws, p, 5);
   // ---- expected log-likelihood and its adjoints ----
   double mub = 0.0, vb = 0.0, ellp = 0.0, etap = 0.0;
   if (p.lik == TGP_LIK_GAUSS) {
@@ -492,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
 
-  TGP_STAMP(a.ws, p, 6);
+  ROW_STAMP(a.ws, p, 6);
   // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = L^-T Abar ----
 #pragma unroll
   for (int i = 0; i < MT; ++i) Ba[i] *= vb;
@@ -527,8 +622,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   lds_barrier();  // panels dead: the region becomes the transposition tile
 
-  TGP_STAMP(a.ws, p, 7);
-  double* slab = a.ws + p.slabs + (size_t)blockIdx.x * p.slab_len;
+  ROW_STAMP(a.ws, p, 7);
+  double* slab = a.ws + p.slabs + (size_t)bid * p.slab_len;
   const int col = wave * 16 + nl;
 
   // ---- phase 1: E = Kbar o K through LDS (transposed), T = E [xs, xs^2, 1] on MFMA ----
@@ -557,7 +652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   lds_barrier();
 
-  TGP_STAMP(a.ws, p, 8);
+  ROW_STAMP(a.ws, p, 8);
   // ---- phase 2: A through LDS, G = A diag(vbar) A^T (lower tiles), s = A mubar ----
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -565,7 +660,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
   if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
   lds_barrier();
-  TGP_STAMP(a.ws, p, 17);
+  ROW_STAMP(a.ws, p, 17);
   // Row-blocks of G are dealt to the waves in balanced groups -- MT odd: {MT-1}, {MT-2, 0}, {MT-3, 1}, ...; MT even:
   // {MT-1, 0}, {MT-2, 1}, ... (every group holds MT or MT+1 of the MT(MT+1)/2 lower tiles) -- so that the 16 A-operand
   // fragments of a row-block are read from LDS ONCE, kept in registers (first raw for s = A mubar, then scaled by vbar for
@@ -617,9 +712,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   }
-  TGP_STAMP(a.ws, p, 18);
+  ROW_STAMP(a.ws, p, 18);
 
-  TGP_STAMP(a.ws, p, 9);
+  ROW_STAMP(a.ws, p, 9);
   // ---- scalars, flow parameter gradients ----
   const double e1 = wave_sum(ellp), e2 = wave_sum(etap), e3 = wave_sum(q == 0 ? vb : 0.0);
   if (lane == 0) { red[wave * 4] = e1; red[wave * 4 + 1] = e2; red[wave * 4 + 2] = e3; }
@@ -634,9 +729,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const double s = wave_sum(acc[j * 64 + lane]);
     if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
   }
-  TGP_STAMP(a.ws, p, 10);
+  ROW_STAMP(a.ws, p, 10);
 #ifdef TGP_STAMPS
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 23] = (double)clock64();
+  if (bid == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 23] = (double)clock64();
 #endif
   for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
   if (a.g_rowp != nullptr && q == 0 && valid) {
@@ -646,6 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       a.g_rowp[(size_t)n * RP + jr] = ap[0] + ap[16] + ap[32] + ap[48];
     }
   }
+  if constexpr (FUSED) sync_leave(sy, nb_total);
 }
 
 }  // namespace tgp

@@ -11,13 +11,15 @@
 
 namespace tgp {
 
-template <int DP, int MODE>
+template <int DP, int MODE, bool FUSED>
 static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
   constexpr bool TRAIN = MODE != 0;
-  auto kern = k_rows<TGP_MT, DP, MODE>;
+  auto kern = k_rows<TGP_MT, DP, MODE, FUSED>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
-  hipLaunchKernelGGL(kern, dim3(a.p.nblocks + (TRAIN ? a.p.MT : 0)), dim3(256), lds, st, a);
+  // fused: chain block, transform block, MT^2 tile blocks, then the row blocks and the MT passenger blocks
+  const int grid = (FUSED ? 2 + a.p.MT * a.p.MT : 0) + a.p.nblocks + (TRAIN ? a.p.MT : 0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   return 0;
@@ -26,9 +28,11 @@ static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
 template <int DP>
 static int launch_dp(const RowArgs& a, int mode, size_t lds, hipStream_t st) {
   switch (mode) {
-    case 0: return launch_one<DP, 0>(a, lds, st);
-    case 1: return launch_one<DP, 1>(a, lds, st);
-    default: return launch_one<DP, 2>(a, lds, st);
+    case 0: return launch_one<DP, 0, false>(a, lds, st);
+    case 1: return launch_one<DP, 1, false>(a, lds, st);
+    case 2: return launch_one<DP, 2, false>(a, lds, st);
+    case 3: return launch_one<DP, 1, true>(a, lds, st);    // fused prepare + rows
+    default: return launch_one<DP, 2, true>(a, lds, st);
   }
 }
 

@@ -176,7 +176,7 @@ class ElboEngine:
         self.g_rowp = torch.zeros_like(self.rowp) if self.rowp is not None else None
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.step_dev = torch.zeros(2, dtype=torch.int32, device=self.device) if share is None else share.step_dev
-        self.status = torch.zeros(4, dtype=torch.int32, device=self.device) if share is None else share.status
+        self.status = torch.zeros(8, dtype=torch.int32, device=self.device) if share is None else share.status
         self.pre_step = None        # callables launched (and captured) before / after the step: the minibatch gather
         self.post_step = None
         mbg = mb_global if mb_global is not None else self.N

@@ -133,7 +133,7 @@ def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=No
     md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel)
     ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev, md.kernel)
     out = torch.empty(4, dtype=torch.float64, device=dev)
-    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    status = torch.zeros(8, dtype=torch.int32, device=dev)
     g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
          "m": torch.empty_like(m), "Lam": torch.empty_like(Lam), "lvn": torch.empty_like(lvn)}
     gs = L.TgpGrads()
@@ -235,7 +235,7 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="sca
     ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel)
     mu = torch.empty(X.shape[0], dtype=torch.float64, device=dev)
     v = torch.empty_like(mu)
-    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    status = torch.zeros(8, dtype=torch.int32, device=dev)
     rc = lib.tgp_qf_moments_f64(md, L.ptr(X), L.ptr(mu), L.ptr(v), L.ptr(status), L.ptr(ws), ws.numel() * 8,
                                 L.stream_ptr())
     L.check(rc, "tgp_qf_moments_f64")
@@ -273,7 +273,7 @@ def qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, mu_bar, v_bar, jitter=0.0, kern
     gs = L.TgpGrads()
     gs.Z, gs.raw_ls, gs.raw_os, gs.m, gs.Lam = (L.ptr(g[k]) for k in ("Z", "raw_ls", "raw_os", "m", "Lam"))
     gs.log_var_noise = L.ptr(glvn)
-    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    status = torch.zeros(8, dtype=torch.int32, device=dev)
     rc = lib.tgp_qf_moments_bwd_f64(md, L.ptr(X), L.ptr(mu_bar), L.ptr(v_bar), gs, L.ptr(status), L.ptr(ws), ws.numel() * 8,
                                     L.stream_ptr())
     L.check(rc, "tgp_qf_moments_bwd_f64")
@@ -364,7 +364,7 @@ def cholesky(A, want_inverse=False):
     M = A.shape[0]
     Lo = torch.empty_like(A)
     Li = torch.empty_like(A) if want_inverse else None
-    status = torch.zeros(4, dtype=torch.int32, device=A.device)
+    status = torch.zeros(8, dtype=torch.int32, device=A.device)
     nws = lib.tgp_cholesky_workspace_bytes(M)
     ws = torch.empty(nws // 8 + 16, dtype=torch.float64, device=A.device) if nws else None
     L.check(lib.tgp_cholesky_f64(L.ptr(A), M, L.ptr(Lo), L.ptr(Li), L.ptr(status), L.ptr(ws),
