@@ -25,9 +25,10 @@ void set_error_text(const char* fmt, ...) {
   va_end(ap);
 }
 
-// TGP_FUSED_LAUNCH=0 keeps prepare and rows as two launches (diagnostics; read once)
+// TGP_FUSED_LAUNCH=1 runs prepare and rows as ONE launch (k_rows<..., FUSED>; read once).  Off by default: measured at
+// the Power size it ties with the two launches (DESIGN.md section 4c says where its time goes).
 static bool fused_launch_enabled() {
-  static const bool on = [] { const char* e = getenv("TGP_FUSED_LAUNCH"); return !(e && e[0] == '0'); }();
+  static const bool on = [] { const char* e = getenv("TGP_FUSED_LAUNCH"); return e && e[0] == '1'; }();
   return on;
 }
 

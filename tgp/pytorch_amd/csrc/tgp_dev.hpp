@@ -437,11 +437,21 @@ __device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16], 
 // Inverse of a 16x16 lower-triangular tile by one wave: in dg[c] = L[l & 15][c]; out x[r] = (L^-1)[r][l & 15] (column
 // `lane` of the inverse, zero above the diagonal).  Off the factorisation's chain (a helper wave runs it one block
 // column behind).
+// GATED = false (a caller with registers to spare: the fused launch's chain blocks, 512 per wave): the 120 broadcasts
+// and the 16 reciprocals are left free to be issued ahead of the substitution chain.
+template <bool GATED = true>
 __device__ __forceinline__ void trtri16(const double (&dg)[16], double (&x)[16], int lane) {
   double gate = 0.0;  // x[k-1]: the broadcasts of step k are tied behind it (below)
+  double rinvs[16];
+  if constexpr (!GATED) {
+    static_for<16>([&](auto kc) { constexpr int k = decltype(kc)::value; rinvs[k] = bcast_row_k<k>(dg[k]); });
+    rcp_fast_n<16>(rinvs);
+  }
   static_for<16>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const double rinv = rcp_fast(bcast_row_k<k>(dg[k]));
+    double rinv;
+    if constexpr (GATED) rinv = rcp_fast(bcast_row_k<k>(dg[k]));
+    else rinv = rinvs[k];
     double s0 = 0.0, s1 = 0.0;
     static_for<16>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
@@ -449,7 +459,7 @@ __device__ __forceinline__ void trtri16(const double (&dg)[16], double (&x)[16],
         // None of the 120 broadcasts depends on x: left alone hipcc issues them all up front and keeps them alive
         // (240 VGPRs: the callers spilled).  The empty asm makes step k's operands wait for x[k-1].
         double t = dg[m];
-        asm volatile("" : "+v"(t) : "v"(gate));
+        if constexpr (GATED) asm volatile("" : "+v"(t) : "v"(gate));
         if constexpr ((m & 1) == 0) s0 = fma(bcast_row_k<k>(t), x[m], s0);
         else s1 = fma(bcast_row_k<k>(t), x[m], s1);
       }

@@ -11,6 +11,7 @@
 //          and the ARD-RBF parameter gradients from Kbar_MM and the row statistics T.
 // All GEMM-shaped work is 16x16 output tiles on v_mfma_f64_16x16x4_f64, one wave per tile.
 #include "tgp_dev.hpp"
+#include "tgp_prep.hpp"
 #include "tgp_launch.hpp"
 
 namespace tgp {
@@ -37,98 +38,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   const int r = lane & 15, q = lane >> 4;
   const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, MT = p.MT;
 
+  int32_t* sy = status + 4;   // hand-off words (tgp_prep.hpp): here only SY_TILES and SY_DONE are used
+  const int nb_total = 3 + MT * MT;
   if (blockIdx.x >= 3) {
-    // ---------------- tile blocks: Lq, Lq^T, K_MM copies + S = Lq Lq^T (sparse_MF_SP.py:316,344-346) ------------
-    const int t = blockIdx.x - 3, ti = t / MT, tj = t % MT;
-    if (tid < 256) {
-      const int rr = tid >> 4, cc = tid & 15, row = ti * 16 + rr, col = tj * 16 + cc;
-      double lq = 0.0, k = 0.0;
-      if (row < M && col < M) {
-        if (col <= row) lq = md.Lam[(size_t)row * M + col];
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-          const double il = 1.0 / softplus_d(md.raw_ls[d]);
-          const double tt = md.Z[(size_t)row * D + d] * il - md.Z[(size_t)col * D + d] * il;
-          d2 += tt * tt;
-        }
-        k = softplus_d(md.raw_os[0]) * exp_fast(-0.5 * d2);
-      }
-      ws[p.Lq + (size_t)row * MP + col] = lq;
-      ws[p.LqT + (size_t)col * MP + row] = lq;
-      ws[p.Kmm + (size_t)row * MP + col] = k;
-      if (tj > ti) {  // strictly-upper tile: zero in L and in J = L^-1 (formed by the row kernel's passenger blocks)
-        ws[p.L + (size_t)row * MP + col] = 0.0;
-        ws[p.J + (size_t)row * MP + col] = 0.0;
-      }
-    }
-    if (wave == 4) {  // S tile on a wave that did no copy work
-      const int i = ti * 16 + r, j = tj * 16 + r;
-      d4 acc = {0, 0, 0, 0};
-      const int kend = (ti < tj ? ti : tj) * 16 + 16;  // Lq[i,k] = 0 for k > i
-      for (int k = 0; k < kend; k += 4) {
-        const int kk = k + q;
-        const double a = (i < M && kk <= i) ? md.Lam[(size_t)i * M + kk] : 0.0;
-        const double b = (j < M && kk <= j) ? md.Lam[(size_t)j * M + kk] : 0.0;
-        acc = TGP_MFMA(a, b, acc);
-      }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) ws[p.S_ + (size_t)(ti * 16 + q + 4 * rr) * MP + tj * 16 + r] = acc[rr];
-    }
+    // ---------------- tile blocks: Lq, Lq^T, K_MM copies + S = Lq Lq^T (sparse_MF_SP.py:316,344-346); they count
+    //                  themselves in SY_TILES once K_MM is out: the chain blocks take K_MM's columns >= 2 from there
+    prep_tile_role<PREP_THREADS, true>(p, md, ws, (int)blockIdx.x - 3, sy);
+    sync_leave(sy, nb_total);
     return;
   }
 
   if (blockIdx.x == 2) {
     // ---------------- transforms, padded copies, flow parameter transforms, KL, header ---------------------------
-    __shared__ double red1[16];
-    double* hdr = ws + p.hdr;
-    if (tid < 16) {
-      const double l = tid < D ? softplus_d(md.raw_ls[tid]) : 1.0;  // gpytorch Positive constraint = softplus
-      ws[p.ls + tid] = l;
-      ws[p.ils + tid] = tid < D ? 1.0 / l : 0.0;
-    }
-    for (int i = tid; i < MP * DP; i += PREP_THREADS) {
-      const int mrow = i / DP, d = i % DP;
-      ws[p.Zs + i] = (mrow < M && d < D) ? md.Z[(size_t)mrow * D + d] * (1.0 / softplus_d(md.raw_ls[d])) : 0.0;
-    }
-    for (int i = tid; i < MP; i += PREP_THREADS) ws[p.mpad + i] = i < M ? md.m[i] : 0.0;
-    {
-      for (int b = tid; b < fp.nblk; b += PREP_THREADS) {
-        const int kind = fp.blk[4 * b], K = fp.blk[4 * b + 1], poff = fp.blk[4 * b + 2], flags = fp.blk[4 * b + 3];
-        if (flags & TGP_FLAG_PER_ROW) continue;
-        const int np = kind == TGP_FLOW_STEPTANH ? 4 * K : 2;
-        for (int j = 0; j < np; ++j) {
-          const double x = md.theta[poff + j];
-          bool res;
-          if (kind == TGP_FLOW_STEPTANH) res = (j & 1);  // b_k, d_k: TanhFlow set_restrictions=True (flow.py:1075)
-          else res = (flags & TGP_FLAG_RESTRICT) && j == (kind == TGP_FLOW_AFFINE ? 0 : 1);
-          ws[p.tp + poff + j] = res ? softplus_d(x) : x;
-          ws[p.tg + poff + j] = res ? sigmoid_d(x) : 1.0;
-        }
-      }
-    }
-    // whitened KL (models/sparse_MF_SP.py:406-431)
-    double kl_part = 0.0;
-    for (int i = tid; i < M * M; i += PREP_THREADS) {
-      const int rr = i / M, cc = i % M;
-      if (cc <= rr) {
-        const double x = md.Lam[i];
-        kl_part += x * x;
-        if (cc == rr) kl_part -= log(x * x);
-      }
-    }
-    for (int i = tid; i < M; i += PREP_THREADS) kl_part += md.m[i] * md.m[i];
-    kl_part = wave_sum(kl_part);
-    if (lane == 0) red1[wave] = kl_part;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int i = 0; i < PREP_THREADS / 64; ++i) s += red1[i];
-      hdr[H_S2] = softplus_d(md.raw_os[0]);
-      hdr[H_KL] = 0.5 * (s - (double)M);
-      hdr[H_ETA] = md.log_var_noise[0];
-      hdr[H_EINV] = exp(-md.log_var_noise[0]);  // 1/positive_transform (dsp/utils.py:39-41, 'exp')
-      hdr[H_SIG_OS] = sigmoid_d(md.raw_os[0]);
-    }
+    prep_xform_role<PREP_THREADS, false>(p, md, fp, ws);
+    sync_leave(sy, nb_total);
     return;
   }
 
@@ -154,9 +77,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   const int LD = MP + 1;
   double* A = sm;                            // MP x LD: lower = K_MM -> L
   double* zs = sm + (size_t)MP * LD;         // MP x DP scaled inducing points, present when p.zs_lds (LDS budget allows)
-  __shared__ int s_info, s_nan, s_next;
+  __shared__ int s_info, s_nan, s_next, s_sync;
   __shared__ double s_ils[16];
-  if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; }
+  if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; s_sync = 0; }
   int tbase = 0;  // first task id of the current window (the same in every wave)
   if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   const double s2 = softplus_d(md.raw_os[0]);
@@ -251,9 +174,28 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // tile (i, c) of K_MM minus the contributions of the block columns [0, ncol) (all final): the tile's first value
   // in LDS (C/D layout: rows q + 4u, column r).  The four exponentials of a lane are written stage by stage
   // (exp_fast_n: independent chains for the scheduler; called element by element they came out back to back)
+  const double* __restrict__ Kg = ws + p.Kmm;
+  bool tiles_seen = false;
   auto fill_tile = [&](int i, int c, int ncol) {
     double kv[4];
-    if (zl) {
+    if (c >= 2) {
+      // Round 4: the tile blocks of this launch have K_MM in global memory long before column 2 is due (window 1, ~10 us
+      // in; they are done by ~7): four coherent loads per lane instead of four exponential chains -- the 21 tile fills
+      // were what the task waves of a window could not finish under the chain's register pass.
+      if (!tiles_seen) {
+        const int v = sync_wait(sy + SY_TILES, [&](int x) { return (x & 0xffff) >= MT * MT; });
+        if (v == (int)0x80000000 && lane == 0) s_sync = 1;
+        tiles_seen = true;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] = ld_agent(Kg + (size_t)(16 * i + q + 4 * u) * MP + 16 * c + r);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = 16 * i + q + 4 * u, cc = 16 * c + r;
+        has_nan |= (kv[u] != kv[u]);
+        if (rr == cc) kv[u] = rr < M ? kv[u] + jit : 1.0;   // jitter on the diagonal, identity on the padding
+      }
+    } else if (zl) {
       const int cc = 16 * c + r;
       double e[4];
       TGP_EACH(u, 4) {
@@ -438,10 +380,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   }
 #endif
   if (tid == 0 && cb == 0) {   // (block 1 arrives at the same three words)
-    status[0] = s_info;
+    status[0] = s_sync != 0 ? TGP_STATUS_SYNC_TIMEOUT : s_info;
     status[1] = s_nan;
     status[2] = s_info == 0 ? attempt : 0;
   }
+  sync_leave(sy, nb_total);
 #undef PREP_BARRIER
 }
 

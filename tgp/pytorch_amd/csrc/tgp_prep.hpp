@@ -8,10 +8,11 @@
 //
 // Cross-workgroup hand-off inside ONE launch (fused path only).  Four int32 words behind the caller's status words
 // (status[4..7]; the ABI asks for them to be zero before the first call, every launch leaves them zero):
-//   SY_XF    1 once the transform block has written Zs, 1/l, the header scalars, the flow parameter transforms, padded m
-//   SY_TILES number of tile blocks that have written their tiles of L_q, L_q^T, K_MM, S
-//   SY_COLS  16 * attempt + number of operand panels of L complete in global memory (panel c = tiles (c, k < c) of L and
-//            L^T and -Dinv_c), `attempt` = level of the on-device jitter ladder the factorisation is at
+//   SY_TILES bits 0-15: number of tile blocks that have written their tiles of L_q, L_q^T, K_MM; bits 16-23: ... of S;
+//            bit 24: the transform block has written Zs, 1/l, the header scalars, the flow parameter transforms, padded m
+//   SY_COLS0 / SY_COLS1 (one per chain block b = 0, 1): 16 * attempt + n, every operand panel c < n of parity c & 1 = b
+//            is complete in global memory (panel c = tiles (c, k < c) of L and L^T and -Dinv_c); `attempt` = level of
+//            the on-device jitter ladder the factorisation is at
 //   SY_DONE  number of blocks of the launch that have finished; the last one zeroes the four words
 // No fences: an agent-scope release / acquire costs a write-back / invalidate of the whole L2 of the XCD on gfx950 (135
 // polling row blocks kept every L2 of the chip empty: the first fused build took 130 us).  Instead every datum that
@@ -27,7 +28,8 @@
 
 namespace tgp {
 
-enum { SY_XF = 0, SY_TILES = 1, SY_COLS = 2, SY_DONE = 3 };
+enum { SY_COLS0 = 0, SY_TILES = 1, SY_COLS1 = 2, SY_DONE = 3 };
+#define TGP_SY_XF_BIT (1 << 24)
 #define TGP_STATUS_SYNC_TIMEOUT (-77)
 #define TGP_SYNC_MAX_POLLS (1 << 22)
 
@@ -91,7 +93,7 @@ __device__ __forceinline__ void sync_leave(int32_t* sy, int nblocks_total) {
   if (threadIdx.x == 0) {
     const int old = __hip_atomic_fetch_add(sy + SY_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == nblocks_total - 1) {   // every other block has left: nobody reads the words any more
-      sync_st(sy + SY_XF, 0); sync_st(sy + SY_TILES, 0); sync_st(sy + SY_COLS, 0); sync_st(sy + SY_DONE, 0);
+      sync_st(sy + SY_COLS0, 0); sync_st(sy + SY_TILES, 0); sync_st(sy + SY_COLS1, 0); sync_st(sy + SY_DONE, 0);
     }
   }
 }
@@ -100,8 +102,8 @@ __device__ __forceinline__ void sync_leave(int32_t* sy, int nblocks_total) {
 // tile role: 16x16 tile t of {Lq, Lq^T, K_MM -> HBM} and the S = Lq Lq^T tile (one MFMA chain)
 // (sparse_MF_SP.py:316,344-346).  NT threads (256 or 512); the first 256 copy, one wave forms S.
 // ---------------------------------------------------------------------------------------------------
-// `sy` (fused launch): SY_TILES += 1 once K_MM / L_q / L_q^T are out -- the chain block waits for exactly that -- and
-// += 65536 once the S tile is (only the passenger blocks read S, tens of microseconds later).
+// `sy` (fused launch): SY_TILES += 1 once K_MM / L_q / L_q^T are out -- the chain blocks wait for exactly that -- and
+// += 1 << 16 once the S tile is (only the passenger blocks read S, tens of microseconds later).
 template <int NT, bool SHARED>
 __device__ __forceinline__ void prep_tile_role(const Plan& p, const tgp_model& md, double* __restrict__ ws, int t,
                                                int32_t* sy = nullptr) {
@@ -111,18 +113,28 @@ __device__ __forceinline__ void prep_tile_role(const Plan& p, const tgp_model& m
   // 1/l_d and sigma^2 once per block (every thread evaluating D + 1 softplus chains of its own took 4 us: nobody waited
   // for the tile blocks while they rode beside a 26 us factorisation, the fused launch's chain block does)
   __shared__ double t_ils[17];
+  // (this thread's own operands are requested before the transforms and their barrier: one memory round trip, not two)
+  double zr[16], zc[16], lq = 0.0;
+  const int rr0 = tid >> 4, cc0 = tid & 15, row0 = ti * 16 + rr0, col0 = tj * 16 + cc0;
+  const bool inside = tid < 256 && row0 < M && col0 < M;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) {
+    zr[d] = (inside && d < D) ? md.Z[(size_t)row0 * D + d] : 0.0;
+    zc[d] = (inside && d < D) ? md.Z[(size_t)col0 * D + d] : 0.0;
+  }
+  if (inside && col0 <= row0) lq = md.Lam[(size_t)row0 * M + col0];
   if (tid < 16) t_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   if (tid == 64) t_ils[16] = softplus_d(md.raw_os[0]);
   __syncthreads();
   if (tid < 256) {
-    const int rr = tid >> 4, cc = tid & 15, row = ti * 16 + rr, col = tj * 16 + cc;
-    double lq = 0.0, k = 0.0;
-    if (row < M && col < M) {
-      if (col <= row) lq = md.Lam[(size_t)row * M + col];
+    const int row = row0, col = col0;
+    double k = 0.0;
+    if (inside) {
       double d2 = 0.0;
-      for (int d = 0; d < D; ++d) {
-        const double il = t_ils[d];
-        const double tt = md.Z[(size_t)row * D + d] * il - md.Z[(size_t)col * D + d] * il;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        const double il = t_ils[d];   // 0 beyond D
+        const double tt = zr[d] * il - zc[d] * il;
         d2 += tt * tt;
       }
       k = t_ils[16] * exp_fast(-0.5 * d2);
@@ -151,7 +163,7 @@ __device__ __forceinline__ void prep_tile_role(const Plan& p, const tgp_model& m
   }
   if (sy != nullptr) {
     __syncthreads();
-    if (tid == 0) sync_add(sy + SY_TILES, 65536);
+    if (tid == 0) sync_add(sy + SY_TILES, 1 << 16);
   }
 }
 
@@ -202,7 +214,7 @@ __device__ __forceinline__ void prep_xform_role(const Plan& p, const tgp_model& 
   }
   if (sy != nullptr) {   // fused launch: everything a row block stages is out; the KL below is only read by k_bwd5
     __syncthreads();     // (drains every wave's stores)
-    if (tid == 0) sync_st(sy + SY_XF, 1);
+    if (tid == 0) sync_add(sy + SY_TILES, TGP_SY_XF_BIT);
   }
   // whitened KL (models/sparse_MF_SP.py:406-431)
   double kl_part = 0.0;
@@ -226,7 +238,10 @@ __device__ __forceinline__ void prep_xform_role(const Plan& p, const tgp_model& 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// chain role of the FUSED launch: the blocked right-looking Cholesky of K_MM by ONE 256-thread workgroup (one wave per
+// chain role of the FUSED launch: the blocked right-looking Cholesky of K_MM by a 256-thread workgroup; TWO of them (cb =
+// 0, 1) run it redundantly -- same arithmetic, bit for bit, nothing exchanged -- and share what leaves the workgroup
+// (write-out of L / L^T, the inverses of the diagonal tiles) by the parity of the panel: four waves alone spent 4-6 us per
+// block column on that against the 2.2 us of the chain's register pass.  (one wave per
 // SIMD: wave 0 -- for the rows beyond 64 below the diagonal also wave 1 -- runs the register pass of the block column,
 // potrf_panel16; the other waves take the window's tasks from a counter in LDS), publishing the operand panels of the
 // row blocks as they complete.  Differences from k_prep_a's chain blocks (tgp_mm.hip), all following from the fused
@@ -243,9 +258,10 @@ __device__ __forceinline__ void prep_xform_role(const Plan& p, const tgp_model& 
 // ---------------------------------------------------------------------------------------------------
 template <int MT>
 __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model& md, double* __restrict__ ws, int32_t* status,
-                                                 double* sm) {
+                                                 double* sm, int cb) {
   constexpr int MP = MT * 16, LD = MP + 1, NW = 4, NT = 256;
   int32_t* sy = status + 4;
+  int32_t* my_cols = sy + (cb == 0 ? SY_COLS0 : SY_COLS1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -326,27 +342,41 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
       }
     }
   };
-  // block column c, tiles (i, c), i = c .. MT-1, -= L[i rows, 0 .. 16 ncol) L[c rows, 0 .. 16 ncol)^T (all final): ONE
-  // task -- the B operand (the rows of tile row c) is read from LDS once and kept in registers for all the tiles
-  auto catch_up_col = [&](int c, int ncol) {
-    double bf[4 * (MT > 1 ? MT - 1 : 1)];
+  // block column c, tiles (i, c), i = c .. MT-1, -= L[i rows, 0 .. 16 NC) L[c rows, 0 .. 16 NC)^T (all final): ONE task.
+  // NC is a compile-time constant (dispatch below): straight-line code, the B operand (the rows of tile row c) read
+  // from LDS once and kept in registers, and two tiles per trip with all their LDS reads ahead of the first MFMA -- as
+  // a tile-by-tile loop with a run-time column count (a branch per k-step, read -> wait -> MFMA) a tile with 12 MFMAs
+  // took a microsecond.
+  auto catch_up_nc = [&](int c, auto ncc) {
+    constexpr int NC = decltype(ncc)::value;
+    double bf[4 * NC];
 #pragma unroll
-    for (int s4 = 0; s4 < 4 * (MT - 1); ++s4)
-      if (s4 < 4 * ncol) bf[s4] = A[(16 * c + r) * LD + 4 * s4 + q];
-    for (int i = c; i < MT; ++i) {
-      double af[4 * (MT > 1 ? MT - 1 : 1)], cur[4];
+    for (int s4 = 0; s4 < 4 * NC; ++s4) bf[s4] = A[(16 * c + r) * LD + 4 * s4 + q];
+    for (int i = c; i < MT; i += 2) {
+      const bool two = i + 1 < MT;
+      const int i1 = two ? i + 1 : i;
+      double af0[4 * NC], af1[4 * NC], cur0[4], cur1[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4 * (MT - 1); ++s4)
-        if (s4 < 4 * ncol) af[s4] = A[(16 * i + r) * LD + 4 * s4 + q];
+      for (int s4 = 0; s4 < 4 * NC; ++s4) { af0[s4] = A[(16 * i + r) * LD + 4 * s4 + q]; af1[s4] = A[(16 * i1 + r) * LD + 4 * s4 + q]; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = A[(16 * i + q + 4 * u) * LD + 16 * c + r];
-      d4 acc = {0, 0, 0, 0};
+      for (int u = 0; u < 4; ++u) { cur0[u] = A[(16 * i + q + 4 * u) * LD + 16 * c + r]; cur1[u] = A[(16 * i1 + q + 4 * u) * LD + 16 * c + r]; }
+      d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4 * (MT - 1); ++s4)
-        if (s4 < 4 * ncol) acc = TGP_MFMA(af[s4], bf[s4], acc);
+      for (int s4 = 0; s4 < 4 * NC; ++s4) acc0 = TGP_MFMA(af0[s4], bf[s4], acc0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) A[(16 * i + q + 4 * u) * LD + 16 * c + r] = cur[u] - acc[u];
+      for (int s4 = 0; s4 < 4 * NC; ++s4) acc1 = TGP_MFMA(af1[s4], bf[s4], acc1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[(16 * i + q + 4 * u) * LD + 16 * c + r] = cur0[u] - acc0[u];
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) A[(16 * i1 + q + 4 * u) * LD + 16 * c + r] = cur1[u] - acc1[u];
+      }
     }
+  };
+  auto catch_up_col = [&](int c, int ncol) {
+    static_for<(MT > 2 ? MT - 2 : 1)>([&](auto k) {
+      if (ncol == decltype(k)::value + 1) catch_up_nc(c, std::integral_constant<int, decltype(k)::value + 1>{});
+    });
   };
   // lower tile (ti, tj) of L and tile (tj, ti) of L^T -> global memory: four 16-byte stores per lane (lane = row 8 h +
   // (lane >> 3), column pair 2 (lane & 7)), every LDS read of the tile ahead of the first store
@@ -388,7 +418,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
     double dgv[16], xv[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) dgv[c] = A[(16 * jt + li) * LD + 16 * jt + c];
-    trtri16(dgv, xv, li);
+    trtri16<false>(dgv, xv, li);
     store_nD(jt, xv);
   };
   auto sub16 = [&](int i, int c, int k0) {
@@ -410,15 +440,15 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
   auto lds_only_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
 #ifdef TGP_STAMPS
-#define CHAIN_STAMP(i) do { if (tid == 0) ws[p.hdr + H_PSTAMP + (i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
-#define WAVE_STAMP(j, k) do { if (lane == 0) ws[p.dbg + ((j) * 4 + wave) * 4 + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define CHAIN_STAMP(i) do { if (tid == 0 && cb == 0) ws[p.hdr + H_PSTAMP + (i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define WAVE_STAMP(j, k) do { if (lane == 0 && cb == 0) ws[p.dbg + ((j) * 4 + wave) * 4 + (k)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CHAIN_STAMP(i) do { } while (0)
 #define WAVE_STAMP(j, k) do { } while (0)
 #endif
   CHAIN_STAMP(0);
 #ifdef TGP_STAMPS
-  if (tid == 0) ws[p.hdr + 61] = (double)p.dbg;
+  if (tid == 0 && cb == 0) ws[p.hdr + 61] = (double)p.dbg;
 #endif
   const bool ladder = md.jitter_ladder > 0.0;
   int attempt = 0;
@@ -436,6 +466,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
       bool did_diag = false;
       WAVE_STAMP(j, 0);
       if (wave < npw) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tile inverse this wave stored a window ago)
         const int li = lane & 15, l0 = wave * 64 + lane;
         const bool has = l0 < npan;
         const int prow = j0 + (npan > 0 ? 16 : 0) + (has ? l0 : 0);
@@ -446,6 +477,8 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
 #pragma unroll
           for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
         }
+        // (the inverse of the LAST diagonal tile rides in its pass -- nothing below the tile, every row block waiting for
+        //  it; the others are tasks of the next window: beside a panel the three-array pass took 3.6 us against 2.0)
         int bad = 0;
         if (npan > 0) {
           bad = potrf_panel16<true>(dg, a);
@@ -453,12 +486,12 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
 #pragma unroll
             for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
           }
-        } else {
-          // the last diagonal tile: its inverse rides in the pass (nothing below the tile, so no third register array
-          // beside a panel row) and goes straight to the workspace -- every row block is waiting for it
+        } else if ((j & 1) == cb) {
           double xv[16];
           bad = potrf_panel16<false, true>(dg, a, xv, li);
           store_nD(j, xv);
+        } else {
+          bad = potrf_panel16<false>(dg, a);
         }
         if (wave == 0) {
 #pragma unroll
@@ -477,11 +510,13 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
         // window c+1) -- published one window late, which costs nothing: only the last panel is ever waited for.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         WAVE_STAMP(j, 1);
-        const int nt = j >= 1 ? 1 : 0;
+        // (what leaves the workgroup is shared with the other chain block by the parity of the panel it belongs to:
+        //  panel c = tile row c and -Dinv_c, plus the diagonal tile c, is block c & 1's)
+        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;     // -Dinv_{j-1}, and the diagonal tile (j-1, j-1)
         const int nfe = j == 0 ? ((MT > 1 ? 1 : 0) + (MT > 2 ? 1 : 0)) : (j + 2 < MT ? 1 : 0);
         const int ncu = (j >= 1 && j + 1 < MT) ? 1 : 0;
-        const int nwr = j + nt;   // tiles (j, 0 .. j-1) and (j-1, j-1)
-        const int ntask = nt + nfe + ncu + nwr;
+        const int nwo = (j & 1) == cb ? j : 0;                       // tiles (j, 0 .. j-1)
+        const int ntask = nt + nfe + ncu + nwo + nt;
 #ifdef TGP_STAMPS
         int lg = 0;
 #endif
@@ -490,7 +525,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
           if (lane == 0) t = atomicAdd(&s_next, 1);
           t = __builtin_amdgcn_readfirstlane(t) - tbase;
 #ifdef TGP_STAMPS
-          if (j == 3 && lane == 0 && lg < 10) { ws[p.dbg + 120 + wave * 24 + 2 * lg] = (double)t; ws[p.dbg + 120 + wave * 24 + 2 * lg + 1] = (double)__builtin_amdgcn_s_memrealtime(); }
+          if (j == 3 && cb == 0 && lane == 0 && lg < 10) { ws[p.dbg + 120 + wave * 24 + 2 * lg] = (double)t; ws[p.dbg + 120 + wave * 24 + 2 * lg + 1] = (double)__builtin_amdgcn_s_memrealtime(); }
           ++lg;
 #endif
           if (t >= ntask) break;
@@ -509,19 +544,19 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
           t -= nfe;
           if (t < ncu) { catch_up_col(j + 1, j); continue; }
           t -= ncu;
-          if (t < j) write_L(j, t); else write_L(j - 1, j - 1);
+          if (t < nwo) write_L(j, t); else write_L(j - 1, j - 1);
         }
       }
       {
-        const int nt = j >= 1 ? 1 : 0;
+        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;
         const int nfe = j == 0 ? ((MT > 1 ? 1 : 0) + (MT > 2 ? 1 : 0)) : (j + 2 < MT ? 1 : 0);
-        tbase += nt + nfe + ((j >= 1 && j + 1 < MT) ? 1 : 0) + j + nt + (NW - npw);   // tasks + one over-grab per task wave
+        tbase += 2 * nt + nfe + ((j >= 1 && j + 1 < MT) ? 1 : 0) + ((j & 1) == cb ? j : 0) + (NW - npw);   // tasks + one over-grab per task wave
       }
       WAVE_STAMP(j, 3);
       lds_only_barrier();
       CHAIN_STAMP(2 + 2 * j);
       failed = s_info != 0 || s_sync != 0;
-      if (j >= 2 && !failed && tid == 0) sync_st(sy + SY_COLS, 16 * attempt + j - 1);
+      if (j >= 2 && !failed && tid == 0) sync_st(my_cols, 16 * attempt + j - 1);
       if (failed) break;
       if (did_diag) {
 #pragma unroll
@@ -545,13 +580,15 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
   // tail: the last diagonal tile of L (k_bwd12 reads it; its inverse left with the pass), every store of the launch
   // drained, then the terminal count.  A final attempt that failed still publishes -- the row blocks must not wait for
   // ever; status[] tells the host.
-  if (wave == 1) write_L(MT - 1, MT - 1);
+  if (wave == 1 && ((MT - 1) & 1) == cb) write_L(MT - 1, MT - 1);
   window_barrier();
   if (tid == 0) {
-    status[0] = s_sync != 0 ? TGP_STATUS_SYNC_TIMEOUT : s_info;
-    status[1] = s_nan;
-    status[2] = (s_info == 0 && s_sync == 0) ? attempt : 0;
-    sync_st(sy + SY_COLS, 16 * attempt + MT);
+    if (cb == 0) {   // (the other chain block arrives at the same three words)
+      status[0] = s_sync != 0 ? TGP_STATUS_SYNC_TIMEOUT : s_info;
+      status[1] = s_nan;
+      status[2] = (s_info == 0 && s_sync == 0) ? attempt : 0;
+    }
+    sync_st(my_cols, 16 * attempt + MT);
   }
   CHAIN_STAMP(2 + 2 * MT);
 #undef CHAIN_STAMP
