@@ -158,30 +158,39 @@ def cpu_baseline(prob, budget_s=15.0, max_steps=400, mlp=None):
         opt.step()
 
     ncpu = os.cpu_count() or 1
-    best, best_t = 1, float("inf")
-    cand = {min(8, ncpu), min(32, ncpu), min(64, ncpu)} if big else {1, min(4, ncpu), min(8, ncpu), min(16, ncpu), min(32, ncpu)}
-    for nt in sorted(cand):
+    # Thread count: every candidate is timed for >= 1.5 s (a share of the budget) and the best measured RATE is kept --
+    # best-of-three single steps flipped the choice between 16 and 32 threads from run to run, and the reported
+    # baseline with it (20 vs 33 steps/s on the same host).  All candidates are reported in `sample`.
+    cand = sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu)} if big else {1, min(4, ncpu), min(8, ncpu), min(16, ncpu), min(32, ncpu)})
+    per = max(1.5, 0.4 * budget_s / len(cand))
+    rates = {}
+    for nt in cand:
         torch.set_num_threads(nt)
-        one()
-        t = float("inf")
-        for _ in range(1 if big else 3):          # best of three: one noisy step used to flip the choice between runs
-            t0 = time.perf_counter()
+        one()                                     # warm the pool
+        t0 = time.perf_counter()
+        k = 0
+        while True:
             one()
-            t = min(t, time.perf_counter() - t0)
-        if t < best_t:
-            best, best_t = nt, t
-        if t > 3.0:
+            k += 1
+            dtc = time.perf_counter() - t0
+            if dtc >= per or (big and k >= 1):
+                break
+        rates[nt] = k / dtc
+        if dtc / k > 3.0:
             break
+    best = max(rates, key=rates.get)
     torch.set_num_threads(best)
+    one()
     t0 = time.perf_counter()
     n = 0
-    while n < max_steps and time.perf_counter() - t0 < budget_s:
+    while n < max_steps and time.perf_counter() - t0 < budget_s * 0.6:
         one()
         n += 1
     dt = time.perf_counter() - t0
+    cal = ", ".join("%d thr %.1f/s" % (nt, rates[nt] * ns / N) for nt in sorted(rates))
     return {"value": n / dt * ns / N, "unit": "ELBO-steps/s", "cores": best, "kind": "port", "host_cpus": ncpu,
-            "sample": "%d steps on the first %d of %d rows%s (oracle/tgp_oracle.py, float64, torch.optim.Adam, %d threads "
-                      "chosen by calibration), %.1f s" % (n, ns, N, ", rate scaled by rows" if ns < N else "", best, dt)}
+            "sample": "%d steps on the first %d of %d rows%s (oracle/tgp_oracle.py, float64, torch.optim.Adam, %d threads: the "
+                      "best of the calibrated rates [%s], each timed >= %.1f s), %.1f s" % (n, ns, N, ", rate scaled by rows" if ns < N else "", best, cal, per, dt)}
 
 
 def launch_ranks(n):
@@ -216,9 +225,11 @@ def main():
                     help="default: strong for the Power / Boston workloads (north_star: the same problem on 1/2/4/8 GPUs), "
                          "weak for the airline workloads (a rank's 250 k rows are 1/8 of configs[4])")
     ap.add_argument("--capture-allreduce", action="store_true", help="capture the collective inside the HIP graph")
-    ap.add_argument("--collective", default="torch", choices=["torch", "abi"],
-                    help="torch: torch.distributed.all_reduce between two graphs (default); abi: the C ABI's tgp_allreduce_f64 "
-                         "(RCCL on the compute stream, inside the captured step, U steps per graph launch); needs backend nccl")
+    ap.add_argument("--collective", default="auto", choices=["auto", "torch", "abi"],
+                    help="auto (default): over RCCL with more than one rank the engine checks the C ABI's tgp_allreduce_f64 "
+                         "against torch.distributed.all_reduce on a seeded buffer and, when every rank agrees, uses it (RCCL on "
+                         "the compute stream, inside ONE captured graph, U steps per launch); otherwise, and with `torch`, "
+                         "torch.distributed.all_reduce between two graphs; `abi` skips the check")
     ap.add_argument("--replicas", type=int, default=1, help="(1 GPU only) K independent training runs of the workload on K "
                     "streams, value = their aggregate steps/s: how the chip is filled when several UCI splits train at once")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
@@ -278,7 +289,8 @@ def main():
     eng = ElboEngine(Xr, Yr, params, N_total=float(n_global), flow_blocks=prob["program"],
                      S=w["S"], device=dev, world_size=world, rank=rank, mb_global=n_global,
                      mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None,
-                     collective=args.collective if world > 1 else "torch")
+                     collective=(None if args.collective == "auto" else args.collective) if world > 1 else "torch")
+    log("collective: %s" % json.dumps(eng.collective_info))
 
     def barrier():
         if world > 1:
@@ -330,8 +342,22 @@ def main():
             for _ in range(k):
                 run()
     run_steps(args.warmup)
+    # A short run (the driver's --steps 20 at 0.11 ms is 2 ms of GPU work) is repeated until >= 50 ms have been timed in
+    # total: `steps` stays as given, the median repeat is still what is reported, `repeats` says how many there were.
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    probe = time.perf_counter() - t0
+    nrep = max(args.repeats, 1)
+    if probe * nrep < 0.05:
+        nrep = min(int(0.05 / max(probe, 1e-6)) + 1, 2000)
+        if world > 1:                              # the same count on every rank
+            t = torch.tensor([float(nrep)], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            nrep = int(t[0])
     dts = []
-    for _ in range(max(args.repeats, 1)):
+    for _ in range(nrep):
         barrier()
         t0 = time.perf_counter()
         run_steps(args.steps)
@@ -391,6 +417,7 @@ def main():
               "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
               "allreduce": ("none" if world == 1 else ("in-graph" if eng.graph == "full" else "between two graphs")),
               "collective": ("tgp_allreduce_f64 (C ABI, compute stream)" if eng.comm is not None else "torch.distributed"),
+              "selfcheck": eng.collective_info.get("selfcheck"), "selfcheck_detail": eng.collective_info.get("why"),
               "allreduce_doubles": eng.fp.n + eng.fp.extra}
         result = {
             # BASELINE.json's metric string for the configuration it is quoted on; other workloads say what they are
@@ -412,9 +439,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds, mlp=mlp)
     if world > 1:
         torch.distributed.barrier()
-        if eng.comm is not None:
-            torch.cuda.synchronize()
-            eng.comm.close()
+        torch.cuda.synchronize()
+        eng.close()
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -64,6 +64,11 @@ def test_engine_graphs_with_a_live_rccl_group(tmp_path):
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["graphs"] == [None, "split", "full"], res["graphs"]
     assert res["split_equals_eager"] and res["full_equals_eager"], res
+    # the default collective of a multi-rank engine over RCCL: self-checked, promoted, one graph, unrolled
+    a = res["auto"]
+    assert a["promoted"] and a["info"]["collective"] == "abi" and a["info"]["selfcheck"] == "pass", a
+    assert a["graph"] == "full" and a["unroll"] == 4
+    assert a["many_equals_single"] and a["elbo_is_ell_minus_reduced_kl"], a
 
 
 def test_bench_starts_its_own_ranks():
@@ -84,6 +89,8 @@ def test_bench_starts_its_own_ranks():
     assert res["metric"] == "ELBO-steps/sec (N x M kernel + chol + flow), Power M=100 S=32"
     assert res["config"]["global_rows_per_step"] == 8611 and res["config"]["rows_per_gpu"] in (4305, 4306)
     pg = res["config"]["process_group"]
+    # (gloo rehearsal: no RCCL under the group, so the engine keeps torch.distributed -- the fallback branch)
+    assert pg["collective"] == "torch.distributed" and pg["selfcheck"] == "skipped"
     assert pg["world_size"] == 2 and pg["backend"] == "gloo" and pg["allreduce"] == "between two graphs"
     assert res["value"] > 0 and res["config"]["final_elbo"] == res["config"]["final_elbo"]
 

@@ -220,3 +220,17 @@ def test_timeline_tool_reads_a_kernel_trace(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "timeline.py"), str(f)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "step = 4 kernels" in out.stdout and "k_rows<7, 4, 1>" in out.stdout and "union of kernel intervals" in out.stdout
+
+
+def test_collective_decision_function():
+    """engine.choose_collective: which all-reduce a data-parallel engine starts with (VERDICT r3 #2)."""
+    from tgp.pytorch_amd.engine import choose_collective as c
+    assert c(None, 1, None) == ("torch", False)            # one rank, no process group: nothing to reduce
+    assert c(None, 2, "gloo") == ("torch", False)          # rehearsal backend: no RCCL under it
+    assert c(None, 8, "nccl") == ("abi", True)             # the 8-GPU node: ABI collective, after its self-check
+    assert c("auto", 1, "nccl") == ("abi", True)           # asked for explicitly: one rank is enough to run the check
+    assert c("torch", 8, "nccl") == ("torch", False)       # the caller's choice is taken as is
+    assert c("abi", 2, "gloo") == ("abi", False)
+    import pytest
+    with pytest.raises(ValueError):
+        c("rccl", 2, "nccl")

@@ -4,7 +4,7 @@ ELBO -> (-ELBO).backward() -> Adam.step()) with everything resident on the GPU.
 * every trainable tensor is a view into ONE flat float64 buffer (parameters, gradients, Adam moments),
   so the optimiser is a single launch and the multi-GPU exchange is a single all-reduce;
 * the C-ABI argument structs are built once (pointers never change), so one step is
-  `tgp_elbo_step_f64` + `tgp_adam_dev_groups_f64` = 7 kernel launches (M <= 128) with no host synchronisation, plus
+  `tgp_elbo_step_adam_f64` = 6 kernel launches (M <= 128) with no host synchronisation, plus
   the MLP forward/backward launches for input-dependent flows;
 * `capture()` records that sequence into a HIP graph (torch.cuda.CUDAGraph is only the stream/graph
   plumbing) and `replay()` re-launches it;
@@ -76,6 +76,23 @@ class RcclComm:
             self.comm = None
 
 
+def choose_collective(requested, world_size, backend):
+    """Which all-reduce a data-parallel engine starts with, and whether it has to prove itself first.
+    Returns (candidate, needs_selfcheck): candidate in {"torch", "abi"}.
+      "torch": torch.distributed.all_reduce between two graphs (any backend; one Python iteration per step);
+      "abi"  : tgp_allreduce_f64 on the compute stream, a node of ONE captured graph (U steps per launch).
+    `requested`: None / "auto" = pick; "torch" / "abi" = the caller's choice, taken as is.  "auto" proposes the ABI
+    collective wherever RCCL is the transport (backend "nccl") and more than one rank exists -- subject to the
+    self-check of ElboEngine._selfcheck_collective -- and torch.distributed everywhere else (gloo rehearsals, one rank)."""
+    if requested in ("torch", "abi"):
+        return requested, False
+    if requested not in (None, "auto"):
+        raise ValueError("collective must be None, 'auto', 'torch', 'abi' or an RcclComm")
+    if backend == "nccl" and (world_size > 1 or requested == "auto"):
+        return "abi", True
+    return "torch", False
+
+
 def pre_reduce(grad, n, world_size):
     """KL is identical on every rank: pre-divide so that the sum restores it."""
     grad[n + 2].div_(world_size)
@@ -141,14 +158,36 @@ class ElboEngine:
         # compute stream, INSIDE the captured step (one graph, U steps per launch like a single rank's) -- an RcclComm or
         # the string (a communicator is then created here; torch.distributed only carries its 128-byte id).  With "abi" a
         # 1-rank engine runs the collective too (sum over one rank): the path the GPU tests can reach on one GPU.
-        collective = collective if collective is not None else os.environ.get("TGP_COLLECTIVE", "torch")
-        self.comm = None
+        # Default (None / "auto"): with more than one rank over RCCL the engine builds the ABI communicator, reduces a seeded
+        # buffer through BOTH paths and keeps the ABI collective only if every rank saw the same sums (choose_collective,
+        # _selfcheck_collective); any other situation keeps torch.distributed.  `collective_info` records the decision.
+        collective = collective if collective is not None else os.environ.get("TGP_COLLECTIVE") or None
+        self.comm, self._own_comm = None, False
+        self.collective_info = {"collective": "torch", "selfcheck": "skipped", "why": "one rank"}
         if isinstance(collective, RcclComm):
             self.comm = collective
-        elif collective == "abi":
-            self.comm = RcclComm(self.world_size, self.rank, process_group)
-        elif collective != "torch":
-            raise ValueError("collective must be 'torch', 'abi' or an RcclComm")
+            self.collective_info = {"collective": "abi", "selfcheck": "skipped", "why": "communicator passed in"}
+        else:
+            backend = torch.distributed.get_backend(process_group) if torch.distributed.is_initialized() else None
+            cand, check = choose_collective(collective, self.world_size, backend)
+            self.collective_info = {"collective": cand, "selfcheck": "skipped",
+                                    "why": "requested" if collective in ("torch", "abi") else "backend %s, %d rank(s)" % (backend, self.world_size)}
+            if cand == "abi":
+                # (RCCL binds the communicator and the stream to the CURRENT device: make that this engine's)
+                with torch.cuda.device(self.device):
+                    # (the communicator spans the process group that carries its id, whatever `world_size` weights KL with)
+                    cw = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else self.world_size
+                    cr = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else self.rank
+                    self.comm = RcclComm(cw, cr, process_group)
+                    self._own_comm = True
+                    if check:
+                        ok, why = self._selfcheck_collective(process_group)
+                        self.collective_info.update(selfcheck="pass" if ok else "fail", why=why)
+                        if not ok:
+                            import warnings
+                            warnings.warn("tgp_allreduce_f64 failed its self-check (%s): keeping torch.distributed.all_reduce" % why)
+                            self.close()
+                            self.collective_info["collective"] = "torch"
         self.X = X.to(self.device, torch.float64).contiguous()
         self.Y = Y.reshape(-1).to(self.device, torch.float64).contiguous()
         self.N, self.D = self.X.shape
@@ -222,6 +261,35 @@ class ElboEngine:
         self.graph = None
         self._warm = False
 
+    def _selfcheck_collective(self, group, n=4099, seed=1234):
+        """First contact with the node: the same seeded buffer (different on every rank) summed through tgp_allreduce_f64
+        and through torch.distributed.all_reduce; the ABI collective is kept only if EVERY rank got the same sums to
+        1e-15 relative (a ring and a tree add in different orders: not bitwise).  One host sync, before any capture."""
+        g = torch.Generator(device="cpu").manual_seed(seed + self.rank)
+        ref = torch.randn(n, generator=g, dtype=torch.float64).to(self.device)
+        a, b = ref.clone(), ref.clone()
+        self.comm.allreduce(a, n)
+        torch.distributed.all_reduce(b, op=torch.distributed.ReduceOp.SUM, group=group)
+        err = float(((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).cpu())
+        ok = torch.tensor([1.0 if err <= 1e-15 * max(self.world_size, 1) else 0.0], dtype=torch.float64, device=self.device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=group)
+        good = bool(ok.item() > 0.5)
+        return good, "max rel diff %.1e on rank %d, all ranks %s" % (err, self.rank, "agree" if good else "do NOT agree")
+
+    def close(self):
+        """Destroy the communicator this engine created (one it was handed stays its owner's)."""
+        if self.comm is not None and self._own_comm:
+            with torch.cuda.device(self.device):
+                self.comm.close()
+        if self._own_comm:
+            self.comm, self._own_comm = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ---- one step, eager launches ------------------------------------------------------------------
     def elbo(self, phases=7):
         out = self.fp.out if self._out is None else self._out      # (ELBO, ELL, KL) of this step: see capture(unroll)
@@ -246,7 +314,8 @@ class ElboEngine:
     def allreduce(self):
         if self.comm is not None:
             pre_reduce(self.fp.grad, self.fp.n, self.world_size)
-            self.comm.allreduce(self.fp.grad, self.fp.n + self.fp.extra)
+            with torch.cuda.device(self.device):
+                self.comm.allreduce(self.fp.grad, self.fp.n + self.fp.extra)
             post_reduce(self.fp.grad, self.fp.n)
             return
         allreduce_flat(self.fp.grad, self.fp.n, self.world_size, self.pg)
@@ -436,11 +505,17 @@ class ElboEngine:
             return
         self.hist_u = torch.zeros(U - 1, 4, dtype=torch.float64, device=self.device)
         gU = torch.cuda.CUDAGraph()
+        # With a collective in the unit the step's scalars must stay where allreduce() / pre_reduce / post_reduce act on
+        # them -- behind the gradients in fp.grad -- and reach hist_u by a captured 4-double copy AFTER the reduction; the
+        # redirected `out` of the single-rank form would log rank-local, un-reduced values (and re-sum a stale slot).
+        reduced = self.comm is not None or self.world_size > 1
         try:
             with torch.cuda.graph(gU, capture_error_mode=CAPTURE_MODE):
                 for u in range(U):
-                    self._out = self.hist_u[u] if u < U - 1 else None
+                    self._out = self.hist_u[u] if (u < U - 1 and not reduced) else None
                     unit()
+                    if reduced and u < U - 1:
+                        self.hist_u[u].copy_(self.fp.out)
         finally:
             self._out = None        # a failed capture must not leave later steps writing their scalars into hist_u
         self.gU, self.unroll = gU, U
