@@ -136,9 +136,13 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
     // every gradient of the call must be a view of adam->grads
     const double* lo = adam->grads;
     const double* hi = adam->grads + adam->n;
+    // ... START AND EXTENT: the update kernels index params / exp_avg / exp_avg_sq with the gradients' offsets, so a block
+    // that ran past adam->n would be written past the caller's buffers
     const double* gp[7] = {grads->Z, grads->raw_ls, grads->raw_os, grads->m, grads->Lam, grads->log_var_noise, grads->theta};
+    const size_t gn[7] = {(size_t)model->M * model->D, (size_t)model->D, 1, (size_t)model->M, (size_t)model->M * model->M, 1,
+                          (size_t)P};
     for (int k = 0; k < 7; ++k)
-      if (gp[k] != nullptr && (gp[k] < lo || gp[k] >= hi)) return -12;
+      if (gp[k] != nullptr && gn[k] > 0 && (gp[k] < lo || gp[k] + gn[k] > hi)) return -12;
     ad.p = adam->params; ad.g = adam->grads; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.n = (long)adam->n;
     ad.lam_off = (long)(grads->Lam - adam->grads); ad.lam_n = (long)model->M * model->M;
     ad.lr = adam->lr; ad.b1 = adam->beta1; ad.b2 = adam->beta2; ad.eps = adam->eps;
@@ -552,6 +556,13 @@ int tgp_mlp_backward_adam_f64(const tgp_mlp* mlp, const double* X, double* W, co
   if (!g_W) return -6;
   if (!workspace) return -7;
   if (!adam || adam->params != W || adam->grads != g_W || !adam->exp_avg || !adam->exp_avg_sq || !adam->step_dev) return -9;
+  // the optimiser state must cover every weight the kernel updates (nnets x weights per net)
+  {
+    size_t per = (size_t)mlp->H * mlp->D + mlp->H;
+    for (int l = 1; l < mlp->L; ++l) per += (size_t)mlp->H * mlp->H + mlp->H;
+    per += (size_t)mlp->H + 1;
+    if (adam->n < 1 || (size_t)adam->n != per * (size_t)mlp->nnets) return -9;
+  }
   AdamDev ad;
   ad.p = adam->params; ad.g = adam->grads; ad.m = adam->exp_avg; ad.v = adam->exp_avg_sq; ad.n = (long)adam->n;
   ad.lr = adam->lr; ad.b1 = adam->beta1; ad.b2 = adam->beta2; ad.eps = adam->eps;

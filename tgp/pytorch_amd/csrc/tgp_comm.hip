@@ -37,8 +37,14 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_mu;
 
-int comm_error(const char* what, int rc) {
-  set_error_text("%s: %s (%d)", what, g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "RCCL error", rc);
+// the table as it stands (a copy taken under the lock: comm_load may be filling it on another host thread)
+Rccl rccl() {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_rccl;
+}
+
+int comm_error(const Rccl& r, const char* what, int rc) {
+  set_error_text("%s: %s (%d)", what, r.get_error_string ? r.get_error_string(rc) : "RCCL error", rc);   // (thread-local text)
   return TGP_E_COMM;
 }
 }  // namespace
@@ -69,32 +75,36 @@ int comm_load(const char* path) {
 }
 
 int comm_unique_id(void* id128) {
-  if (g_rccl.handle == nullptr) return TGP_E_COMM;
+  const Rccl r = rccl();
+  if (r.handle == nullptr) return TGP_E_COMM;
   UniqueId id;
-  if (int rc = g_rccl.get_unique_id(&id)) return comm_error("ncclGetUniqueId", rc);
+  if (int rc = r.get_unique_id(&id)) return comm_error(r, "ncclGetUniqueId", rc);
   memcpy(id128, id.internal, sizeof(id.internal));
   return 0;
 }
 
 int comm_init(const void* id128, int nranks, int rank, void** comm) {
-  if (g_rccl.handle == nullptr) return TGP_E_COMM;
+  const Rccl r = rccl();
+  if (r.handle == nullptr) return TGP_E_COMM;
   UniqueId id;
   memcpy(id.internal, id128, sizeof(id.internal));
   Comm c = nullptr;
-  if (int rc = g_rccl.comm_init_rank(&c, nranks, id, rank)) return comm_error("ncclCommInitRank", rc);
+  if (int rc = r.comm_init_rank(&c, nranks, id, rank)) return comm_error(r, "ncclCommInitRank", rc);
   *comm = c;
   return 0;
 }
 
 int comm_allreduce(void* comm, double* buf, int64_t n, hipStream_t st) {
-  if (g_rccl.handle == nullptr) return TGP_E_COMM;
-  if (int rc = g_rccl.all_reduce(buf, buf, (size_t)n, kFloat64, kSum, comm, st)) return comm_error("ncclAllReduce", rc);
+  const Rccl r = rccl();
+  if (r.handle == nullptr) return TGP_E_COMM;
+  if (int rc = r.all_reduce(buf, buf, (size_t)n, kFloat64, kSum, comm, st)) return comm_error(r, "ncclAllReduce", rc);
   return 0;
 }
 
 int comm_destroy(void* comm) {
-  if (g_rccl.handle == nullptr) return TGP_E_COMM;
-  if (int rc = g_rccl.comm_destroy(comm)) return comm_error("ncclCommDestroy", rc);
+  const Rccl r = rccl();
+  if (r.handle == nullptr) return TGP_E_COMM;
+  if (int rc = r.comm_destroy(comm)) return comm_error(r, "ncclCommDestroy", rc);
   return 0;
 }
 

@@ -279,7 +279,8 @@ def nets_rowp(nets, X2d, samples=1, spec=None):
         step[0] += 1                                    # a fresh mask per call
     W = torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()])
     Xs = X2d.contiguous() if samples == 1 else X2d.repeat(samples, 1)
-    return ops.mlp_forward(spec, Xs, W, bool(drop_on), step)
+    # (this call site's own mask stream: its counter starts at 0 like the training step's and the evaluation's)
+    return ops.mlp_forward(spec.salted(ops.MASK_SALT_NETS), Xs, W, bool(drop_on), step)
 
 
 def compile_flow(flow):

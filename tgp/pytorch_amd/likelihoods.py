@@ -33,9 +33,9 @@ class GaussianLinearMean(_GaussianBase):
     """p(y|f) = N(y|f, s2): closed-form ELL (GaussianLinearMean.py:60-87) and moments (:89-118)."""
 
     def expected_log_prob(self, Y, gauss_mean, gauss_cov, **kwargs):
-        ell, _, _, _ = ops.ell_gauss(Y.reshape(-1), gauss_mean.reshape(-1).contiguous(), gauss_cov.reshape(-1).contiguous(),
-                                     self._lvn().detach().reshape(-1)[:1].contiguous())
-        return ell.reshape(1)
+        # differentiable in the moments and the noise like the reference's torch code (gradients from the same launch)
+        return ops.EllGaussFunction.apply(Y.reshape(-1), gauss_mean.reshape(-1).contiguous(), gauss_cov.reshape(-1).contiguous(),
+                                          self._lvn().reshape(-1)[:1].contiguous())
 
     def marginal_moments(self, gauss_mean, gauss_cov, diagonal=True, **kwargs):
         assert diagonal, "only diagonal covariances on this path"
@@ -50,21 +50,37 @@ class GaussianNonLinearMean(_GaussianBase):
         super().__init__(out_dim, noise_init, noise_is_shared)
         self.quad_points = quadrature_points
 
-    def _flow_inputs(self, flow, X, dev):
+    def _flow_inputs(self, flow, X, dev, with_grad=False):
         spec, theta_list, nets = compile_flow(flow[0])
-        theta = torch.stack([p.detach().reshape(()) for p in theta_list]).to(dev) if theta_list else None
+        if with_grad:     # keep the graph to the flow's parameters (expected_log_prob)
+            theta = torch.stack([p.reshape(()) for p in theta_list]).to(dev) if theta_list else None
+        else:
+            theta = torch.stack([p.detach().reshape(()) for p in theta_list]).to(dev) if theta_list else None
         rowp = None
         if nets:
             from .flow import nets_rowp
-            rowp = nets_rowp(nets, X[0] if X.dim() == 3 else X)      # the HIP MLP kernel (dropout follows the layers)
+            X2d = X[0] if X.dim() == 3 else X
+            if with_grad and torch.is_grad_enabled():
+                from .flow import mlp_spec, _mask_step
+                mspec = mlp_spec(nets, seed=cg.config_seed)
+                if mspec is None:
+                    raise ops.L.TgpError("the flow's parameter networks are outside the HIP MLP kernel's coverage")
+                step = _mask_step.setdefault(str(X2d.device), torch.zeros(2, dtype=torch.int32, device=X2d.device))
+                drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
+                if drop_on:
+                    step[0] += 1
+                W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
+                rowp = ops.MlpFunction.apply(X2d.detach().contiguous(), W, mspec.salted(ops.MASK_SALT_NETS), bool(drop_on), step.clone())
+            else:
+                rowp = nets_rowp(nets, X2d)      # the HIP MLP kernel (dropout follows the layers)
         return spec, theta, rowp
 
     def expected_log_prob(self, Y, gauss_mean, gauss_cov, flow, X, **kwargs):
         assert len(flow) == self.out_dim == 1, "one flow per output; Dy = 1 on this path"
-        spec, theta, rowp = self._flow_inputs(flow, X, gauss_mean.device)
-        res = ops.ell_flow(Y.reshape(-1), gauss_mean.reshape(-1).contiguous(), gauss_cov.reshape(-1).contiguous(),
-                           self._lvn().detach().reshape(-1)[:1].contiguous(), spec, theta, self.quad_points, rowp)
-        return res["ell"].reshape(1)
+        # differentiable in the moments, the noise and the flow's parameters like the reference's torch code
+        spec, theta, rowp = self._flow_inputs(flow, X, gauss_mean.device, with_grad=True)
+        return ops.EllFlowFunction.apply(Y.reshape(-1), gauss_mean.reshape(-1).contiguous(), gauss_cov.reshape(-1).contiguous(),
+                                         self._lvn().reshape(-1)[:1].contiguous(), theta, rowp, spec, self.quad_points)
 
     def marginal_moments(self, gauss_mean, gauss_cov, flow, X, **kwargs):
         assert len(flow) == self.out_dim == 1

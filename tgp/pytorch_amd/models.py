@@ -164,7 +164,10 @@ class sparse_MF_SP(nn.Module):
                 # over minibatches, an evaluation between ELBO() and backward()) must not change the mask the
                 # backward recomputes
                 Xs = X2d.contiguous() if samples == 1 else X2d.repeat(samples, 1)
-                rowp = ops.MlpFunction.apply(Xs, W, mspec, bool(drop_on), self._cfg["mlp_step"].clone())
+                # evaluation draws from a mask stream of its own: the resident engine counts its training steps from 0
+                # too, and MC-dropout samples at test time must not replay the masks of training step k
+                mcall = mspec if with_grad else mspec.salted(ops.MASK_SALT_EVAL)
+                rowp = ops.MlpFunction.apply(Xs, W, mcall, bool(drop_on), self._cfg["mlp_step"].clone())
         return spec, theta, rowp
 
     # ---- model computations ------------------------------------------------------------------------

@@ -508,6 +508,47 @@ def ell_flow(Y, mu, v, lvn, flow, theta, S, rowp=None, scale=1.0):
     return {"ell": out[0], "g_lvn": out[1], "g_mu": gmu, "g_v": gv, "g_theta": gth[:flow.P], "g_rowp": grp}
 
 
+class EllGaussFunction(torch.autograd.Function):
+    """ELL = GaussianLinearMean.expected_log_prob (likelihoods/GaussianLinearMean.py:60-87) with autograd in (mu, v,
+    log_var_noise) -- the reference's method is plain torch code, differentiable wherever it is called; tgp_ell_gauss_f64
+    returns the value and every gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, Y, mu, v, lvn):
+        ell, g_lvn, gmu, gv = ell_gauss(Y, mu.detach(), v.detach(), lvn.detach())
+        ctx.save_for_backward(g_lvn, gmu, gv)
+        ctx.lvn_shape = lvn.shape
+        return ell.reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g_lvn, gmu, gv = ctx.saved_tensors
+        g = g.reshape(())
+        return None, g * gmu, g * gv, (g * g_lvn).reshape(ctx.lvn_shape)
+
+
+class EllFlowFunction(torch.autograd.Function):
+    """ELL = GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:64-150) with autograd in (mu, v,
+    log_var_noise, theta, rowp): tgp_ell_flow_f64 returns all of them."""
+
+    @staticmethod
+    def forward(ctx, Y, mu, v, lvn, theta, rowp, flow, S):
+        res = ell_flow(Y, mu.detach(), v.detach(), lvn.detach(), flow, theta.detach() if theta is not None else None, S,
+                       rowp.detach() if rowp is not None else None)
+        ctx.save_for_backward(res["g_lvn"], res["g_mu"], res["g_v"], res["g_theta"],
+                              res["g_rowp"] if res["g_rowp"] is not None else res["g_lvn"])
+        ctx.has = (theta is not None, rowp is not None)
+        ctx.lvn_shape = lvn.shape
+        return res["ell"].reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g_lvn, gmu, gv, gth, grp = ctx.saved_tensors
+        g = g.reshape(())
+        return (None, g * gmu, g * gv, (g * g_lvn).reshape(ctx.lvn_shape), g * gth if ctx.has[0] else None,
+                g * grp if ctx.has[1] else None, None, None)
+
+
 def flow_eval(f, flow, theta, rowp=None, want=("G", "dG", "logdG")):
     """G(f), dG/df, log dG/df for f of shape (S,N) or (N,) (CompositeFlow.forward / forward_grad)."""
     lib = L.load()
@@ -572,6 +613,13 @@ class MlpSpec:
         self.act = {"relu": 0, "tanh": 1}[act]
         self.drop_p, self.seed = float(drop_p), int(seed)
 
+    def salted(self, salt):
+        """The same networks with the dropout-mask stream of another call site (seed ^ salt): masks are a hash of (seed,
+        step, net, layer, row, unit) and every call site counts its own steps from 0, so without a salt the masks of
+        evaluation call k would be those of training step k."""
+        return MlpSpec(self.D, self.H, self.L, self.nnets, act={0: "relu", 1: "tanh"}[self.act], drop_p=self.drop_p,
+                       seed=self.seed ^ int(salt))
+
     @property
     def weights_per_net(self):
         return self.D * self.H + self.H + (self.L - 1) * (self.H * self.H + self.H) + self.H + 1
@@ -634,6 +682,10 @@ class MlpFunction(torch.autograd.Function):
     def backward(ctx, g_out):
         X, W = ctx.saved_tensors
         return None, mlp_backward(ctx.spec, X, W.detach(), g_out.contiguous(), ctx.training, ctx.step_dev), None, None, None
+
+
+MASK_SALT_EVAL = 0x45564131     # model-class evaluation (test_log_likelihood, predictive moments)
+MASK_SALT_NETS = 0x4E455453     # flow.nets_rowp (CompositeFlow.forward, sampling)
 
 
 def mlp_keep_mask(seed, step, net, layer, rows, units, p):
