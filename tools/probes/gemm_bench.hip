@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
   {
     // pipeline shapes: NC x MP x MP triangular (n-major layout), SYRK and T
     const int NC = argc > 1 ? atoi(argv[1]) : 15744, MP = 1024;
+    const int LDP = argc > 2 ? atoi(argv[2]) : 0;   // leading-dimension padding of the x-major operands (doubles): 0 = the power-of-two stride
     struct { const char* name; bool ta, tb; int tri, xcd; } cs[] = {
       {"NT full        ", false, true, 0, 0}, {"NT full xcd1   ", false, true, 0, 1},
       {"NT triBU       ", false, true, TRI_B_UPPER, 0}, {"NT triBU xcd1  ", false, true, TRI_B_UPPER, 1},
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
     for (auto& c : cs) {
       GemmArgs g;
       if (c.ta) g = gemm_args(A, MP, B, NC, C, NC, MP, NC, MP, 1.0, 0.0, c.tri);  // m-major: C[MP][NC] = J^T-like [k][m] x Kc [k][NC]
-      else g = gemm_args(A, MP, B, MP, C, MP, NC, MP, MP, 1.0, 0.0, c.tri);
+      else g = gemm_args(A, MP + LDP, B, MP + LDP, C, MP + LDP, NC, MP, MP, 1.0, 0.0, c.tri);
       g.xcd = c.xcd;
       float t = c.ta ? run<true, false>(g, 10) : (c.tb ? run<false, true>(g, 10) : run<false, false>(g, 10));
       const double f = 2.0 * NC * (double)MP * MP * (c.tri ? 0.5625 : 1.0);
