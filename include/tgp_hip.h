@@ -43,7 +43,7 @@ extern "C" {
 #endif
 
 #define TGP_VERSION 102
-#define TGP_FUSED_MAX_M 128 /* up to here the whole step is 7 fused kernels (operators resident in LDS/registers) */
+#define TGP_FUSED_MAX_M 128 /* up to here the whole step is 6 fused kernel launches (operators resident in LDS/registers) */
 #define TGP_BIG_MAX_M 4096  /* above: chunked path built on a tiled float64 MFMA GEMM                             */
 
 /* error codes (negative return values below -64 are generic) */
