@@ -20,5 +20,3 @@ for n, v in zip(names, w0):
         print("  %-22s %8.0f" % (n, v))
 print("  total %.0f cycles" % sum(w0))
 print("window work per wave (cycles; j = 0 | summed over j >= 1): " + "  ".join("w%d %.0f|%.0f" % (k, w2[2 * k], w2[2 * k + 1]) for k in range(8)))
-tt = eng.ws[32 + 27:32 + 32].cpu().tolist(); tc = eng.ws[21:26].cpu().tolist()
-print("wave 3 by task type (cycles total / count): " + "  ".join("%s %.0f/%d" % (n, a, c) for n, a, c in zip(["fill+catchup", "sub16", "inv_tile", "write_L", "write_J"], tt, tc)))
