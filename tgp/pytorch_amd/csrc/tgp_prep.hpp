@@ -10,9 +10,9 @@
 // (status[4..7]; the ABI asks for them to be zero before the first call, every launch leaves them zero):
 //   SY_TILES bits 0-15: number of tile blocks that have written their tiles of L_q, L_q^T, K_MM; bits 16-23: ... of S;
 //            bit 24: the transform block has written Zs, 1/l, the header scalars, the flow parameter transforms, padded m
-//   SY_COLS0 / SY_COLS1 (one per chain block b = 0, 1): 16 * attempt + n, every operand panel c < n of parity c & 1 = b
-//            is complete in global memory (panel c = tiles (c, k < c) of L and L^T and -Dinv_c); `attempt` = level of
-//            the on-device jitter ladder the factorisation is at
+//   SY_COLS0 / SY_COLS1: a 16-bit field per chain block b (b = 0, 1 in SY_COLS0, b = 2, 3 in SY_COLS1): 16 * attempt + n,
+//            every operand panel c < n with c mod TGP_CHAIN_BLOCKS = b is complete in global memory (panel c = tiles
+//            (c, k < c) of L and L^T and -Dinv_c); `attempt` = level of the on-device jitter ladder the factorisation is at
 //   SY_DONE  number of blocks of the launch that have finished; the last one zeroes the four words
 // No fences: an agent-scope release / acquire costs a write-back / invalidate of the whole L2 of the XCD on gfx950 (135
 // polling row blocks kept every L2 of the chip empty: the first fused build took 130 us).  Instead every datum that
@@ -30,6 +30,12 @@ namespace tgp {
 
 enum { SY_COLS0 = 0, SY_TILES = 1, SY_COLS1 = 2, SY_DONE = 3 };
 #define TGP_SY_XF_BIT (1 << 24)
+#ifndef TGP_CHAIN_BLOCKS
+#define TGP_CHAIN_BLOCKS 4 /* redundant factorisation workgroups of the fused launch (1, 2 or 4): they share what leaves the workgroup */
+#endif
+// chain block b's progress field: 16 bits (16 * ladder attempt + panels complete) in SY_COLS0 (b = 0, 1) / SY_COLS1 (b = 2, 3)
+__device__ __forceinline__ int cols_word(int b) { return (b >> 1) ? SY_COLS1 : SY_COLS0; }
+__device__ __forceinline__ int cols_field(int x, int b) { return (x >> (16 * (b & 1))) & 0xffff; }
 #define TGP_STATUS_SYNC_TIMEOUT (-77)
 #define TGP_SYNC_MAX_POLLS (1 << 22)
 
@@ -261,7 +267,9 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
                                                  double* sm, int cb) {
   constexpr int MP = MT * 16, LD = MP + 1, NW = 4, NT = 256;
   int32_t* sy = status + 4;
-  int32_t* my_cols = sy + (cb == 0 ? SY_COLS0 : SY_COLS1);
+  constexpr int R = TGP_CHAIN_BLOCKS;
+  int32_t* my_cols = sy + cols_word(cb);
+  __shared__ int s_pub, s_drain;   // this block's published field; task waves that have drained their earlier stores (cumulative)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -270,8 +278,8 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
   double* zs = sm + (size_t)MP * LD;
   __shared__ int s_info, s_nan, s_next, s_sync;
   __shared__ double s_ils[16];
-  if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; s_sync = 0; }
-  int tbase = 0;
+  if (tid == 0) { s_info = 0; s_nan = 0; s_next = 0; s_sync = 0; s_pub = 0; s_drain = 0; }
+  int tbase = 0, dbase = 0;
   if (tid < 16) s_ils[tid] = tid < D ? 1.0 / softplus_d(md.raw_ls[tid]) : 0.0;
   const double s2 = softplus_d(md.raw_os[0]);
   const bool zl = p.zs_lds != 0;
@@ -438,6 +446,15 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
   // in global memory when the publishing thread passes it
   auto window_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
   auto lds_only_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // this block's field <- v (monotone; one publisher at a time: thread 0 at a window's barrier, or the inverse's wave
+  // inside the window, which joins that barrier afterwards)
+  auto publish = [&](int v) {
+    const int old = s_pub;
+    if (v > old) {
+      s_pub = v;
+      sync_add(my_cols, (v - old) << (16 * (cb & 1)));
+    }
+  };
 
 #ifdef TGP_STAMPS
 #define CHAIN_STAMP(i) do { if (tid == 0 && cb == 0) ws[p.hdr + H_PSTAMP + (i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
@@ -486,7 +503,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
 #pragma unroll
             for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
           }
-        } else if ((j & 1) == cb) {
+        } else if ((j % R) == cb) {
           double xv[16];
           bad = potrf_panel16<false, true>(dg, a, xv, li);
           store_nD(j, xv);
@@ -509,13 +526,14 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
         // issued up to window j-1, i.e. the operand panels 0 .. j-2 (panel c = tile row c, window c, and -Dinv_c,
         // window c+1) -- published one window late, which costs nothing: only the last panel is ever waited for.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(&s_drain, 1);
         WAVE_STAMP(j, 1);
         // (what leaves the workgroup is shared with the other chain block by the parity of the panel it belongs to:
         //  panel c = tile row c and -Dinv_c, plus the diagonal tile c, is block c & 1's)
-        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;     // -Dinv_{j-1}, and the diagonal tile (j-1, j-1)
+        const int nt = (j >= 1 && ((j - 1) % R) == cb) ? 1 : 0;     // -Dinv_{j-1}, and the diagonal tile (j-1, j-1)
         const int nfe = j == 0 ? ((MT > 1 ? 1 : 0) + (MT > 2 ? 1 : 0)) : (j + 2 < MT ? 1 : 0);
         const int ncu = (j >= 1 && j + 1 < MT) ? 1 : 0;
-        const int nwo = (j & 1) == cb ? j : 0;                       // tiles (j, 0 .. j-1)
+        const int nwo = (j % R) == cb ? j : 0;                       // tiles (j, 0 .. j-1)
         const int ntask = nt + nfe + ncu + nwo + nt;
 #ifdef TGP_STAMPS
         int lg = 0;
@@ -529,7 +547,20 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
           ++lg;
 #endif
           if (t >= ntask) break;
-          if (t < nt) { inv_diag(j - 1); continue; }
+          if (t < nt) {
+            inv_diag(j - 1);
+            // panel j-1 is this block's and complete with these stores (its tile row went out a window ago): publish it
+            // now rather than at the next window's barrier -- for the last panels that is what the row blocks wait for.
+            // (own stores drained; the other task waves' drains of this window's entry counted in LDS)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+              const int need = dbase + (NW - npw);
+              for (int it = 0; it < (1 << 20) && __hip_atomic_load(&s_drain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++it)
+                __builtin_amdgcn_s_sleep(1);
+              if (s_info == 0 && s_sync == 0) publish(16 * attempt + j);
+            }
+            continue;
+          }
           t -= nt;
           if (t < nfe) {
             if (!tiles_seen) {
@@ -548,15 +579,16 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
         }
       }
       {
-        const int nt = (j >= 1 && ((j - 1) & 1) == cb) ? 1 : 0;
+        const int nt = (j >= 1 && ((j - 1) % R) == cb) ? 1 : 0;
         const int nfe = j == 0 ? ((MT > 1 ? 1 : 0) + (MT > 2 ? 1 : 0)) : (j + 2 < MT ? 1 : 0);
-        tbase += 2 * nt + nfe + ((j >= 1 && j + 1 < MT) ? 1 : 0) + ((j & 1) == cb ? j : 0) + (NW - npw);   // tasks + one over-grab per task wave
+        tbase += 2 * nt + nfe + ((j >= 1 && j + 1 < MT) ? 1 : 0) + ((j % R) == cb ? j : 0) + (NW - npw);   // tasks + one over-grab per task wave
+        dbase += NW - npw;
       }
       WAVE_STAMP(j, 3);
       lds_only_barrier();
       CHAIN_STAMP(2 + 2 * j);
       failed = s_info != 0 || s_sync != 0;
-      if (j >= 2 && !failed && tid == 0) sync_st(my_cols, 16 * attempt + j - 1);
+      if (j >= 2 && !failed && tid == 0) publish(16 * attempt + j - 1);
       if (failed) break;
       if (did_diag) {
 #pragma unroll
@@ -580,7 +612,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
   // tail: the last diagonal tile of L (k_bwd12 reads it; its inverse left with the pass), every store of the launch
   // drained, then the terminal count.  A final attempt that failed still publishes -- the row blocks must not wait for
   // ever; status[] tells the host.
-  if (wave == 1 && ((MT - 1) & 1) == cb) write_L(MT - 1, MT - 1);
+  if (wave == 1 && ((MT - 1) % R) == cb) write_L(MT - 1, MT - 1);
   window_barrier();
   if (tid == 0) {
     if (cb == 0) {   // (the other chain block arrives at the same three words)
@@ -588,7 +620,7 @@ __device__ __forceinline__ void fused_chain_role(const Plan& p, const tgp_model&
       status[1] = s_nan;
       status[2] = (s_info == 0 && s_sync == 0) ? attempt : 0;
     }
-    sync_st(my_cols, 16 * attempt + MT);
+    publish(16 * attempt + MT);
   }
   CHAIN_STAMP(2 + 2 * MT);
 #undef CHAIN_STAMP

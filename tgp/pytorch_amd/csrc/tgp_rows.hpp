@@ -160,8 +160,9 @@ __device__ __forceinline__ d4 subst_chain(const double* a0, int nsum, int dstep0
 
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
 // scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
-// FUSED (training modes only): the launch carries the prepare roles in front of the row blocks -- blocks 0, 1 the
-// factorisation chain (twice), block 2 the parameter transforms, blocks 3 .. 2 + MT^2 the tile blocks (tgp_prep.hpp) -- and the
+// FUSED (training modes only): the launch carries the prepare roles in front of the row blocks -- blocks 0 .. CR-1 the
+// factorisation chain (CR = TGP_CHAIN_BLOCKS redundant copies), block CR the parameter transforms, then MT^2 tile blocks
+// (tgp_prep.hpp) -- and the
 // row blocks wait on the hand-off words for what they need instead of on a kernel boundary: staging and the K tile run
 // under the factorisation, the forward substitution follows it panel by panel, and what is left after the last panel is
 // B = Lq^T A onwards.
@@ -197,25 +198,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const double* __restrict__ ws = a.ws;
   const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
   int32_t* sy = FUSED ? a.status + 4 : nullptr;
-  const int nb_total = 3 + MT * MT + p.nblocks + MT;   // blocks of a fused launch
+  constexpr int CR = TGP_CHAIN_BLOCKS;
+  const int nb_total = CR + 1 + MT * MT + p.nblocks + MT;   // blocks of a fused launch
   int bid = blockIdx.x;                                // index among the row blocks, then the passengers
   if constexpr (FUSED) {
-    if (blockIdx.x < 2) {
+    if ((int)blockIdx.x < CR) {
       fused_chain_role<MT>(p, a.md, a.ws, a.status, sm, (int)blockIdx.x);
       sync_leave(sy, nb_total);
       return;
     }
-    if (blockIdx.x == 2) {
+    if ((int)blockIdx.x == CR) {
       prep_xform_role<256, true>(p, a.md, a.prog, a.ws, sy);   // (publishes SY_XF itself, ahead of the KL)
       sync_leave(sy, nb_total);
       return;
     }
-    if ((int)blockIdx.x < 3 + MT * MT) {
-      prep_tile_role<256, true>(p, a.md, a.ws, (int)blockIdx.x - 3, sy);   // (counts itself in SY_TILES)
+    if ((int)blockIdx.x < CR + 1 + MT * MT) {
+      prep_tile_role<256, true>(p, a.md, a.ws, (int)blockIdx.x - (CR + 1), sy);   // (counts itself in SY_TILES)
       sync_leave(sy, nb_total);
       return;
     }
-    bid = (int)blockIdx.x - (3 + MT * MT);
+    bid = (int)blockIdx.x - (CR + 1 + MT * MT);
   }
   // block-uniform wait on a hand-off word: thread 0 polls, the workgroup learns the value through LDS
   int* sync_box = reinterpret_cast<int*>(red + 30);
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     if constexpr (FUSED) {   // everything of the prepare roles: padded m, S, all of L^T and the tile inverses
       block_wait(SY_TILES, [&](int x) { return (x & TGP_SY_XF_BIT) != 0 && ((x >> 16) & 0xff) >= MT * MT; });   // padded m; the S tiles
-      block_wait(SY_COLS0, [&](int x) { return (x & 15) >= MT; });
-      block_wait(SY_COLS1, [&](int x) { return (x & 15) >= MT; });
+#pragma unroll
+      for (int b = 0; b < CR; ++b) block_wait(cols_word(b), [&](int x) { return (cols_field(x, b) & 15) >= MT; });
     }
     const double* __restrict__ LTg = ws + p.LT;
     const double* __restrict__ nDg = ws + p.nD;
@@ -474,7 +476,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if (redo) continue;
-        const int v = block_wait((i & 1) ? SY_COLS1 : SY_COLS0, [&](int x) { return (x >> 4) > att || ((x >> 4) == att && (x & 15) > i); });
+        const int ob = i % CR;   // the chain block that owns panel i
+        const int vw = block_wait(cols_word(ob), [&](int x) { const int f = cols_field(x, ob); return (f >> 4) > att || ((f >> 4) == att && (f & 15) > i); });
+        const int v = vw == (int)0x80000000 ? vw : cols_field(vw, ob);
         if (v != (int)0x80000000 && (v >> 4) != att) { att = v >> 4; redo = true; continue; }
         double* buf = pan + (i & 1) * (MP * 16);
         issue(0, i, stg[i & 1]);

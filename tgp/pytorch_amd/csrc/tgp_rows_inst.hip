@@ -17,8 +17,8 @@ static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
   auto kern = k_rows<TGP_MT, DP, MODE, FUSED>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
-  // fused: two chain blocks, transform block, MT^2 tile blocks, then the row blocks and the MT passenger blocks
-  const int grid = (FUSED ? 3 + a.p.MT * a.p.MT : 0) + a.p.nblocks + (TRAIN ? a.p.MT : 0);
+  // fused: TGP_CHAIN_BLOCKS chain blocks, transform block, MT^2 tile blocks, then the row blocks and the MT passenger blocks
+  const int grid = (FUSED ? TGP_CHAIN_BLOCKS + 1 + a.p.MT * a.p.MT : 0) + a.p.nblocks + (TRAIN ? a.p.MT : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
