@@ -740,28 +740,33 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
   double* Lb = Lm + o * ld + o;
   double* Jb = Jm + o * ld + o;
   if (tid == 0) { s_info = 0; s_next = 0; }
-  for (int e = tid; e < 128 * 128; e += POTRF_THREADS) {
-    const int rr = e >> 7, cc = e & 127;
-    if ((cc >> 4) <= (rr >> 4)) A[rr * LD + cc] = Lb[(size_t)rr * ld + cc];
+  // Round 4: the schedule of k_prep_a's factorisation blocks as it stands after round 4 (tgp_mm.hip), on 8 x 8 tiles of
+  // 16 with the block read from global memory: right-looking, ONE register pass of one wave per 16-column panel
+  // (potrf_panel16: diagonal tile + every row below it; no inverse, triangular solve or panel product on the chain), one
+  // 4-MFMA update per tile of the next block column between two panels, and everything else taken from a task counter in
+  // LDS by the other waves in the pass's shadow, each task straight-line code with its LDS reads ahead of its MFMAs:
+  //   window j:  Dinv_{j-1} (trtri16 by a task wave, no longer in the pass: 3.4 k instead of 4.1 k cycles per panel)
+  //              block column j+1 -= block columns 0 .. j-1, ONE task per half column with a compile-time depth
+  //              row j-2 of J = L^-1, a tile per task, stored to LDS (for the rows below) and to global memory at once
+  //              tile row j-1 of L -> global memory, 16-byte stores
+  // (round 3 took the catch-up tile by tile with run-time k loops, carried the inverse in the pass, wrote J out in tasks
+  //  of its own and loaded the whole block before the first pass: 39.5 us per diagonal block.)
+  // the block's lower tiles -> LDS: 32 rows of 4 per thread, every load in flight before the first LDS store (one memory
+  // round trip for the whole block: it was written by other CUs' trailing update a launch ago and comes from beyond
+  // this XCD's L2 -- fetched column by column in the windows, each fetch was a 2-3 us task and bound its window)
+  {
+    const int col = tid & 127, rsub = tid >> 7, ct = col >> 4;
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      v[k] = 0.0;
+      if (ct <= (k >> 2)) v[k] = Lb[(size_t)(4 * k + rsub) * ld + col];
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+      if (ct <= (k >> 2)) A[(4 * k + rsub) * LD + col] = v[k];
   }
   __syncthreads();
-  // The round-3 schedule of k_prep_a's factorisation block (tgp_mm.hip), on 8 x 8 tiles of 16 with the block read from
-  // global memory instead of generated: right-looking, ONE register pass of one wave per 16-column panel
-  // (potrf_panel16: diagonal tile + every row below it, no inverse / triangular solve / panel product on the chain),
-  // one 4-MFMA update per tile of the next block column between two panels, everything else (catching the later
-  // columns up, the diagonal tiles' inverses, the tiles of J = L^-1, the write-out) taken from a task counter in LDS
-  // by the other waves in the panel pass's shadow.
-  auto ll_sum = [&](int i0, int j0, int kbeg, int kend) {
-    d4 acc = {0, 0, 0, 0};
-    return tile_mm_f([&](int k) { return A[(i0 + r) * LD + k + q]; }, [&](int k) { return A[(j0 + r) * LD + k + q]; }, kbeg,
-                     kend, acc);
-  };
-  // tile (i, c) -= block columns [0, ncol) (all final)
-  auto catchup_tile = [&](int i, int c, int ncol) {
-    const d4 upd = ll_sum(16 * i, 16 * c, 0, 16 * ncol);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] -= upd[rr];
-  };
   // tile (i, c) -= L[i rows, k0 .. k0+15] L[c rows, k0 .. k0+15]^T : one block column's contribution, 4 MFMAs
   auto sub16 = [&](int i, int c, int k0) {
     double a4[4], b4[4];
@@ -776,142 +781,218 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) A[(16 * i + q + 4 * rr) * LD + 16 * c + r] = cur[rr] - acc[rr];
   };
-  auto inv_tile = [&](int j, int c) {
-    const int j0 = 16 * j, c0 = 16 * c;
+  // tiles (i, c), i = i0, i0 + istep, ... (two per trip), -= L[i rows, 0 .. 16 NC) L[c rows, 0 .. 16 NC)^T (all final)
+  auto catch_up_nc = [&](int c, auto ncc, int i0, int istep) {
+    constexpr int NC = decltype(ncc)::value;
+    double bf[4 * NC];
+#pragma unroll
+    for (int s4 = 0; s4 < 4 * NC; ++s4) bf[s4] = A[(16 * c + r) * LD + 4 * s4 + q];
+    for (int i = i0; i < MT; i += istep) {
+      const bool two = i + 1 < MT;
+      const int i1 = two ? i + 1 : i;
+      if constexpr (NC > 3) {   // deep columns: a tile per trip (two tiles' operands + the column's = 72 doubles: spills)
+        for (int ii = i; ii <= i1; ++ii) {
+          double af[4 * NC], cur[4];
+#pragma unroll
+          for (int s4 = 0; s4 < 4 * NC; ++s4) af[s4] = A[(16 * ii + r) * LD + 4 * s4 + q];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cur[u] = A[(16 * ii + q + 4 * u) * LD + 16 * c + r];
+          d4 acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4 * NC; ++s4) acc = TGP_MFMA(af[s4], bf[s4], acc);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) A[(16 * ii + q + 4 * u) * LD + 16 * c + r] = cur[u] - acc[u];
+        }
+        continue;
+      }
+      double af0[4 * NC], af1[4 * NC], cur0[4], cur1[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NC; ++s4) { af0[s4] = A[(16 * i + r) * LD + 4 * s4 + q]; af1[s4] = A[(16 * i1 + r) * LD + 4 * s4 + q]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { cur0[u] = A[(16 * i + q + 4 * u) * LD + 16 * c + r]; cur1[u] = A[(16 * i1 + q + 4 * u) * LD + 16 * c + r]; }
+      d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NC; ++s4) acc0 = TGP_MFMA(af0[s4], bf[s4], acc0);
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NC; ++s4) acc1 = TGP_MFMA(af1[s4], bf[s4], acc1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[(16 * i + q + 4 * u) * LD + 16 * c + r] = cur0[u] - acc0[u];
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) A[(16 * i1 + q + 4 * u) * LD + 16 * c + r] = cur1[u] - acc1[u];
+      }
+    }
+  };
+  auto catch_up_col = [&](int c, int ncol, int h, int halves) {
+    static_for<MT - 2>([&](auto k) {
+      if (ncol == decltype(k)::value + 1)
+        catch_up_nc(c, std::integral_constant<int, decltype(k)::value + 1>{}, c + 2 * h, 2 * halves);
+    });
+  };
+  // Dinv_jt (one wave, trtri16 on its own copy of L_jj) -> LDS and the diagonal tile of J
+  auto inv_diag = [&](int jt) {
+    double dgv[16], xv[16];
+    const double rd = Dt[jt * 256 + r];   // 1 / L_jj[r][r], left here by the pass
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dgv[c] = A[(16 * jt + r) * LD + 16 * jt + c];
+    trtri16<true, true>(dgv, xv, r, rd);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // xv[c] = Dinv[c][r]; the four 16-lane rows hold the same values: row q stores rows 4u + q
+      const double xv4 = q == 0 ? xv[4 * u] : (q == 1 ? xv[4 * u + 1] : (q == 2 ? xv[4 * u + 2] : xv[4 * u + 3]));
+      Dt[jt * 256 + (4 * u + q) * 16 + r] = xv4;
+      Jb[(size_t)(16 * jt + 4 * u + q) * ld + 16 * jt + r] = xv4;
+    }
+  };
+  // tile (jr, c) of J = -Dinv_jr (L[jr, c] Dinv_c + sum_{c < k < jr} L[jr, k] J[k, c]), NK = jr - c - 1 inner tiles:
+  // transposed into the strict-upper tile (c, jr) of A for the rows below, and to global memory from the registers
+  auto inv_tile_nk = [&](int jr, int c, auto nkc) {
+    constexpr int NK = decltype(nkc)::value;
+    const int j0 = 16 * jr, c0 = 16 * c;
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + c0 + k + q]; }, [&](int k) { return Dt[c * 256 + (k + q) * 16 + r]; },
-                    0, 16, acc);
-    acc = tile_mm_f([&](int k) { return A[(j0 + r) * LD + k + q]; }, [&](int k) { return A[(c0 + r) * LD + k + q]; },
-                    c0 + 16, j0, acc);
+    {
+      double af[4], bf[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { af[s4] = A[(j0 + r) * LD + c0 + 4 * s4 + q]; bf[s4] = Dt[c * 256 + (4 * s4 + q) * 16 + r]; }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc = TGP_MFMA(af[s4], bf[s4], acc);
+    }
+    static_for<(NK + 2) / 3>([&](auto gc) {   // the inner tiles three at a time: 24 operand doubles live, reads ahead of the MFMAs
+      constexpr int g0 = 3 * decltype(gc)::value, gn = (NK - g0 < 3 ? NK - g0 : 3);
+      double af[4 * gn], bf[4 * gn];
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * gn; ++s4) {
+        const int k = c0 + 16 + 16 * g0 + 4 * s4;
+        af[s4] = A[(j0 + r) * LD + k + q];
+        bf[s4] = A[(c0 + r) * LD + k + q];
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * gn; ++s4) acc = TGP_MFMA(af[s4], bf[s4], acc);
+    });
     double dj[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) dj[s4] = Dt[j * 256 + r * 16 + 4 * s4 + q];
+    for (int s4 = 0; s4 < 4; ++s4) dj[s4] = Dt[jr * 256 + r * 16 + 4 * s4 + q];
     d4 out = {0, 0, 0, 0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) out = TGP_MFMA(dj[s4], acc[s4], out);
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
+    for (int rr = 0; rr < 4; ++rr) {
+      A[(c0 + r) * LD + j0 + q + 4 * rr] = -out[rr];
+      Jb[(size_t)(j0 + q + 4 * rr) * ld + c0 + r] = -out[rr];
+    }
   };
-  // write-out of tile (ti, tj) of the block: L (ti >= tj; the strict upper part of a diagonal tile as zeros), J likewise,
-  // zeros for the tiles above the diagonal (the block arrives with K's symmetric copy there)
+  auto inv_tile = [&](int jr, int c) {
+    static_for<MT - 1>([&](auto k) {
+      if (jr - c - 1 == decltype(k)::value) inv_tile_nk(jr, c, k);
+    });
+  };
+  // lower tile (ti, tj) of L -> global memory: two 16-byte stores per lane (lane = row 8 h + (lane >> 3), column pair
+  // 2 (lane & 7)); the strict upper part of a diagonal tile as zeros
+  const int rw = lane >> 3, cp = 2 * (lane & 7);
   auto write_L = [&](int ti, int tj) {
+    double a[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      Lb[(size_t)rr * ld + cc] = (ti != tj || cc <= rr) ? A[rr * LD + cc] : 0.0;
+    for (int h = 0; h < 2; ++h) {
+      a[h][0] = A[(16 * ti + 8 * h + rw) * LD + 16 * tj + cp];
+      a[h][1] = A[(16 * ti + 8 * h + rw) * LD + 16 * tj + cp + 1];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * h + rw;
+      if (ti == tj) {
+        if (cp > row) a[h][0] = 0.0;
+        if (cp + 1 > row) a[h][1] = 0.0;
+      }
+      *reinterpret_cast<double2*>(Lb + (size_t)(16 * ti + row) * ld + 16 * tj + cp) = make_double2(a[h][0], a[h][1]);
     }
   };
-  auto write_J = [&](int ti, int tj) {
+  // zeros for the tiles of L right of the diagonal in tile row ti (the block arrives with K's symmetric copy resp. the
+  // trailing update's values there; J's are zero from the fill kernel and nothing else writes them)
+  auto zero_row = [&](int ti) {
+    for (int tj = ti + 1; tj < MT; ++tj) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      Jb[(size_t)rr * ld + cc] = (ti == tj) ? Dt[ti * 256 + (rr & 15) * 16 + (cc & 15)] : A[cc * LD + rr];
-    }
-  };
-  auto zero_tile = [&](int ti, int tj) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rr = 16 * ti + q + 4 * u, cc = 16 * tj + r;
-      Lb[(size_t)rr * ld + cc] = 0.0;
-      Jb[(size_t)rr * ld + cc] = 0.0;
+      for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<double2*>(Lb + (size_t)(16 * ti + 8 * h + rw) * ld + 16 * tj + cp) = make_double2(0.0, 0.0);
     }
   };
 #define POTRF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  auto cu_tasks = [&](int j) { return (j >= 1 && j + 1 < MT) ? (MT - (j + 1) > 2 ? 2 : 1) : 0; };
   int tbase = 0;
-  for (int j = 0; j < MT; ++j) {
+  // windows MT and MT+1 have no panel left: every wave takes tasks -- the last diagonal tile's inverse, the last tile row
+  // of L and row MT-2 of J, then row MT-1 of J (one loop: every task body has ONE call site and is inlined; called from a
+  // tail of its own as well, the J tile came out as a function with its closure in scratch memory)
+  for (int j = 0; j < MT + 2; ++j) {
     const int j0 = 16 * j;
     const int npan = (MT - 1 - j) * 16;
-    const int npw = npan > 64 ? 2 : (npan > 0 ? 1 : 0);
+    const int npw = j >= MT ? 0 : (npan > 64 ? 2 : 1);   // panel waves (window MT-1: wave 0 with the diagonal tile alone)
     double ltile[4] = {0.0, 0.0, 0.0, 0.0};
     bool did_diag = false;
-    if (wave < npw || (npw == 0 && wave == 0)) {
-      // wave 0 also carries the diagonal tile's inverse in the pass's shadow and owns L_jj, Dinv_j (see k_prep_a)
+    // window j's tasks, heaviest first
+    const int nt = (j >= 1 && j <= MT) ? 1 : 0;                      // Dinv_{j-1}
+    const int ncu = cu_tasks(j);                                     // column j+1 -= columns 0 .. j-1
+    const int nir = j >= 2 ? j - 2 : 0;                              // row j-2 of J left of its diagonal tile
+    const int nwl = j <= MT ? j : 0;                                 // tile row j-1 of L
+    const int nz = j == 0 ? MT - 1 : 0;
+    const int ntask = nt + ncu + nir + nwl + nz;
+    if (wave < npw) {
       __builtin_amdgcn_s_setprio(3);
-      const int li = lane & 15, l0 = wave * 64 + lane;
+      const int l0 = wave * 64 + lane;
       const bool has = l0 < npan;
       const int prow = j0 + (npan > 0 ? 16 : 0) + (has ? l0 : 0);
-      double dg[16], a[16], x[16];
+      double dg[16], a[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + li) * LD + j0 + c];
+      for (int c = 0; c < 16; ++c) dg[c] = A[(j0 + r) * LD + j0 + c];
       if (npan > 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = A[prow * LD + j0 + c];
       }
       int bad = 0;
-      if (wave == 0) {
-        if (npan > 0) bad = potrf_panel16<true, true>(dg, a, x, li);
-        else bad = potrf_panel16<false, true>(dg, a, x, li);
-      } else {
-        (void)potrf_panel16<true>(dg, a);
-      }
+      // (wave 0 keeps the pass's own reciprocals of the diagonal for inv_diag: the inverse then comes out exactly as when
+      //  it rode in the pass -- a borderline pivot of a later block, K_MM with a duplicated inducing point, depends on it)
+      double rd = 0.0;
+      if (wave != 0) bad = potrf_panel16<true>(dg, a);
+      else if (npan > 0) bad = potrf_panel16<true, false, true>(dg, a, nullptr, r, &rd);
+      else bad = potrf_panel16<false, false, true>(dg, a, nullptr, r, &rd);
+      if (wave == 0 && lane < 16) Dt[j * 256 + lane] = rd;
       if (has && npan > 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) A[prow * LD + j0 + c] = a[c];
       }
       if (wave == 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u)
           ltile[u] = q == 0 ? dg[4 * u] : (q == 1 ? dg[4 * u + 1] : (q == 2 ? dg[4 * u + 2] : dg[4 * u + 3]));
-          const double xv4 = q == 0 ? x[4 * u] : (q == 1 ? x[4 * u + 1] : (q == 2 ? x[4 * u + 2] : x[4 * u + 3]));
-          Dt[j * 256 + (4 * u + q) * 16 + li] = xv4;
-        }
         did_diag = true;
         if (lane == 0 && bad != 0 && s_info == 0) s_info = j0 + bad;
       }
       __builtin_amdgcn_s_setprio(0);
     } else {
-      // tasks of this window, heaviest first: tiles (i, j+2) -= block columns
-      // 0 .. j-1 | tiles (j-1, c) of J | write-out of J row j-2 | tiles (i, j+1) -= block column j-1 | write-out of L row
-      // j-1 | [j = 0] zeros above the diagonal
-      const int n1 = MT - 1 - j, n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
-      const int nc = j >= 1 ? n2 : 0, ni = j >= 1 ? j - 1 : 0, nwj = j >= 2 ? j - 1 : 0, ns = j >= 1 ? n1 : 0, nwl = j;
-      const int nz = j == 0 ? MT * (MT - 1) / 2 : 0;
-      const int ntask = nc + ni + nwj + ns + nwl + nz;
       for (;;) {
         int t = 0;
         if (lane == 0) t = atomicAdd(&s_next, 1);
         t = __builtin_amdgcn_readfirstlane(t) - tbase;
         if (t >= ntask) break;
-        if (t < nc) { catchup_tile(j + 2 + t, j + 2, j); continue; }
-        t -= nc;
-        if (t < ni) { inv_tile(j - 1, t); continue; }
-        t -= ni;
-        if (t < nwj) { write_J(j - 2, t); continue; }
-        t -= nwj;
-        if (t < ns) { sub16(j + 1 + t, j + 1, 16 * (j - 1)); continue; }
-        t -= ns;
+        if (t < nt) { inv_diag(j - 1); continue; }
+        t -= nt;
+        if (t < ncu) { catch_up_col(j + 1, j, t, ncu); continue; }
+        t -= ncu;
+        if (t < nir) { inv_tile(j - 2, t); continue; }
+        t -= nir;
         if (t < nwl) { write_L(j - 1, t); continue; }
         t -= nwl;
-        int ti = 0;  // t -> (ti < tj): row-major over the strict upper triangle of tiles
-        while (t >= MT - 1 - ti) { t -= MT - 1 - ti; ++ti; }
-        zero_tile(ti, ti + 1 + t);
+        zero_row(t);
       }
     }
-    {
-      const int n2 = MT - 2 - j > 0 ? MT - 2 - j : 0;
-      tbase += (j >= 1 ? n2 : 0) + (j >= 1 ? j - 1 : 0) + (j >= 2 ? j - 1 : 0) + (j >= 1 ? MT - 1 - j : 0) + j +
-               (j == 0 ? MT * (MT - 1) / 2 : 0) + (NW - (npw > 0 ? npw : 1));
-    }
+    tbase += ntask + (NW - npw);   // the tasks + one over-grab per task wave
     POTRF_BARRIER();
+    if (j >= MT) continue;
     if (did_diag) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) A[(j0 + (lane & 15)) * LD + j0 + 4 * u + q] = ltile[u];
+      for (int u = 0; u < 4; ++u) A[(j0 + r) * LD + j0 + 4 * u + q] = ltile[u];
     }
     if (j + 1 < MT) {
       for (int i = j + 1 + wave; i < MT; i += NW) sub16(i, j + 1, j0);
-      POTRF_BARRIER();
-    }
-  }
-  // tail: J row MT-1 (Dinv_{MT-1} came with the last window), the last write-outs
-  {
-    const int ni = MT - 1, nwl = MT, nwj = MT - 1;
-    for (int t = wave; t < ni + nwl + nwj; t += NW) {
-      if (t < ni) inv_tile(MT - 1, t);
-      else if (t < ni + nwl) write_L(MT - 1, t - ni);
-      else write_J(MT - 2, t - (ni + nwl));
     }
     POTRF_BARRIER();
-    for (int t = wave; t < MT; t += NW) write_J(MT - 1, t);
   }
 #undef POTRF_BARRIER
   __syncthreads();

@@ -398,14 +398,20 @@ __device__ __forceinline__ int potrf_trtri16(double (&a)[16], double (&x)[16], i
 // interleaved in one wave -- 800 instructions, issue-bound -- then a panel product and a diagonal update per block column).
 // Any wave can run this on its own 64 panel rows: it factorises its own copy of the diagonal tile redundantly and needs
 // nothing from the other waves.  Returns the first bad pivot (1-based; 0 = ok), the same in every lane.
-template <bool PANEL, bool TRTRI = false>
-__device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16], double* x = nullptr, int lane = 0) {
+// RDIAG: *rd = the pass's own 1 / L_jj[lane][lane] (lane = l & 15), for a later trtri16<.., true> that then reproduces the
+// inverse the TRTRI form computes in the pass, bit for bit.
+template <bool PANEL, bool TRTRI = false, bool RDIAG = false>
+__device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16], double* x = nullptr, int lane = 0,
+                                             double* rd = nullptr) {
   int bad = 0;
   static_for<16>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     const double d = bcast_row_k<k>(dg[k]);
     if (!(d > 0.0) && bad == 0) bad = k + 1;  // the same in every lane; also catches NaN
     const double rinv = rsqrt_nr(d);
+    if constexpr (RDIAG) {
+      if (lane == k) *rd = rinv;
+    }
     if constexpr (TRTRI) {
       // row k of X = L_jj^-1 rides in the pass's shadow as in potrf_trtri16: x[r] = X[r][lane & 15]
       double s0 = 0.0, s1 = 0.0;
@@ -439,18 +445,21 @@ __device__ __forceinline__ int potrf_panel16(double (&dg)[16], double (&a)[16], 
 // column behind).
 // GATED = false (a caller with registers to spare: the fused launch's chain blocks, 512 per wave): the 120 broadcasts
 // and the 16 reciprocals are left free to be issued ahead of the substitution chain.
-template <bool GATED = true>
-__device__ __forceinline__ void trtri16(const double (&dg)[16], double (&x)[16], int lane) {
+// RD = true: rd = 1 / L[lane][lane] as the factorisation pass formed it (potrf_panel16<.., .., true>) instead of a
+// reciprocal of its own.
+template <bool GATED = true, bool RD = false>
+__device__ __forceinline__ void trtri16(const double (&dg)[16], double (&x)[16], int lane, double rd = 0.0) {
   double gate = 0.0;  // x[k-1]: the broadcasts of step k are tied behind it (below)
   double rinvs[16];
-  if constexpr (!GATED) {
+  if constexpr (!GATED && !RD) {
     static_for<16>([&](auto kc) { constexpr int k = decltype(kc)::value; rinvs[k] = bcast_row_k<k>(dg[k]); });
     rcp_fast_n<16>(rinvs);
   }
   static_for<16>([&](auto kc) {
     constexpr int k = decltype(kc)::value;
     double rinv;
-    if constexpr (GATED) rinv = rcp_fast(bcast_row_k<k>(dg[k]));
+    if constexpr (RD) rinv = bcast_row_k<k>(rd);
+    else if constexpr (GATED) rinv = rcp_fast(bcast_row_k<k>(dg[k]));
     else rinv = rinvs[k];
     double s0 = 0.0, s1 = 0.0;
     static_for<16>([&](auto mc) {
