@@ -723,6 +723,15 @@ __global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double
 //   in : lower triangle of Lm[o.., o..] (o = 128 kb), already updated by the previous block columns
 //   out: L_kk (zero above the diagonal) in place, J_kk = L_kk^-1 into J's diagonal block
 // ---------------------------------------------------------------------------------------------------
+#ifdef TGP_STAMPS
+// diagnostic build (tools/probes/stamp_big.py): s_memrealtime (100 MHz) of every wave at [0] kernel entry, [1] block in
+// LDS, [2 + 3 j ..] window j: entry / own work done / after the window's barrier; [40] end.  Block kb = 1 of the last
+// factorisation.
+__device__ unsigned long long g_potrf_stamps[8 * 48];
+#define BSTAMP(i) do { if (kb == 1 && lane == 0) g_potrf_stamps[wave * 48 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
 #define POTRF_THREADS 512
 #define POTRF_LD 129
 #define POTRF_LDS_BYTES ((128 * POTRF_LD + 8 * 256) * sizeof(double))
@@ -740,6 +749,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
   double* Lb = Lm + o * ld + o;
   double* Jb = Jm + o * ld + o;
   if (tid == 0) { s_info = 0; s_next = 0; }
+  BSTAMP(0);
   // Round 4: the schedule of k_prep_a's factorisation blocks as it stands after round 4 (tgp_mm.hip), on 8 x 8 tiles of
   // 16 with the block read from global memory: right-looking, ONE register pass of one wave per 16-column panel
   // (potrf_panel16: diagonal tile + every row below it; no inverse, triangular solve or panel product on the chain), one
@@ -767,6 +777,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
       if (ct <= (k >> 2)) A[(4 * k + rsub) * LD + col] = v[k];
   }
   __syncthreads();
+  BSTAMP(1);
   // tile (i, c) -= L[i rows, k0 .. k0+15] L[c rows, k0 .. k0+15]^T : one block column's contribution, 4 MFMAs
   auto sub16 = [&](int i, int c, int k0) {
     double a4[4], b4[4];
@@ -933,6 +944,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
     const int nwl = j <= MT ? j : 0;                                 // tile row j-1 of L
     const int nz = j == 0 ? MT - 1 : 0;
     const int ntask = nt + ncu + nir + nwl + nz;
+    BSTAMP(2 + 3 * j);
     if (wave < npw) {
       __builtin_amdgcn_s_setprio(3);
       const int l0 = wave * 64 + lane;
@@ -983,7 +995,9 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
       }
     }
     tbase += ntask + (NW - npw);   // the tasks + one over-grab per task wave
+    BSTAMP(3 + 3 * j);
     POTRF_BARRIER();
+    BSTAMP(4 + 3 * j);
     if (j >= MT) continue;
     if (did_diag) {
 #pragma unroll
@@ -996,8 +1010,16 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
   }
 #undef POTRF_BARRIER
   __syncthreads();
+  BSTAMP(40);
   if (tid == 0 && s_info != 0 && status[0] == 0) status[0] = (int)o + s_info;
 }
+#ifdef TGP_STAMPS
+}  // namespace tgp
+extern "C" int tgp_debug_potrf_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp::g_potrf_stamps), sizeof(unsigned long long) * 8 * 48);
+}
+namespace tgp {
+#endif
 
 __global__ __launch_bounds__(256) void k_big_sub_eye(double* __restrict__ S, int MP) {
   const int i = blockIdx.x * 256 + threadIdx.x;
