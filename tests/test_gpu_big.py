@@ -372,6 +372,17 @@ def _shard_step(N, lo=0, hi=None, mb_global=None):
     return out.cpu(), {k: t.cpu() for k, t in g.items()}
 
 
+def test_big_minibatch_step_is_bit_reproducible():
+    """10 000 rows at M = 1000 (the reference's Airline minibatch): split-K slabs, the two-stream chunk pipeline and the
+    riding inverse all reduce in a fixed order -- four steps, the same bits."""
+    o1, g1 = _shard_step(10000)
+    for _ in range(3):
+        o2, g2 = _shard_step(10000)
+        assert torch.equal(o1, o2)
+        for k in g1:
+            assert torch.equal(g1[k], g2[k]), k
+
+
 def test_big_full_shard_properties(tmp_path):
     """The real per-GPU shard of BASELINE configs[4]: N = 250 000 rows, D = 8, M = 1000, StepTanhL 5x6, S = 32 (16 natural
     row chunks).  Too large for the CPU oracle, so the size-independent properties: bit reproducibility; shard additivity
