@@ -48,6 +48,23 @@ int main(int argc, char** argv) {
       const double f = 2.0 * NC * (double)MP * MP * (c.tri ? 0.5625 : 1.0);
       printf("%s %.3f ms  %.1f TF/s (useful)\n", c.name, t, f / t / 1e9);
     }
+    {
+      // the NT product at the TN line's GRID SHAPE (8 tile rows x NC / 128 tile columns): small x-major A [MP][k], big x-major
+      // B [NC][k] (op(B) = B^T), C [MP][NC] -- separates "x-major operands" from "128 x 8 grid" as the cause of the NT / TN gap
+      for (int xcd : {0, 1}) {
+        GemmArgs g = gemm_args(A, MP, B, MP, C, NC, MP, NC, MP, 1.0, 0.0, 0);
+        g.xcd = xcd;
+        float t = run<false, true>(g, 10);
+        printf("NT full, m = MP, n = NC (swapped shape) xcd%d  %.3f ms  %.1f TF/s (useful)\n", xcd, t, 2.0 * NC * (double)MP * MP / t / 1e9);
+      }
+      // and the TN product at the NT lines' shape: C [NC][MP] = A^T ([k][NC] k-major, big) x B ([k][MP] k-major, small)
+      for (int xcd : {0, 1}) {
+        GemmArgs g = gemm_args(A, NC, B, MP, C, MP, NC, MP, MP, 1.0, 0.0, 0);
+        g.xcd = xcd;
+        float t = run<true, false>(g, 10);
+        printf("TN full, m = NC, n = MP (the NT lines' shape) xcd%d  %.3f ms  %.1f TF/s (useful)\n", xcd, t, 2.0 * NC * (double)MP * MP / t / 1e9);
+      }
+    }
     for (int ks : {8, 12, 14, 16, 28}) for (int xcd : {2}) for (int sc = 0; sc < 2; ++sc) {
       GemmArgs g = gemm_args(A, MP, A, MP, C, MP, MP, MP, NC, 1.0, 1.0, TRI_C_LOWER);
       g.ksplit = ks; g.cz = (size_t)MP * MP; g.xcd = xcd; g.k_scale = sc ? V : nullptr;
