@@ -23,12 +23,15 @@
  *   - return value: 0 = launched; <0 = -(index of the offending argument) or TGP_E_*;
  *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[8], ZERO before its first use):
  *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive;
- *                   TGP_STATUS_SYNC_TIMEOUT = -77: a block of the fused step launch gave up waiting, results invalid),
+ *                   TGP_STATUS_SYNC_TIMEOUT: a workgroup of the prepare launch gave up waiting for a hand-off word --
+ *                   the hand-off words were not zero, or its producers never became resident; results invalid),
  *       status[1] = 1 if K_MM contained a NaN (the reference raises NanError, dsp/utils.py:241-254),
  *       status[2] = level of the on-device jitter ladder that succeeded (tgp_model.jitter_ladder), status[3] reserved,
- *       status[4..7] = hand-off words of the fused step launch (M <= 128: the factorisation's blocks run in the same
- *                   launch as the row blocks and publish the panels of L through these words); the library leaves
- *                   them zero at the end of every call, the caller must not touch them while a call is in flight,
+ *       status[4..7] = hand-off words between workgroups of ONE launch (M <= 128: the tile blocks of the prepare
+ *                   launch count themselves in status[4] once their tile of K_MM is in global memory, status[5] counts
+ *                   the blocks that have left; [6], [7] reserved); the library leaves them zero at the end of every
+ *                   call, the caller must not touch them while a call is in flight.  A caller built against the
+ *                   int32[4] status of ABI versions <= 100 must grow the buffer: check tgp_version() >= 101,
  *     so the host can replay with the reference's jitter ladder (dsp/utils.py:256-269) without a
  *     device sync per step.  No exception crosses the ABI.
  */
@@ -52,6 +55,8 @@ extern "C" {
 #define TGP_E_LDS (-102)         /* flow program too large for one CU's LDS                    */
 #define TGP_E_LAUNCH (-103)      /* hipLaunchKernel failed; see tgp_last_error()               */
 #define TGP_E_COMM (-104)        /* RCCL not loaded / an RCCL call failed; see tgp_last_error() */
+/* value of status[0] (not a return value): a hand-off wait inside a launch expired (see Conventions) */
+#define TGP_STATUS_SYNC_TIMEOUT (-77)
 
 /* ---- flow program (models/flow.py CompositeFlow.forward :155-158) -------------------------------
  * A flow is a sequence of `nblk` blocks; block b is four int32: {kind, K, poff, flags}.

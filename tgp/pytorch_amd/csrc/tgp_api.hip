@@ -25,13 +25,6 @@ void set_error_text(const char* fmt, ...) {
   va_end(ap);
 }
 
-// TGP_FUSED_LAUNCH=1 runs prepare and rows as ONE launch (k_rows<..., FUSED>; read once).  Off by default: measured at
-// the Power size it ties with the two launches (DESIGN.md section 4c says where its time goes).
-static bool fused_launch_enabled() {
-  static const bool on = [] { const char* e = getenv("TGP_FUSED_LAUNCH"); return e && e[0] == '1'; }();
-  return on;
-}
-
 static int check_model(const tgp_model* m, bool need_lik) {
   if (m == nullptr) return -1;
   if (m->N < 1 || m->D < 1 || m->D > 16) return -1;
@@ -161,12 +154,10 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   p.nslots = fp.nslots;
-  // PREPARE and ROWS asked for together: ONE launch, the factorisation's blocks in front of the row blocks
-  const bool fuse = (phases & TGP_PHASE_PREPARE) && (phases & TGP_PHASE_ROWS) && fused_launch_enabled();
-  if ((phases & TGP_PHASE_PREPARE) && !fuse)
+  if (phases & TGP_PHASE_PREPARE)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (phases & TGP_PHASE_ROWS)
-    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st, fuse ? status : nullptr)) return rc;
+    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
   if (phases & TGP_PHASE_BACKWARD)
     if (int rc = launch_backward_mm(p, md, *grads, out, ws, st, adam != nullptr ? &ad : nullptr)) return rc;
   return 0;

@@ -51,8 +51,7 @@ int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* st
 
 // tgp_rows.hip
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
-                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st,
-                int32_t* fused_status = nullptr);
+                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
 // tgp_big.hip (general-M path, 128 < M <= TGP_BIG_MAX_M)
 size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel);

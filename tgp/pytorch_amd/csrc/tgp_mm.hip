@@ -17,10 +17,10 @@
 namespace tgp {
 
 // ---------------------------------------------------------------------------------------------------
-// k_prep_a  (grid = 2 + MT*MT workgroups of 512 threads)
-//   block 0      : K_MM into LDS, blocked left-looking Cholesky + blocked triangular inverse (8 waves, MFMA)
-//   block 1      : parameter transforms, Zs, padded m, flow parameter transforms, KL, header scalars
-//   block 2 + t  : 16x16 tile t of {Lq, Lq^T, K_MM -> HBM} and the S = Lq Lq^T tile (one MFMA chain)
+// k_prep_a  (grid = MT*MT + 3 workgroups of 512 threads; producers of the in-launch hand-off carry the lowest indices)
+//   block t < MT^2   : 16x16 tile t of {Lq, Lq^T, K_MM -> HBM} and the S = Lq Lq^T tile (one MFMA chain)
+//   block MT^2       : parameter transforms, Zs, padded m, flow parameter transforms, KL, header scalars
+//   blocks MT^2 + 1, MT^2 + 2 : the two chain blocks -- K_MM into LDS, blocked right-looking Cholesky (8 waves, MFMA)
 // ---------------------------------------------------------------------------------------------------
 #define PREP_THREADS 512
 #ifndef TGP_W4_WINDOWS
@@ -38,17 +38,21 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   const int r = lane & 15, q = lane >> 4;
   const int M = p.M, D = p.D, MP = p.MP, DP = p.DP, MT = p.MT;
 
-  int32_t* sy = status + 4;   // hand-off words (tgp_prep.hpp): here only SY_TILES and SY_DONE are used
+  int32_t* sy = status + 4;   // hand-off words (tgp_prep.hpp): SY_TILES and SY_DONE
   const int nb_total = 3 + MT * MT;
-  if (blockIdx.x >= 3) {
+  // The tile blocks -- the PRODUCERS the chain blocks wait for -- come first in the grid: workgroups are dispatched in
+  // index order, so they are resident (or done) before a chain block can occupy a CU and spin (with the chain
+  // blocks in front, a saturated GPU could seat the waiters and leave their producers queued until the bounded wait
+  // expired).
+  if ((int)blockIdx.x < MT * MT) {
     // ---------------- tile blocks: Lq, Lq^T, K_MM copies + S = Lq Lq^T (sparse_MF_SP.py:316,344-346); they count
     //                  themselves in SY_TILES once K_MM is out: the chain blocks take K_MM's columns >= 2 from there
-    prep_tile_role<PREP_THREADS, true>(p, md, ws, (int)blockIdx.x - 3, sy);
+    prep_tile_role<PREP_THREADS, true>(p, md, ws, (int)blockIdx.x, sy);
     sync_leave(sy, nb_total);
     return;
   }
 
-  if (blockIdx.x == 2) {
+  if ((int)blockIdx.x == MT * MT) {
     // ---------------- transforms, padded copies, flow parameter transforms, KL, header ---------------------------
     prep_xform_role<PREP_THREADS, false>(p, md, fp, ws);
     sync_leave(sy, nb_total);
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
   // needs only tiles of its own column) and of L.  The task windows, not the chain, bound this launch (the four SIMDs of
   // one CU saturated by instruction issue): a second CU takes 40 % of a window's work at the price of nothing but a CU
   // that was idle.
-  const int cb = (int)blockIdx.x;   // 0 or 1: this block's column parity
+  const int cb = (int)blockIdx.x - (MT * MT + 1);   // 0 or 1: this block's column parity
   // Round-3 schedule: RIGHT-looking, one 16-column PANEL factorisation per block column (potrf_panel16: the diagonal
   // tile and every row below it leave one register pass of one wave -- no inverse of the diagonal tile, no triangular
   // solve, no panel product on the critical chain), everything GEMM-shaped on the other waves:

@@ -8,16 +8,10 @@ namespace tgp {
 DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7) DECL(8)
 #undef DECL
 
-// fused_status != nullptr: the prepare roles ride in front of the row blocks (one launch for PREPARE + ROWS, training
-// only); the pointer is the caller's status array, whose words 4..7 are the hand-off words of the launch
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
-                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st,
-                int32_t* fused_status) {
+                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
   RowArgs a;
   a.p = p;
-  a.md = md;
-  a.status = fused_status;
-  const bool fused = train && fused_status != nullptr;
   a.X = X; a.Y = Y; a.rowp = rowp; a.g_rowp = g_rowp; a.mu = mu; a.v = v; a.ws = ws;
   a.prog = fp; a.xs = md.xs; a.wn = md.wn; a.scale = md.scale;
   const size_t lim = 160 * 1024 - 1024;
@@ -32,15 +26,6 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
     }
   }
   if (lds > lim) return TGP_E_LDS;
-  if (fused) {
-    // the chain block keeps K_MM / L (MP x (MP+1)) and, budget allowing, the scaled inducing points in LDS
-    const size_t mat = (size_t)p.MP * (p.MP + 1) * sizeof(double), zsb = (size_t)p.MP * p.DP * sizeof(double);
-    a.p.zs_lds = mat + zsb <= lim ? 1 : 0;
-    const size_t need = mat + (a.p.zs_lds ? zsb : 0);
-    if (need > lim) return TGP_E_LDS;
-    if (need > lds) lds = need;
-    mode += 2;
-  }
   switch (p.MT) {
     case 1: return launch_rows_mt1(a, mode, lds, st);
     case 2: return launch_rows_mt2(a, mode, lds, st);

@@ -45,9 +45,6 @@ struct RowArgs {
   const double* xs;
   const double* wn;
   double scale;
-  // fused launch only (k_rows<..., FUSED = true>): the model for the prepare roles and the status / hand-off words
-  tgp_model md;
-  int32_t* status;
 };
 
 // LDS carve-up (offsets in doubles)
@@ -160,15 +157,8 @@ __device__ __forceinline__ d4 subst_chain(const double* a0, int nsum, int dstep0
 
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
 // scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
-// FUSED (training modes only): the launch carries the prepare roles in front of the row blocks -- blocks 0 .. CR-1 the
-// factorisation chain (CR = TGP_CHAIN_BLOCKS redundant copies), block CR the parameter transforms, then MT^2 tile blocks
-// (tgp_prep.hpp) -- and the
-// row blocks wait on the hand-off words for what they need instead of on a kernel boundary: staging and the K tile run
-// under the factorisation, the forward substitution follows it panel by panel, and what is left after the last panel is
-// B = Lq^T A onwards.
-template <int MT, int DP, int MODE, bool FUSED = false>
+template <int MT, int DP, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_rows(RowArgs a) {
-  static_assert(!FUSED || MODE != 0, "the fused launch is a training launch");
   constexpr bool TRAIN = MODE != 0;
   constexpr int MP = MT * 16;
   constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
@@ -197,41 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nl = lane & 15, q = lane >> 4;
   const double* __restrict__ ws = a.ws;
   const int N = p.N, D = p.D, M = p.M, P = p.P, RP = p.RP;
-  int32_t* sy = FUSED ? a.status + 4 : nullptr;
-  constexpr int CR = TGP_CHAIN_BLOCKS;
-  const int nb_total = CR + 1 + MT * MT + p.nblocks + MT;   // blocks of a fused launch
-  int bid = blockIdx.x;                                // index among the row blocks, then the passengers
-  if constexpr (FUSED) {
-    if ((int)blockIdx.x < CR) {
-      fused_chain_role<MT>(p, a.md, a.ws, a.status, sm, (int)blockIdx.x);
-      sync_leave(sy, nb_total);
-      return;
-    }
-    if ((int)blockIdx.x == CR) {
-      prep_xform_role<256, true>(p, a.md, a.prog, a.ws, sy);   // (publishes SY_XF itself, ahead of the KL)
-      sync_leave(sy, nb_total);
-      return;
-    }
-    if ((int)blockIdx.x < CR + 1 + MT * MT) {
-      prep_tile_role<256, true>(p, a.md, a.ws, (int)blockIdx.x - (CR + 1), sy);   // (counts itself in SY_TILES)
-      sync_leave(sy, nb_total);
-      return;
-    }
-    bid = (int)blockIdx.x - (CR + 1 + MT * MT);
-  }
-  // block-uniform wait on a hand-off word: thread 0 polls, the workgroup learns the value through LDS
-  int* sync_box = reinterpret_cast<int*>(red + 30);
-  auto block_wait = [&](int word, auto pred) {
-    if (tid == 0) {
-      const int v = sync_wait(sy + word, pred);
-      if (v == (int)0x80000000) a.status[0] = TGP_STATUS_SYNC_TIMEOUT;
-      sync_box[0] = v;
-    }
-    lds_barrier();
-    const int v = sync_box[0];
-    lds_barrier();
-    return v;
-  };
+  const int bid = blockIdx.x;                          // index among the row blocks, then the passengers
 
   if (TRAIN && bid >= p.nblocks) {
     // ---- passenger blocks (one per 16-column block c of J): what only the backward M x M chain needs -- J = L^-1
@@ -244,11 +200,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     //      now read as J^T -- and wave 3 the 16 entries of w.
     const int c = __builtin_amdgcn_readfirstlane(bid - p.nblocks);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    if constexpr (FUSED) {   // everything of the prepare roles: padded m, S, all of L^T and the tile inverses
-      block_wait(SY_TILES, [&](int x) { return (x & TGP_SY_XF_BIT) != 0 && ((x >> 16) & 0xff) >= MT * MT; });   // padded m; the S tiles
-#pragma unroll
-      for (int b = 0; b < CR; ++b) block_wait(cols_word(b), [&](int x) { return (cols_field(x, b) & 15) >= MT; });
-    }
     const double* __restrict__ LTg = ws + p.LT;
     const double* __restrict__ nDg = ws + p.nD;
     const double* __restrict__ Sg = ws + p.S_;
@@ -259,22 +210,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < MT; ++i) {
       if (i < c) continue;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) df[i][s4] = ld_maybe<FUSED>(nDg + i * 256 + nl * 16 + 4 * s4 + q);   // A operand of -Dinv_i
+      for (int s4 = 0; s4 < 4; ++s4) df[i][s4] = *(nDg + i * 256 + nl * 16 + 4 * s4 + q);   // A operand of -Dinv_i
 #pragma unroll
       for (int kb = 0; kb < i; ++kb) {
         if (kb < c) continue;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) lf[i * (i - 1) / 2 + kb][s4] = ld_maybe<FUSED>(LTg + (size_t)(16 * kb + 4 * s4 + q) * MP + 16 * i + nl);
+        for (int s4 = 0; s4 < 4; ++s4) lf[i * (i - 1) / 2 + kb][s4] = *(LTg + (size_t)(16 * kb + 4 * s4 + q) * MP + 16 * i + nl);
       }
     }
     d4 dc;  // Dinv_c in accumulator layout
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) dc[rr] = -ld_maybe<FUSED>(nDg + c * 256 + (4 * rr + q) * 16 + nl);
+    for (int rr = 0; rr < 4; ++rr) dc[rr] = -*(nDg + c * 256 + (4 * rr + q) * 16 + nl);
     double mf[MT][4];  // this lane's entries of m (for w)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) mf[i][rr] = ld_maybe<FUSED>(ws + p.mpad + 16 * i + 4 * rr + q);
+      for (int rr = 0; rr < 4; ++rr) mf[i][rr] = *(ws + p.mpad + 16 * i + 4 * rr + q);
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       Jt[i] = d4{0, 0, 0, 0};
@@ -308,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const int kk = 16 * kb + 4 * s4 + q;
-          bf[kb][s4] = ld_maybe<FUSED>(Sg + (size_t)kk * MP + 16 * jj + nl) - (kk == 16 * jj + nl ? 1.0 : 0.0);
+          bf[kb][s4] = *(Sg + (size_t)kk * MP + 16 * jj + nl) - (kk == 16 * jj + nl ? 1.0 : 0.0);
         }
       }
       d4 h = {0, 0, 0, 0};
@@ -332,7 +283,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sw = quad_sum(sw);
       if (q == 0) a.ws[p.w + 16 * c + nl] = sw;
     }
-    if constexpr (FUSED) sync_leave(sy, nb_total);
     return;
   }
 
@@ -349,10 +299,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int d = 0; d < DP; ++d) xraw[d] = d < D ? a.X[(size_t)nc * D + d] : 0.0;
   const double y = TRAIN ? a.Y[nc] : 0.0;
-  if constexpr (FUSED) block_wait(SY_TILES, [](int x) { return (x & TGP_SY_XF_BIT) != 0; });   // header, Zs, 1/l, m, flow parameter transforms
-  // (fused: written by another block of this launch a moment ago -- not through the scalar cache)
-  const double s2 = ld_maybe<FUSED>(ws + p.hdr + H_S2), eta = ld_maybe<FUSED>(ws + p.hdr + H_ETA),
-               einv = ld_maybe<FUSED>(ws + p.hdr + H_EINV);
+  const double s2 = *(ws + p.hdr + H_S2), eta = *(ws + p.hdr + H_ETA),
+               einv = *(ws + p.hdr + H_EINV);
 
   // ---- operand panels: the A operands of the four triangular products (16 columns x up to MP rows of L^T, Lq, Lq^T, L)
   //      are staged by the whole workgroup through two LDS buffers (aliased on the transposition tile, which is
@@ -381,9 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int u = 0; u < MT; ++u)
       if (u < nb) {
-        if (kind == 0 && u == i) st[u] = ld_maybe<FUSED>(nD + i * 256 + (tid & 15) * 16 + (tid >> 4));        // (-Dinv_i)^T
-        else if (kind == 3 && u == 0) st[u] = ld_maybe<FUSED>(nD + i * 256 + (tid >> 4) * 16 + (tid & 15));   // -Dinv_i
-        else st[u] = ld_maybe<FUSED>(Mt + (size_t)16 * u * MP);
+        if (kind == 0 && u == i) st[u] = *(nD + i * 256 + (tid & 15) * 16 + (tid >> 4));        // (-Dinv_i)^T
+        else if (kind == 3 && u == 0) st[u] = *(nD + i * 256 + (tid >> 4) * 16 + (tid & 15));   // -Dinv_i
+        else st[u] = *(Mt + (size_t)16 * u * MP);
       }
   };
   auto commit = [&](int par, bool lower, int i, const double (&st)[MT]) {
@@ -396,10 +344,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // panel sequences of the two phases (pp = 0 .. 2 MT - 1; buffer and register set = pp & 1)
   auto issue1 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(0, pp, st); else issue(1, pp - MT, st); };
   auto issue2 = [&](int pp, double (&st)[MT]) { if (pp < MT) issue(2, pp, st); else issue(3, 2 * MT - 1 - pp, st); };
-  if constexpr (!FUSED) {
-    issue1(0, stg[0]);
-    if (MT * 2 > 1) issue1(1, stg[1]);
-  }
+  issue1(0, stg[0]);
+  if (MT * 2 > 1) issue1(1, stg[1]);
   // ---- stage the small shared operands ----
   // (the first slice of every array is requested before anything is stored: the loops below, one after the other,
   //  paid one L2 round trip each)
@@ -407,11 +353,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NZ = (MP * DP + 255) / 256;
     double zv[NZ];
 #pragma unroll
-    for (int u = 0; u < NZ; ++u) zv[u] = tid + 256 * u < MP * DP ? ld_maybe<FUSED>(ws + p.Zs + tid + 256 * u) : 0.0;
-    const double mv0 = tid < MP ? ld_maybe<FUSED>(ws + p.mpad + tid) : 0.0;
-    const double il0 = tid < 16 ? ld_maybe<FUSED>(ws + p.ils + tid) : 0.0;
+    for (int u = 0; u < NZ; ++u) zv[u] = tid + 256 * u < MP * DP ? *(ws + p.Zs + tid + 256 * u) : 0.0;
+    const double mv0 = tid < MP ? *(ws + p.mpad + tid) : 0.0;
+    const double il0 = tid < 16 ? *(ws + p.ils + tid) : 0.0;
     const bool fl = p.lik == TGP_LIK_FLOW;
-    const double tp0 = (fl && tid < P) ? ld_maybe<FUSED>(ws + p.tp + tid) : 0.0, tg0 = (fl && tid < P) ? ld_maybe<FUSED>(ws + p.tg + tid) : 0.0;
+    const double tp0 = (fl && tid < P) ? *(ws + p.tp + tid) : 0.0, tg0 = (fl && tid < P) ? *(ws + p.tg + tid) : 0.0;
     const double xs0 = (fl && tid < p.S) ? a.xs[tid] : 0.0, wn0 = (fl && tid < p.S) ? a.wn[tid] : 0.0;
 #pragma unroll
     for (int u = 0; u < NZ; ++u)
@@ -421,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (fl) {
       if (tid < P) { tpL[tid] = tp0; tgL[tid] = tg0; tiL[tid] = rcp_fast(tp0); }
       if (tid < p.S) { xsL[tid] = xs0; wnL[tid] = wn0; }
-      for (int i = tid + 256; i < P; i += 256) { tpL[i] = ld_maybe<FUSED>(ws + p.tp + i); tgL[i] = ld_maybe<FUSED>(ws + p.tg + i); tiL[i] = rcp_fast(tpL[i]); }
+      for (int i = tid + 256; i < P; i += 256) { tpL[i] = *(ws + p.tp + i); tgL[i] = *(ws + p.tg + i); tiL[i] = rcp_fast(tpL[i]); }
       for (int i = tid + 256; i < p.S; i += 256) { xsL[i] = a.xs[i]; wnL[i] = a.wn[i]; }
       for (int i = tid; i < 4 * p.nblk; i += 256) progL[i] = a.prog.blk[i];
     }
@@ -464,45 +410,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   d4 Aa[MT], Ba[MT];
   // ---- A = L^-1 K by forward substitution: A_i = Dinv_i (K_i - sum_{kb < i} L[i,kb] A_kb)  (A operand = rows of L^T,
   //      then of -Dinv_i^T; the running right-hand side starts as -K_i, which already sits in accumulator layout) ----
-  if constexpr (FUSED) {
-    // The factorisation runs beside this block: tile i waits for panel i (SY_COLS), stages it and closes -- nothing to
-    // prefetch, the chain is the slower side.  SY_COLS also carries the jitter-ladder attempt: panels of an attempt that
-    // died (a pivot failed further down) are worthless, and since the terminal count MT is only ever published for the
-    // attempt that ended the factorisation, a block that sees the attempt change simply starts the substitution again.
-    int att = 0;
-    bool redo;
-    do {
-      redo = false;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if (redo) continue;
-        const int ob = i % CR;   // the chain block that owns panel i
-        const int vw = block_wait(cols_word(ob), [&](int x) { const int f = cols_field(x, ob); return (f >> 4) > att || ((f >> 4) == att && (f & 15) > i); });
-        const int v = vw == (int)0x80000000 ? vw : cols_field(vw, ob);
-        if (v != (int)0x80000000 && (v >> 4) != att) { att = v >> 4; redo = true; continue; }
-        double* buf = pan + (i & 1) * (MP * 16);
-        issue(0, i, stg[i & 1]);
-        commit(i & 1, true, i, stg[i & 1]);
-        lds_barrier();
-        const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
-        Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
-                                    [&](int st) { return Aa[st / 4][st % 4]; });
-      }
-    } while (redo);
-    block_wait(SY_TILES, [&](int x) { return (x & 0xffff) >= MT * MT; });   // Lq, Lq^T (long since there)
-    issue1(MT, stg[MT & 1]);
-    if (MT > 1) issue1(MT + 1, stg[(MT + 1) & 1]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const double* buf = pan + (i & 1) * (MP * 16);
-      commit(i & 1, true, i, stg[i & 1]);
-      lds_barrier();
-      if (i + 2 < 2 * MT) issue1(i + 2, stg[i & 1]);
-      const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
-      Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
-                                  [&](int st) { return Aa[st / 4][st % 4]; });
-    }
+  for (int i = 0; i < MT; ++i) {
+    const double* buf = pan + (i & 1) * (MP * 16);
+    commit(i & 1, true, i, stg[i & 1]);
+    lds_barrier();
+    if (i + 2 < 2 * MT) issue1(i + 2, stg[i & 1]);
+    const d4 c0 = {-Kr[4 * i], -Kr[4 * i + 1], -Kr[4 * i + 2], -Kr[4 * i + 3]};
+    Aa[i] = subst_chain<4 * MT>(buf + q * 16 + nl, 4 * i, 4 * i, c0, [&](int st) { return st; },
+                                [&](int st) { return Aa[st / 4][st % 4]; });
   }
   ROW_STAMP(a.ws, p, 3);
   // ---- B = Lq^T A : B_i = sum_{kb >= i} Lq[kb,i]^T A_kb ; accumulator register r of A_kb is k-step r ----
@@ -745,7 +661,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       a.g_rowp[(size_t)n * RP + jr] = ap[0] + ap[16] + ap[32] + ap[48];
     }
   }
-  if constexpr (FUSED) sync_leave(sy, nb_total);
 }
 
 }  // namespace tgp

@@ -11,14 +11,14 @@
 
 namespace tgp {
 
-template <int DP, int MODE, bool FUSED>
+template <int DP, int MODE>
 static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
   constexpr bool TRAIN = MODE != 0;
-  auto kern = k_rows<TGP_MT, DP, MODE, FUSED>;
+  auto kern = k_rows<TGP_MT, DP, MODE>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
-  // fused: TGP_CHAIN_BLOCKS chain blocks, transform block, MT^2 tile blocks, then the row blocks and the MT passenger blocks
-  const int grid = (FUSED ? TGP_CHAIN_BLOCKS + 1 + a.p.MT * a.p.MT : 0) + a.p.nblocks + (TRAIN ? a.p.MT : 0);
+  // the row blocks, then (training) the MT passenger blocks
+  const int grid = a.p.nblocks + (TRAIN ? a.p.MT : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(e, __FILE__, __LINE__);
@@ -28,11 +28,9 @@ static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
 template <int DP>
 static int launch_dp(const RowArgs& a, int mode, size_t lds, hipStream_t st) {
   switch (mode) {
-    case 0: return launch_one<DP, 0, false>(a, lds, st);
-    case 1: return launch_one<DP, 1, false>(a, lds, st);
-    case 2: return launch_one<DP, 2, false>(a, lds, st);
-    case 3: return launch_one<DP, 1, true>(a, lds, st);    // fused prepare + rows
-    default: return launch_one<DP, 2, true>(a, lds, st);
+    case 0: return launch_one<DP, 0>(a, lds, st);
+    case 1: return launch_one<DP, 1>(a, lds, st);
+    default: return launch_one<DP, 2>(a, lds, st);
   }
 }
 

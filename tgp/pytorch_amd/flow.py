@@ -256,10 +256,11 @@ def mlp_spec(nets, seed=0):
 _mask_step = {}     # device -> int32[2] counter behind the dropout masks drawn outside the training step
 
 
-def nets_rowp(nets, X2d, samples=1, spec=None):
+def nets_rowp(nets, X2d, samples=1, spec=None, with_grad=False):
     """Per-row flow parameters (rows, len(nets)) of an input-dependent flow through tgp_mlp_forward_f64 -- the ONE MLP
-    implementation of this package (training, evaluation, moments, sampling); no autograd here (the training step
-    differentiates through ops.MlpFunction).  Dropout follows the nets' Dropout LAYERS (train mode in training and in the
+    implementation of this package (training, evaluation, moments, sampling).  `with_grad`: the result carries autograd
+    to the networks' weights (ops.MlpFunction: forward AND backward on the HIP MLP kernels) -- same checks, same mask
+    counter, same salt as the plain call (ONE copy of the mask-stream logic).  Dropout follows the nets' Dropout LAYERS (train mode in training and in the
     fully Bayesian evaluation, where enable_eval_dropout() re-enables only them, models/utils_models.py:358-364).
     `samples` > 1 evaluates the rows `samples` times in the same launch -- what the reference does by expanding X to
     (S_MC, N, Dx) (models/sparse_MF_SP.py:753-758): output row s * N + n, every (sample, row) with its own mask.
@@ -277,9 +278,13 @@ def nets_rowp(nets, X2d, samples=1, spec=None):
         step = _mask_step[str(X2d.device)] = torch.zeros(2, dtype=torch.int32, device=X2d.device)
     if drop_on:
         step[0] += 1                                    # a fresh mask per call
-    W = torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()])
     Xs = X2d.contiguous() if samples == 1 else X2d.repeat(samples, 1)
     # (this call site's own mask stream: its counter starts at 0 like the training step's and the evaluation's)
+    if with_grad and torch.is_grad_enabled():
+        W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
+        # (the backward recomputes the masks of THIS call: it gets its own copy of the counter's value)
+        return ops.MlpFunction.apply(Xs, W, spec.salted(ops.MASK_SALT_NETS), bool(drop_on), step.clone())
+    W = torch.cat([p.detach().reshape(-1) for net in nets for p in net.parameters()])
     return ops.mlp_forward(spec.salted(ops.MASK_SALT_NETS), Xs, W, bool(drop_on), step)
 
 

@@ -60,19 +60,7 @@ class GaussianNonLinearMean(_GaussianBase):
         if nets:
             from .flow import nets_rowp
             X2d = X[0] if X.dim() == 3 else X
-            if with_grad and torch.is_grad_enabled():
-                from .flow import mlp_spec, _mask_step
-                mspec = mlp_spec(nets, seed=cg.config_seed)
-                if mspec is None:
-                    raise ops.L.TgpError("the flow's parameter networks are outside the HIP MLP kernel's coverage")
-                step = _mask_step.setdefault(str(X2d.device), torch.zeros(2, dtype=torch.int32, device=X2d.device))
-                drop_on = any(mod.training for mod in nets[0].modules() if "Dropout" in type(mod).__name__)
-                if drop_on:
-                    step[0] += 1
-                W = torch.cat([p.reshape(-1) for net in nets for p in net.parameters()])
-                rowp = ops.MlpFunction.apply(X2d.detach().contiguous(), W, mspec.salted(ops.MASK_SALT_NETS), bool(drop_on), step.clone())
-            else:
-                rowp = nets_rowp(nets, X2d)      # the HIP MLP kernel (dropout follows the layers)
+            rowp = nets_rowp(nets, X2d, with_grad=with_grad)      # the HIP MLP kernel (dropout follows the layers)
         return spec, theta, rowp
 
     def expected_log_prob(self, Y, gauss_mean, gauss_cov, flow, X, **kwargs):

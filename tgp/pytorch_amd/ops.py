@@ -19,6 +19,15 @@ class NanError(RuntimeError):
     """Same role as gpytorch.utils.errors.NanError raised by dsp/utils.py:241-254."""
 
 
+STATUS_SYNC_TIMEOUT = -77   # include/tgp_hip.h TGP_STATUS_SYNC_TIMEOUT: status[0] of a launch whose hand-off wait expired
+
+
+class HandoffTimeoutError(RuntimeError):
+    """A workgroup of the prepare launch gave up waiting for a hand-off word (status[0] == TGP_STATUS_SYNC_TIMEOUT):
+    the status buffer's hand-off words (status[4..7]) were not zero at the call, or the launch's producer workgroups
+    never became resident.  The results of that call are invalid; this is NOT a Cholesky failure."""
+
+
 class NotPSDError(RuntimeError):
     pass
 
@@ -117,7 +126,8 @@ def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, fl
 
 def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=None, rowp=None, S=None, jitter=0.0,
               kl_scale=1.0, mb_global=None, want_moments=False, kernel="scale_rbf"):
-    """One fused ELBO evaluation + all gradients on the GPU.  Returns (out[4], grads dict, status[4], (mu, v)).
+    """One fused ELBO evaluation + all gradients on the GPU.  Returns (out[4], grads dict, status[8], (mu, v)); status[0..2] are the
+    Cholesky words of include/tgp_hip.h, status[4..7] the in-launch hand-off words (zero before and after every call).
 
     out = [ELL_shard - KL, ELL_shard, KL, 0]; grads are d(ELL_shard - kl_scale*KL)/d(param).
     `mb_global` = global minibatch size when X is a row shard (defaults to X.shape[0])."""
@@ -166,6 +176,9 @@ def raise_for_status(status, retrying=False):
     """Translate the device status words into the reference's exceptions; returns True if a retry with more
     jitter is needed."""
     info, nan = int(status[0]), int(status[1])
+    if info == STATUS_SYNC_TIMEOUT:
+        raise HandoffTimeoutError("a hand-off wait inside the prepare launch expired (status[0] = %d): status[4..7] "
+                                  "must be zero before the first call and untouched while a call is in flight" % info)
     if nan:
         raise NanError("cholesky: K_MM contains NaN")
     return info != 0

@@ -83,8 +83,6 @@ python tools/probes/time_bayes_eval.py 2>&1 | grep -v amdgpu > $O/bayes_eval_tim
 python tools/probes/stamp_prep.py 2>&1 | grep -v amdgpu > $O/prep_phase_stamps.txt; head -12 $O/prep_phase_stamps.txt
 python tools/probes/stamp_run.py 2>&1 | grep -v amdgpu > $O/rows_phase_stamps.txt; tail -4 $O/rows_phase_stamps.txt
 python tools/probes/stamp_big.py 2>&1 | grep -v amdgpu > $O/big_potrf_window_timeline.txt; head -14 $O/big_potrf_window_timeline.txt
-TGP_FUSED_LAUNCH=1 python tools/probes/stamp_fused.py 2>&1 | grep -v amdgpu | cut -c1-400 > $O/fused_launch_timeline.txt; head -12 $O/fused_launch_timeline.txt
-TGP_FUSED_LAUNCH=1 python bench.py --steps 2000 --warmup 100 --no-cpu-baseline > $O/bench_tgp_power_tanh3x2_fused_launch.json 2> /dev/null; cut -c1-200 $O/bench_tgp_power_tanh3x2_fused_launch.json
 bash tools/probes/valu_pass.sh > $O/valu_pass.log 2>&1; cp gpurun_out/r04v/pmc_valu_standalone.csv $O/pmc_valu_standalone.csv; cp gpurun_out/r04v/pmc_valu_rows.csv $O/pmc_valu_rows.csv
 ./tools/probes/potrf_panel_rate > $O/potrf_panel_rate.txt 2>&1; cat $O/potrf_panel_rate.txt
 # ---- kernel timelines of one replayed step (tools/probes/timeline.py): start offset, duration, queue, gap per kernel ----
