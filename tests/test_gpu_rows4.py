@@ -1,0 +1,81 @@
+"""The 4-rows-per-wave row kernel (csrc/tgp_rows4.hpp, v_mfma_f64_4x4x4_4b) against the 16-rows-per-wave one on the same
+inputs: which of the two a training launch gets is decided inside the library (flow likelihood and at most 4 306 rows ->
+k_rows4), `TGP_ROWS4=0` (read once per process) forces k_rows -- so the reference side runs in a child process.  Also:
+bit reproducibility of k_rows4, and the oracle at a size where k_rows4 runs with 8-wave workgroups."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(455, 13, 5, "tanh3x2", 32), (1077, 4, 100, "tanh3x2", 32), (2153, 4, 100, "sal2", 32), (4306, 4, 100, "tanh3x2", 32),
+         (1000, 8, 37, "idsal3", 20), (3001, 16, 128, "sal2", 32), (37, 3, 16, "tanh3x2", 7)]
+
+
+def _run(case):
+    from tgp.pytorch_amd import ops, synthetic
+    N, D, M, flow, S = case
+    dev = torch.device("cuda:0")
+    prob = synthetic.synthetic_problem(N, D, M, seed=11, flow=flow, S=S)
+    p = {k: v.to(dev) for k, v in prob["params"].items()}
+    rowp = prob["rowp"].to(dev) if prob["rowp"] is not None else None
+    fs = ops.FlowSpec(prob["program"], p["theta"].numel(), 0 if rowp is None else rowp.shape[1], dev)
+    out, g, status, (mu, v) = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
+                                            p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], prob["N_total"],
+                                            flow=fs, theta=p["theta"], rowp=rowp, S=S, want_moments=True)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    res = {"out": out.cpu(), "mu": mu.cpu(), "v": v.cpu()}
+    res.update({"g_" + k: t.cpu() for k, t in g.items() if t is not None})
+    return res
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def test_rows4_matches_rows16_and_is_reproducible(tmp_path):
+    if os.environ.get("TGP_ROWS4") == "0":
+        pytest.skip("this process is pinned to k_rows")
+    ref_file = str(tmp_path / "rows16.pt")
+    env = dict(os.environ, TGP_ROWS4="0")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), ref_file], env=env, cwd=ROOT)
+    ref = torch.load(ref_file)
+    for case, r16 in zip(CASES, ref):
+        a, b = _run(case), _run(case)
+        for k in a:
+            assert torch.equal(a[k], b[k]), ("k_rows4 is not bit-reproducible", case, k)
+            tol = 1e-10 if k in ("out", "mu", "v") else 1e-8
+            assert _rel(a[k], r16[k]) < tol, (case, k, _rel(a[k], r16[k]))
+
+
+def test_rows4_against_the_oracle_at_a_two_gpu_shard_size():
+    """N = 4306 (half of Power: 8-wave workgroups of k_rows4) against the CPU oracle: values 1e-9, gradients 1e-7."""
+    from oracle import tgp_oracle as orc       # checker only
+    from tgp.pytorch_amd import ops
+    dev = torch.device("cuda:0")
+    prob = orc.synthetic_problem(4306, 4, 100, seed=5, flow="tanh3x2", S=32)
+    (elbo, ell, kld), og = orc.elbo_and_grads(prob["X"], prob["Y"], prob["params"], prob["N_total"], prob["program"],
+                                              prob["xs"], prob["ws"])
+    p = {k: v.to(dev) for k, v in prob["params"].items()}
+    flow = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, dev)
+    out, g, status, _ = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
+                                      p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], prob["N_total"],
+                                      flow=flow, theta=p["theta"], S=32)
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0
+    assert _rel(out[0].cpu(), elbo) < 1e-9 and _rel(out[1].cpu(), ell) < 1e-9
+    for k_hip, k_or in (("Z", "Z"), ("raw_ls", "raw_lengthscale"), ("raw_os", "raw_outputscale"), ("m", "m"),
+                        ("Lam", "Lam"), ("lvn", "log_var_noise"), ("theta", "theta")):
+        assert _rel(g[k_hip].cpu(), og[k_or]) < 1e-7, (k_hip, _rel(g[k_hip].cpu(), og[k_or]))
+
+
+if __name__ == "__main__":       # child of the first test: the same cases through k_rows (TGP_ROWS4=0 in the environment)
+    assert os.environ.get("TGP_ROWS4") == "0"
+    torch.save([_run(c) for c in CASES], sys.argv[1])

@@ -86,7 +86,7 @@ size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, in
     return big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel) * sizeof(double);
   Plan p;
   if (make_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
-  size_t d = p.total;
+  size_t d = p.total + (size_t)(plan_alloc_blocks(N) - p.nblocks) * p.slab_len;   // slabs for whichever row kernel runs
   const size_t lik = lik_workspace_doubles(N, P, RP);
   if (lik > d) d = lik;
   return d * sizeof(double);
@@ -152,8 +152,12 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   }
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
-  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   p.nslots = fp.nslots;
+  if (const int nw4 = choose_rows4(p, true)) {
+    if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, nw4)) return rc;
+    p.nslots = fp.nslots;
+  }
+  if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   if (phases & TGP_PHASE_PREPARE)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (phases & TGP_PHASE_ROWS)
@@ -194,6 +198,8 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) return launch_big_moments(md, X, mu, v, status, ws, workspace_bytes / sizeof(double), st);
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
+  if (const int nw4 = choose_rows4(p, false))
+    if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS, nw4)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   FlowProg fp;
   fp.nblk = 0; fp.nslots = 0;
@@ -228,6 +234,8 @@ int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double
   }
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_ADJOINT)) return rc;
+  if (const int nw4 = choose_rows4(p, true))
+    if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_ADJOINT, nw4)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (int rc = launch_rows(p, md, fp, X, mu_bar, v_bar, nullptr, nullptr, nullptr, ws, true, st)) return rc;

@@ -46,6 +46,8 @@ namespace tgp {
 struct Plan {
   int N, D, M, S, nblk, P, RP, lik;
   int MT, MP, DP, CT, CT16, ntri, nblocks;
+  int nw4;     // 0: the 16-rows-per-wave row kernel (k_rows, 64 rows per block); else k_rows4 with nw4 waves per block
+  int rpb;     // data rows per row block (= per slab): 64 or 4 * nw4
   int nslots;  // store-mode flow stack slots
   int zs_lds;  // k_prep_a keeps Zs in LDS (set by the launcher from the LDS budget)
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
@@ -70,7 +72,22 @@ enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik) {
+// Waves per workgroup the 4-rows-per-wave row kernel (tgp_rows4.hpp) uses at N rows, 0 = not a candidate.  MEASURED
+// (profiles/r05_rows4_vs_rows16.txt, ROWS phase alone, M = 100, StepTanhL 3 x 2): it wins where the 16-row kernel has fewer
+// waves than the chip has SIMDs to spare -- 43.5-44.5 us against 52.1-52.4 for N <= 2 153 with 4-wave workgroups, 45-47
+// against 52.8 up to 4 306 rows with 8-wave ones (the row shards of a 2-, 4- or 8-GPU Power run, Boston) -- and loses
+// from 8 192 rows on (59.7 / 72.9 us against 53.7 / 54.0 at 8 192 / 8 611 rows: three waves per SIMD leave 168 registers
+// and the flow stack leaves no LDS to prefetch the operand images into), so the full Power batch stays on k_rows.
+inline int rows4_waves(int N) { return N <= 2153 ? 4 : (N <= 4306 ? 8 : 0); }
+// slabs a workspace must hold whichever row kernel runs
+inline int plan_alloc_blocks(int N) {
+  int nb = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
+  const int nw = rows4_waves(N);
+  if (nw > 0 && (N + 4 * nw - 1) / (4 * nw) > nb) nb = (N + 4 * nw - 1) / (4 * nw);
+  return nb < 1 ? 1 : nb;
+}
+
+inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int nw4 = 0) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
   p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik; p.nslots = 0; p.zs_lds = 0;
@@ -78,7 +95,9 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
   p.CT = (2 * p.DP + 1 + 15) / 16; p.CT16 = p.CT * 16;
   p.ntri = p.MT * (p.MT + 1) / 2;
-  p.nblocks = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
+  p.nw4 = nw4;
+  p.rpb = nw4 > 0 ? 4 * nw4 : TGP_ROWS_PER_BLOCK;
+  p.nblocks = (N + p.rpb - 1) / p.rpb;
   if (p.nblocks < 1) p.nblocks = 1;
   p.slab_G = 0;
   p.slab_T = p.slab_G + (size_t)p.ntri * 256;
@@ -782,7 +801,48 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
 // partials are summed over the NB nodes, then over the four lanes that share a data row (quad_sum), and lanes
 // with q == 0 accumulate them into accq[slot * qstride]; per-row parameter partials go to the lane-private
 // accr[(poff + j) * rstride].  All lanes of the wave must call this together (cross-lane sums inside).
-template <int NB>
+// value of lane l ^ 32 / l ^ 16 (gfx950 permlane swaps, see xor_sum32 / xor_sum16)
+__device__ __forceinline__ double lane_xor32(double x, bool hi) {
+  const unsigned lo = __double2loint(x), h = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+  return hi ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double lane_xor16(double x, bool odd) {
+  const unsigned lo = __double2loint(x), h = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+  return odd ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
+}
+// Wave sums of FOUR values for the price of about one and a half: a reduce-scatter over the two top lane bits (after the
+// xor-32 step a lane carries two of the four partial sums, after the xor-16 step one), then the four rotations inside
+// the row of 16 lanes.  Lane 16 q (q = 0..3) ends with the wave's total of value q; fixed order, bit-reproducible.
+__device__ __forceinline__ double wave_sum4(double p0, double p1, double p2, double p3, int lane) {
+  const bool b5 = lane & 32, b4 = lane & 16;
+  const double ka = b5 ? p2 : p0, sa = b5 ? p0 : p2, kb = b5 ? p3 : p1, sb = b5 ? p1 : p3;
+  const double ra = ka + lane_xor32(sa, b5), rb = kb + lane_xor32(sb, b5);
+  const double k = b4 ? rb : ra, sd = b4 ? ra : rb;
+  const double v = k + lane_xor16(sd, b4);
+  return ror_sum<1>(ror_sum<2>(ror_sum<4>(ror_sum<8>(v))));
+}
+// ... of TWO values: lane 0 ends with the total of p0, lane 32 with the total of p1
+__device__ __forceinline__ double wave_sum2(double p0, double p1, int lane) {
+  const bool b5 = lane & 32;
+  const double k = b5 ? p1 : p0, sd = b5 ? p0 : p1;
+  double v = k + lane_xor32(sd, b5);
+  v = xor_sum16(v);
+  return ror_sum<1>(ror_sum<2>(ror_sum<4>(ror_sum<8>(v))));
+}
+
+// RED: how far the shared-parameter partials are summed before the leader lanes add them to `accq`: 0 = over the four
+// lanes l, l^16, l^32, l^48 (k_rows: they share a data row; leaders = lanes 0..15), 2 = over the whole wave (k_rows4:
+// leader = lane 0; one accumulator column per wave instead of sixteen -- its LDS is the flow stack's).
+template <int RED>
+__device__ __forceinline__ double flow_red(double x) {
+  if constexpr (RED == 2) return wave_sum(x);
+  else return quad_sum(x);
+}
+template <int NB, int RED = 0>
 __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], const double* __restrict__ rp,
                                            const double* stack, int sstride, int nslots, double* accq, int qstride,
                                            bool qlead, double* accr, int rstride) {
@@ -815,8 +875,14 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
         lds_acc(accr + (poff + 0) * rstride, pa);
         lds_acc(accr + (poff + 1) * rstride, pb);
       } else {
-        pa = quad_sum(pa); pb = quad_sum(pb);
-        if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
+        if constexpr (RED == 2) {
+          const int ln = threadIdx.x & 63;
+          const double vv = wave_sum2(pa, pb, ln);
+          if ((ln & 31) == 0) lds_acc(accq + (poff + (ln >> 5)) * qstride, vv);
+        } else {
+          pa = flow_red<RED>(pa); pb = flow_red<RED>(pb);
+          if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
+        }
       }
     } else if (kind == TGP_FLOW_SAL) {
       sl -= 3;
@@ -843,8 +909,14 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
         lds_acc(accr + (poff + 0) * rstride, pa);
         lds_acc(accr + (poff + 1) * rstride, pb);
       } else {
-        pa = quad_sum(pa); pb = quad_sum(pb);
-        if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
+        if constexpr (RED == 2) {
+          const int ln = threadIdx.x & 63;
+          const double vv = wave_sum2(pa, pb, ln);
+          if ((ln & 31) == 0) lds_acc(accq + (poff + (ln >> 5)) * qstride, vv);
+        } else {
+          pa = flow_red<RED>(pa); pb = flow_red<RED>(pb);
+          if (qlead) { lds_acc(accq + (poff + 0) * qstride, pa); lds_acc(accq + (poff + 1) * qstride, pb); }
+        }
       }
     } else {
       sl -= 1 + K;
@@ -872,12 +944,18 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
           p3 -= dz[u];
           gp[u] += se[u];
         }
-        p0 = quad_sum(p0); p1 = quad_sum(p1 * g1); p2 = quad_sum(p2); p3 = quad_sum(p3 * g3);
-        if (qlead) {
-          lds_acc(accq + (o + 0) * qstride, p0);
-          lds_acc(accq + (o + 1) * qstride, p1);
-          lds_acc(accq + (o + 2) * qstride, p2);
-          lds_acc(accq + (o + 3) * qstride, p3);
+        if constexpr (RED == 2) {
+          const int ln = threadIdx.x & 63;
+          const double vv = wave_sum4(p0, p1 * g1, p2, p3 * g3, ln);
+          if ((ln & 15) == 0) lds_acc(accq + (o + (ln >> 4)) * qstride, vv);
+        } else {
+          p0 = flow_red<RED>(p0); p1 = flow_red<RED>(p1 * g1); p2 = flow_red<RED>(p2); p3 = flow_red<RED>(p3 * g3);
+          if (qlead) {
+            lds_acc(accq + (o + 0) * qstride, p0);
+            lds_acc(accq + (o + 1) * qstride, p1);
+            lds_acc(accq + (o + 2) * qstride, p2);
+            lds_acc(accq + (o + 3) * qstride, p3);
+          }
         }
       }
       TGP_EACH(u, NB) c[u] *= gp[u];

@@ -1,12 +1,33 @@
 // tgp_rows.hip -- dispatch of the fused row kernel over its compile-time tilings (MT = ceil(M/16), DP)
 #include "tgp_rows.hpp"
 #include "tgp_launch.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace tgp {
 
 #define DECL(n) int launch_rows_mt##n(const RowArgs& a, int mode, size_t lds, hipStream_t st);
 DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7) DECL(8)
 #undef DECL
+size_t rows4_lds_bytes(const Plan& p, bool train, int nw);   // tgp_rows_inst.hip (needs tgp_rows4.hpp)
+
+// Which row kernel: the 4-rows-per-wave kernel (tgp_rows4.hpp) where it measured faster -- a training launch with the
+// Gauss-Hermite (flow) likelihood on at most 4 306 rows (rows4_waves, tgp_dev.hpp; the closed-form likelihoods have no
+// quadrature to spread and stay on k_rows: 36 us against 34) -- and where its LDS plan fits a CU.  TGP_ROWS4=0 forces the
+// 16-row kernel, TGP_ROWS4=<4|8> a workgroup size (A/B measurements, tools/probes/rows_kernel_time.py).
+int choose_rows4(const Plan& p, bool train) {
+  static const int env = [] { const char* e = getenv("TGP_ROWS4"); return e ? atoi(e) : -1; }();
+  if (env == 0 || !train) return 0;
+  int nw = p.lik == TGP_LIK_FLOW ? rows4_waves(p.N) : 0;
+  if (env == 4 || env == 8) nw = env;
+  if (nw == 0) return 0;
+  if ((p.N + 4 * nw - 1) / (4 * nw) > plan_alloc_blocks(p.N)) return 0;   // (a forced size the workspace has no slabs for)
+  const size_t need = rows4_lds_bytes(p, train, nw);
+  static const bool verbose = getenv("TGP_ROWS4_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "[tgp] choose_rows4: N %d MT %d nslots %d -> nw %d, LDS %zu B\n", p.N, p.MT, p.nslots, nw, need);
+  if (need > 160 * 1024 - 2048) return 0;
+  return nw;
+}
 
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
@@ -25,7 +46,8 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
       lds = row_lds(p, 2, fp.nslots).total * sizeof(double);
     }
   }
-  if (lds > lim) return TGP_E_LDS;
+  if (p.nw4 > 0) mode = 100 + (train ? 50 : 0) + p.nw4;      // k_rows4<.., train, nw4> (its own LDS plan)
+  else if (lds > lim) return TGP_E_LDS;
   switch (p.MT) {
     case 1: return launch_rows_mt1(a, mode, lds, st);
     case 2: return launch_rows_mt2(a, mode, lds, st);
