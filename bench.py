@@ -92,6 +92,57 @@ def rows_kernel_flops(w):
     return 3.0 * fwd
 
 
+# ---- the builder's PREDICTION of a multi-GPU line (VERDICT r4 #5b): per-kernel times measured on ONE MI355X (profiles/r05_*,
+# microseconds) + a stated estimate of the collective, so that the first SCALE record can be judged against a number.
+# Every multi-GPU entry is UNMEASURED ON HARDWARE: no multi-GPU node was available to the builder in any round.
+EXPECT = {
+    # fused path (M <= 128): prepare + [rows(N_rank)] + slab reduction + the M x M adjoint chain; with more than one rank the
+    # Adam update is a launch of its own behind the collective (one rank: folded into the last two backward launches)
+    "tgp_power_tanh3x2": dict(prep=24.8, rows={8611: 49.5, 4306: 50.6, 2153: 48.5, 1077: 47.9}, reduce=5.9, bwd=27.9, adam=4.6),
+    "tgp_power_sal2": dict(prep=24.8, rows={8611: 45.0, 4306: 46.0, 2153: 44.0, 1077: 43.5}, reduce=5.9, bwd=27.9, adam=4.6),
+    "svgp_power": dict(prep=24.8, rows={8611: 37.5, 4306: 36.5, 2153: 36.0, 1077: 35.8}, reduce=5.0, bwd=27.9, adam=4.6),
+    # general-M path: the single-GPU step of the workload (weak scaling: every rank runs it on its own shard) and, for the
+    # minibatch split 8 ways, the measured per-rank share (tgp_airline_mb10k_rank8)
+    "tgp_airline_tanh5x6": dict(ms=31.4),
+    "tgp_airline_mb10k": dict(ms=2.26, strong_ms={8: 1.28}),
+}
+
+
+def allreduce_estimate_us(world, doubles):
+    """RCCL all-reduce of `doubles` float64 over xGMI inside the captured step (tgp_allreduce_f64 on the compute stream).
+    ESTIMATE, not a measurement: a latency term (ring / tree hops of ~4 us each: 2 (W - 1) steps) plus the ring's wire time
+    2 (W - 1) / W x bytes at 0.7 x 153 GB/s per link."""
+    if world <= 1:
+        return 0.0
+    hops = 2 * (world - 1)
+    return 8.0 + 2.0 * hops + (2.0 * (world - 1) / world) * doubles * 8 / (0.7 * 153e9) * 1e6
+
+
+def expected_line(workload, w, world, scaling, n_doubles, measured_ms_1gpu=None):
+    """config.expected: the predicted ms/step and value of this (workload, world, scaling)."""
+    e = EXPECT.get(workload)
+    ar = allreduce_estimate_us(world, n_doubles)
+    if e is not None and scaling == "strong":
+        nr = -(-w["N"] // world)
+        key = min(e["rows"], key=lambda k: abs(k - nr))
+        us = e["prep"] + e["rows"][key] + e["reduce"] + e["bwd"] + (e["adam"] if world > 1 else 0.0) + ar
+        basis = ("k_prep_a %.1f + row kernel at %d rows/rank %.1f + k_reduce %.1f + k_bwd12/34/5 %.1f%s + all-reduce of %d doubles "
+                 "%.1f us (ESTIMATE: 8 us + 2 us per ring step + wire time; unmeasured on hardware)"
+                 % (e["prep"], nr, e["rows"][key], e["reduce"], e["bwd"], " + k_adam_dev %.1f" % e["adam"] if world > 1 else "",
+                    n_doubles, ar))
+        return {"ms_per_step": us * 1e-3, "value": 1e6 / us, "basis": basis, "measured_on": "1 x MI355X per-kernel times, profiles/r05_*"}
+    if measured_ms_1gpu is None and e is not None and "ms" in e:
+        measured_ms_1gpu = e.get("strong_ms", {}).get(world) if scaling == "strong" and world > 1 else e["ms"]
+    if measured_ms_1gpu is not None:
+        us = measured_ms_1gpu * 1e3 + ar
+        units = world if scaling == "weak" else 1
+        return {"ms_per_step": us * 1e-3, "value": units * 1e6 / us,
+                "basis": "single-rank step of this rank's rows %.3f ms + all-reduce of %d doubles %.1f us (ESTIMATE, unmeasured on "
+                         "hardware)" % (measured_ms_1gpu, n_doubles, ar),
+                "measured_on": "1 x MI355X"}
+    return None
+
+
 def make_problem(w, seed):
     from tgp.pytorch_amd.synthetic import synthetic_problem
     return synthetic_problem(w["N"], w["D"], w["M"], seed=seed, flow=w["flow"], S=w["S"])
@@ -181,16 +232,26 @@ def cpu_baseline(prob, budget_s=15.0, max_steps=400, mlp=None):
     best = max(rates, key=rates.get)
     torch.set_num_threads(best)
     one()
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and time.perf_counter() - t0 < budget_s * 0.6:
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
+    # The reported rate is the MEDIAN of three timed windows at the calibrated thread count (one window moved
+    # +-35 % with the host's other tenants from line to line); all three are listed.
+    wins, n_tot, t_tot = [], 0, 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        n = 0
+        while n < max_steps // 3 + 1 and (time.perf_counter() - t0 < budget_s * 0.2 or n == 0):
+            one()
+            n += 1
+        dtw = time.perf_counter() - t0
+        wins.append(n / dtw * ns / N)
+        n_tot += n
+        t_tot += dtw
+    med = sorted(wins)[1]
     cal = ", ".join("%d thr %.1f/s" % (nt, rates[nt] * ns / N) for nt in sorted(rates))
-    return {"value": n / dt * ns / N, "unit": "ELBO-steps/s", "cores": best, "kind": "port", "host_cpus": ncpu,
-            "sample": "%d steps on the first %d of %d rows%s (oracle/tgp_oracle.py, float64, torch.optim.Adam, %d threads: the "
-                      "best of the calibrated rates [%s], each timed >= %.1f s), %.1f s" % (n, ns, N, ", rate scaled by rows" if ns < N else "", best, cal, per, dt)}
+    return {"value": med, "unit": "ELBO-steps/s", "cores": best, "kind": "port", "host_cpus": ncpu,
+            "windows": [round(x, 2) for x in wins],
+            "sample": "median of 3 timed windows (%s steps/s), %d steps on the first %d of %d rows%s (oracle/tgp_oracle.py, float64, "
+                      "torch.optim.Adam, %d threads: the best of the calibrated rates [%s], each timed >= %.1f s), %.1f s"
+                      % (", ".join("%.1f" % x for x in wins), n_tot, ns, N, ", rate scaled by rows" if ns < N else "", best, cal, per, t_tot)}
 
 
 def launch_ranks(n):
@@ -429,7 +490,9 @@ def main():
             "config": {"workload": args.workload, "rows_per_gpu": int(Xr.shape[0]), "D": w["D"], "M": w["M"], "S": w["S"],
                        "flow": w["flow"], "global_rows_per_step": n_global, "parallelism": "row-shard x%d" % world,
                        "launch": "eager" if args.no_graph else ("hipgraph, %d steps per graph launch" % eng.unroll if many else "hipgraph"), "final_elbo": elbo, "process_group": pg,
-                       "replicas": 1 + len(extra)},
+                       "replicas": 1 + len(extra),
+                       "expected": expected_line(args.workload, w, world, args.scaling, eng.fp.n + eng.fp.extra,
+                                                 measured_ms_1gpu=(1e3 * dt / args.steps) if world == 1 else None)},
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,

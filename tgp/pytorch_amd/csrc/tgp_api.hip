@@ -156,6 +156,9 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   if (const int nw4 = choose_rows4(p, true)) {
     if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, nw4)) return rc;
     p.nslots = fp.nslots;
+  } else if (const int rw = rows_per_wave(p, true); rw != 16) {
+    if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, 0, rw)) return rc;
+    p.nslots = fp.nslots;
   }
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   if (phases & TGP_PHASE_PREPARE)

@@ -47,7 +47,8 @@ struct Plan {
   int N, D, M, S, nblk, P, RP, lik;
   int MT, MP, DP, CT, CT16, ntri, nblocks;
   int nw4;     // 0: the 16-rows-per-wave row kernel (k_rows, 64 rows per block); else k_rows4 with nw4 waves per block
-  int rpb;     // data rows per row block (= per slab): 64 or 4 * nw4
+  int rw;      // data rows per wave of k_rows: 16, or 10 (tgp_rows.hpp, RW) -- meaningful when nw4 == 0
+  int rpb;     // data rows per row block (= per slab): 4 * rw or 4 * nw4
   int nslots;  // store-mode flow stack slots
   int zs_lds;  // k_prep_a keeps Zs in LDS (set by the launcher from the LDS budget)
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
@@ -79,15 +80,21 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // from 8 192 rows on (59.7 / 72.9 us against 53.7 / 54.0 at 8 192 / 8 611 rows: three waves per SIMD leave 168 registers
 // and the flow stack leaves no LDS to prefetch the operand images into), so the full Power batch stays on k_rows.
 inline int rows4_waves(int N) { return N <= 2153 ? 4 : (N <= 4306 ? 8 : 0); }
+// Data rows per wave k_rows uses at N rows when the launch qualifies (training, flow likelihood, shared flow parameters;
+// tgp_rows.hip rows_per_wave): 10 where 4 x 10-row workgroups still number at most one per CU and 16-row waves would leave
+// SIMDs idle (Power: 862 waves in 216 workgroups instead of 539 in 135), else 16.
+inline int rows_rw(int N) { return (N > 4306 && (N + 39) / 40 <= 256) ? 10 : 16; }
 // slabs a workspace must hold whichever row kernel runs
 inline int plan_alloc_blocks(int N) {
   int nb = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
   const int nw = rows4_waves(N);
   if (nw > 0 && (N + 4 * nw - 1) / (4 * nw) > nb) nb = (N + 4 * nw - 1) / (4 * nw);
+  const int rw = rows_rw(N);
+  if ((N + 4 * rw - 1) / (4 * rw) > nb) nb = (N + 4 * rw - 1) / (4 * rw);
   return nb < 1 ? 1 : nb;
 }
 
-inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int nw4 = 0) {
+inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int nw4 = 0, int rw = 16) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > 16 * TGP_MAX_MT) return TGP_E_UNSUPPORTED;
   p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik; p.nslots = 0; p.zs_lds = 0;
@@ -96,7 +103,8 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.CT = (2 * p.DP + 1 + 15) / 16; p.CT16 = p.CT * 16;
   p.ntri = p.MT * (p.MT + 1) / 2;
   p.nw4 = nw4;
-  p.rpb = nw4 > 0 ? 4 * nw4 : TGP_ROWS_PER_BLOCK;
+  p.rw = rw;
+  p.rpb = nw4 > 0 ? 4 * nw4 : 4 * rw;
   p.nblocks = (N + p.rpb - 1) / p.rpb;
   if (p.nblocks < 1) p.nblocks = 1;
   p.slab_G = 0;

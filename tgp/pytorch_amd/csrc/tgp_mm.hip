@@ -406,23 +406,22 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
   const int part = blockIdx.y;
   const int b0 = (int)((long long)p.nblocks * part / TGP_RSPLIT), b1 = (int)((long long)p.nblocks * (part + 1) / TGP_RSPLIT);
   const double* sl = ws + p.slabs + e;
-  // 16 slabs per batch, all requested before the first add, the ragged end inside the batch (clamped index, zero
-  // weight): the slabs come from the Infinity Cache / HBM at 1-2 us per dependent round trip, and the former scalar
-  // tail loop paid one round trip per leftover slab (2 of this kernel's 5 us at Power size)
+  // TGP_RBATCH slabs per batch, all requested before the first add, the ragged end inside the batch (clamped index, zero
+  // weight): the slabs come from the Infinity Cache / HBM at 1-2 us per dependent round trip.  Round 5: 28 per batch (was
+  // 16) -- the 10-rows-per-wave row kernel writes 216 slabs at Power size, 54 per partial sum: two round trips, not four.
+  constexpr int RB = 28;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  // (16 slabs per batch; 40 in flight -- all of a Power-sized partial sum in one round trip -- measured no faster: the
-  //  kernel moves 9.8 MB through 144 workgroups and is bound by that, not by its three round trips)
-  for (int b = b0; b < b1; b += 16) {
-    double t[16];
+  for (int b = b0; b < b1; b += RB) {
+    double t[RB];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < RB; ++u) {
       const int bu = b + u < b1 ? b + u : b1 - 1;
       t[u] = sl[(size_t)bu * p.slab_len];
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = b + u < b1 ? t[u] : 0.0;
-    s0 += (t[0] + t[4]) + (t[8] + t[12]); s1 += (t[1] + t[5]) + (t[9] + t[13]);
-    s2 += (t[2] + t[6]) + (t[10] + t[14]); s3 += (t[3] + t[7]) + (t[11] + t[15]);
+    for (int u = 0; u < RB; ++u) t[u] = b + u < b1 ? t[u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < RB; u += 4) { s0 += t[u]; s1 += t[u + 1]; s2 += t[u + 2]; s3 += t[u + 3]; }
   }
   const double s = (s0 + s1) + (s2 + s3);
   if (e < p.slab_T) {

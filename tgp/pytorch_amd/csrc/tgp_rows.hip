@@ -29,6 +29,17 @@ int choose_rows4(const Plan& p, bool train) {
   return nw;
 }
 
+// Rows per wave of k_rows: TGP_RW_SMALL (10) for a training launch with the flow likelihood and shared flow parameters whose
+// (row, node) pairs fill the lanes in one trip (10 S <= 64 x 5) at the sizes rows_rw() names, if the LDS plan fits; else 16.
+// TGP_ROWS_RW=16 forces 16 (A/B measurements).
+int rows_per_wave(const Plan& p, bool train) {
+  static const int env = [] { const char* e = getenv("TGP_ROWS_RW"); return e ? atoi(e) : 0; }();
+  if (!train || env == 16 || p.lik != TGP_LIK_FLOW || p.RP > 0 || p.nblk < 1) return 16;
+  if (rows_rw(p.N) != TGP_RW_SMALL || TGP_RW_SMALL * p.S > 64 * TGP_RW_NODES) return 16;
+  if (row_lds(p, 1, p.nslots, TGP_RW_SMALL).total * sizeof(double) > 160 * 1024 - 1024) return 16;
+  return TGP_RW_SMALL;
+}
+
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
   RowArgs a;
@@ -47,7 +58,11 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
     }
   }
   if (p.nw4 > 0) mode = 100 + (train ? 50 : 0) + p.nw4;      // k_rows4<.., train, nw4> (its own LDS plan)
-  else if (lds > lim) return TGP_E_LDS;
+  else if (train && p.rw == TGP_RW_SMALL) {                 // k_rows<.., 1, 10>
+    mode = 200;
+    lds = row_lds(p, 1, fp.nslots, TGP_RW_SMALL).total * sizeof(double);
+    if (lds > lim) return TGP_E_LDS;
+  } else if (lds > lim) return TGP_E_LDS;
   switch (p.MT) {
     case 1: return launch_rows_mt1(a, mode, lds, st);
     case 2: return launch_rows_mt2(a, mode, lds, st);

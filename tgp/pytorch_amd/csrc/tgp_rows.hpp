@@ -49,12 +49,14 @@ struct RowArgs {
 
 // LDS carve-up (offsets in doubles)
 struct RowLds {
-  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, ti, xs, wn, stack, acc, red, prog, total;
+  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, ti, xs, wn, stack, acc, red, prog, rin, cbuf, total;
 };
+#define TGP_RW_SMALL 10          /* data rows per wave of the k_rows<.., RW = 10> variant (see the kernel) */
+#define TGP_RW_NODES 5           /* its quadrature nodes in flight per lane: 10 rows x 32 nodes = 64 lanes x 5 */
 
 // mode: 0 = moments only; 1 = training, TGP_NODES_IN_FLIGHT quadrature nodes in flight per lane; 2 = training, one
 // node in flight (fallback when the 4-node stack of a long flow does not fit in LDS); nslots = flow_slots(program)
-__host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
+__host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots, int rw = 16) {
   const bool train = mode != 0;
   RowLds L;
   size_t o = 0;
@@ -77,13 +79,18 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots) {
     // the flow stack (nodes-in-flight x slots x 256 lanes) shares its space with the transposition tile / the operand
     // panels: the flow phase runs strictly between GEMM 2 and GEMM 3
     // (tile, xt, vbs, mbs are contiguous and all dead during the flow phase: the stack may cover all of them)
-    const size_t st = (size_t)(nslots > 0 ? nslots : 1) * (mode == 1 ? TGP_NODES_IN_FLIGHT : 1) * 256;
+    const size_t st = (size_t)(nslots > 0 ? nslots : 1) * (mode == 1 ? (rw < 16 ? TGP_RW_NODES : TGP_NODES_IN_FLIGHT) : 1) * 256;
     if (L.tile + st > o) take(L.tile + st - o);
     L.stack = L.tile;
     L.acc = take((size_t)(p.P > 0 ? p.P : 1) * 64 + (size_t)p.RP * 256);  // [P][64] quad-reduced + [RP][256] per lane
+    L.rin = L.cbuf = o;
+    if (rw < 16) {   // the quadrature's (row, node) pairs are dealt over all 64 lanes: per-wave row inputs and pair results
+      L.rin = take(4 * 48);
+      L.cbuf = take((size_t)4 * 64 * TGP_RW_NODES);
+    }
   } else {
     L.tile = take((size_t)p.MP * 32);  // only the two operand panels (2 x MP x 16)
-    L.xt = L.vbs = L.mbs = L.stack = L.acc = o;
+    L.xt = L.vbs = L.mbs = L.stack = L.acc = L.rin = L.cbuf = o;
   }
   L.total = o;
   return L;
@@ -157,16 +164,25 @@ __device__ __forceinline__ d4 subst_chain(const double* a0, int nsum, int dstep0
 
 // One wave per SIMD by construction (4 waves per workgroup, one workgroup per CU): tell the register allocator and the
 // scheduler so, otherwise hipcc schedules to minimise VGPRs and serialises every LDS read behind its MFMA.
-template <int MT, int DP, int MODE>
+// RW = data rows per wave: 16 (every column of the 16 x 16 x 4 tiles carries a row), or TGP_RW_SMALL = 10 (round 5; training
+// with the flow likelihood and shared flow parameters only).  The tile chains of a wave cost the same whatever the number
+// of columns that carry rows, but the quadrature and the row statistics do not: at Power size 16 rows per wave are 539 waves
+// for 1 024 SIMDs, 10 rows per wave are 862 waves in 216 workgroups -- 10 x 32 (row, node) pairs are exactly 5 per lane,
+// dealt over ALL 64 lanes (pair p = lane + 64 u: row p % 10, node p / 10) with five nodes in flight per lane instead of two
+// trips of four (row inputs and pair results cross the wave through LDS), and the statistics contract over 40 columns
+// instead of 64.
+template <int MT, int DP, int MODE, int RW = 16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_rows(RowArgs a) {
+  static_assert(RW == 16 || (RW == TGP_RW_SMALL && MODE == 1), "rows per wave: 16, or TGP_RW_SMALL in training mode 1");
   constexpr bool TRAIN = MODE != 0;
+  constexpr int RBK = 4 * RW;   // data rows (= statistics columns) per workgroup
   constexpr int MP = MT * 16;
   constexpr int CT = (2 * DP + 1 + 15) / 16, CT16 = CT * 16;
   constexpr int LD = TGP_TILE_LD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const Plan& p = a.p;
-  const RowLds L = row_lds(p, MODE, a.prog.nslots);
+  const RowLds L = row_lds(p, MODE, a.prog.nslots, RW);
   double* zs = sm + L.zs;
   double* ils = sm + L.ils;
   double* mv = sm + L.mv;
@@ -292,8 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
   // this lane's data row and the step header: requested with the first staging loads (they need nothing from LDS;
   // behind the staging barrier they cost a memory round trip of their own)
-  const int n = bid * TGP_ROWS_PER_BLOCK + wave * 16 + nl;
-  const bool valid = n < N;
+  const int n = bid * RBK + wave * RW + nl;
+  const bool valid = nl < RW && n < N;
   const int nc = valid ? n : N - 1;
   double xraw[DP];
 #pragma unroll
@@ -463,49 +479,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     mub = y;
     vb = a.rowp[nc];
   } else {
-    // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): this lane takes the
-    // quadrature nodes s = q, q+4, q+8, ... of its row
     FlowDev F{progL, p.nblk, tpL, tgL, tiL};
     const double sq = sqrt(2.0 * v);
-    const double* rp = (a.rowp != nullptr && RP > 0) ? a.rowp + (size_t)nc * RP : nullptr;
-    double cm = 0.0, cv = 0.0;
-    {
-      // NB nodes in flight per lane (independent dependency chains); every lane runs the same trip count
-      // (cross-lane sums inside the reverse sweep), out-of-range nodes and padding rows carry weight 0
-      constexpr int NB = MODE == 1 ? TGP_NODES_IN_FLIGHT : 1;
+    if constexpr (RW < 16) {
+      // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148) with the wave's RW x S
+      // (row, node) pairs dealt over all 64 lanes, NB per lane in ONE trip (the launcher checked RW * S <= 64 NB and
+      // shared flow parameters): pair p = lane + 64 u is node p / RW of row p % RW.  The row lanes publish (mu, sqrt(2 v),
+      // y) through the wave's LDS words, every pair's d(ell)/d(f0) goes back the same way and the row lanes add their
+      // row's nodes in a fixed order.
+      constexpr int NB = TGP_RW_NODES;
+      double* rin = sm + L.rin + wave * 48;
+      double* cb = sm + L.cbuf + wave * (64 * NB);
+      if (q == 0) { rin[nl] = mu; rin[16 + nl] = sq; rin[32 + nl] = y; }
       double* accq = acc + wave * 16 + nl;
       double* accr = acc + (size_t)P * 64 + tid;
-      const int ntrip = (p.S + 4 * NB - 1) / (4 * NB);
-      lds_barrier();  // the stack aliases the operand panels: all waves must be done with GEMM 2
-      for (int it = 0; it < ntrip; ++it) {
-        double xn[NB], wq[NB], f[NB], c[NB];
+      lds_barrier();  // the stack aliases the operand panels: all waves must be done with GEMM 2 (and rin is visible)
+      double xn[NB], wq[NB], f[NB], c[NB], yv[NB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const int sn = q + 4 * (NB * it + u);
-          xn[u] = xsL[sn < p.S ? sn : 0];
-          wq[u] = (valid && sn < p.S) ? wnL[sn] : 0.0;
-          f[u] = mu + sq * xn[u];
-        }
-        flow_forward_store<NB>(F, f, rp, stack + tid, 256);
+      for (int u = 0; u < NB; ++u) {
+        const int pp = lane + 64 * u, row = pp % RW, sn = pp / RW;
+        const bool ok = sn < p.S && bid * RBK + wave * RW + row < N;
+        xn[u] = xsL[sn < p.S ? sn : 0];
+        wq[u] = ok ? wnL[sn < p.S ? sn : 0] : 0.0;
+        f[u] = rin[row] + rin[16 + row] * xn[u];
+        yv[u] = rin[32 + row];
+      }
+      flow_forward_store<NB>(F, f, nullptr, stack + tid, 256);
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          const double r = y - f[u];
-          ellp += wq[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
-          etap += wq[u] * (-0.5 + 0.5 * einv * r * r);
-          c[u] = a.scale * einv * wq[u] * r;
-        }
-        flow_backward_store<NB>(F, c, rp, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256);
+      for (int u = 0; u < NB; ++u) {
+        const double r = yv[u] - f[u];
+        ellp += wq[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+        etap += wq[u] * (-0.5 + 0.5 * einv * r * r);
+        c[u] = a.scale * einv * wq[u] * r;
+      }
+      flow_backward_store<NB>(F, c, nullptr, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256);
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          cm += c[u];
-          cv += c[u] * xn[u];
+      for (int u = 0; u < NB; ++u) cb[lane + 64 * u] = c[u];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // row lane (nl, q): the nodes q, q + 4, ... of row nl (pair index node * RW + row)
+      double cm = 0.0, cv = 0.0;
+      if (nl < RW) {
+        for (int sn = q; sn < p.S; sn += 4) {
+          const double cc = cb[sn * RW + nl];
+          cm += cc;
+          cv += cc * xsL[sn];
         }
       }
+      mub = quad_sum(cm);
+      vb = quad_sum(cv) / sq;
+      if (!valid) { mub = 0.0; vb = 0.0; }   // (ellp / etap of this lane belong to its PAIRS and are already weighted)
+    } else {
+      // GaussianNonLinearMean.expected_log_prob (likelihoods/GaussianNonLinearMean.py:91-148): this lane takes the
+      // quadrature nodes s = q, q+4, q+8, ... of its row
+      const double* rp = (a.rowp != nullptr && RP > 0) ? a.rowp + (size_t)nc * RP : nullptr;
+      double cm = 0.0, cv = 0.0;
+      {
+        // NB nodes in flight per lane (independent dependency chains); every lane runs the same trip count
+        // (cross-lane sums inside the reverse sweep), out-of-range nodes and padding rows carry weight 0
+        constexpr int NB = MODE == 1 ? TGP_NODES_IN_FLIGHT : 1;
+        double* accq = acc + wave * 16 + nl;
+        double* accr = acc + (size_t)P * 64 + tid;
+        const int ntrip = (p.S + 4 * NB - 1) / (4 * NB);
+        lds_barrier();  // the stack aliases the operand panels: all waves must be done with GEMM 2
+        for (int it = 0; it < ntrip; ++it) {
+          double xn[NB], wq[NB], f[NB], c[NB];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const int sn = q + 4 * (NB * it + u);
+            xn[u] = xsL[sn < p.S ? sn : 0];
+            wq[u] = (valid && sn < p.S) ? wnL[sn] : 0.0;
+            f[u] = mu + sq * xn[u];
+          }
+          flow_forward_store<NB>(F, f, rp, stack + tid, 256);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const double r = y - f[u];
+            ellp += wq[u] * (-0.5 * TGP_LOG_2PI_REF - 0.5 * eta - 0.5 * einv * r * r);
+            etap += wq[u] * (-0.5 + 0.5 * einv * r * r);
+            c[u] = a.scale * einv * wq[u] * r;
+          }
+          flow_backward_store<NB>(F, c, rp, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            cm += c[u];
+            cv += c[u] * xn[u];
+          }
+        }
+      }
+      mub = quad_sum(cm);
+      vb = quad_sum(cv) / sq;
+      if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
     }
-    mub = quad_sum(cm);
-    vb = quad_sum(cv) / sq;
   }
-  if (!valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
+  if (p.lik != TGP_LIK_FLOW && !valid) { mub = 0.0; vb = 0.0; ellp = 0.0; etap = 0.0; }
 
   ROW_STAMP(a.ws, p, 6);
   // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = L^-T Abar ----
@@ -544,16 +611,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   ROW_STAMP(a.ws, p, 7);
   double* slab = a.ws + p.slabs + (size_t)bid * p.slab_len;
-  const int col = wave * 16 + nl;
+  const int col = wave * RW + nl;   // this lane's data row among the workgroup's RBK statistics columns (nl < RW)
 
   // ---- phase 1: E = Kbar o K through LDS (transposed), T = E [xs, xs^2, 1] on MFMA ----
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Ba[i][r] * Kr[4 * i + r];
+    for (int r = 0; r < 4; ++r)
+      if (RW == 16 || nl < RW) tile[(16 * i + 4 * r + q) * LD + col] = Ba[i][r] * Kr[4 * i + r];
 #pragma unroll
   for (int c = 0; c < CT16; ++c) {
-    if ((c & 3) == q) {
+    if ((c & 3) == q && (RW == 16 || nl < RW)) {
       double val = 0.0;
       if (c < DP) val = x[c < DP ? c : 0];
       else if (c < 2 * DP) val = x[(c - DP) < DP ? (c - DP) : 0] * x[(c - DP) < DP ? (c - DP) : 0];
@@ -566,7 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ti = t / CT, tc = t % CT;
     d4 c = {0, 0, 0, 0};
     c = tile_mm_f([&](int k) { return tile[(16 * ti + nl) * LD + k + q]; },
-                  [&](int k) { return xt[(k + q) * CT16 + 16 * tc + nl]; }, 0, TGP_ROWS_PER_BLOCK, c);
+                  [&](int k) { return xt[(k + q) * CT16 + 16 * tc + nl]; }, 0, RBK, c);
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
   }
@@ -577,8 +645,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
-  if (q == 0) { vbs[col] = vb; mbs[col] = mub; }
+    for (int r = 0; r < 4; ++r)
+      if (RW == 16 || nl < RW) tile[(16 * i + 4 * r + q) * LD + col] = Aa[i][r];
+  if (q == 0 && (RW == 16 || nl < RW)) { vbs[col] = vb; mbs[col] = mub; }
   lds_barrier();
   ROW_STAMP(a.ws, p, 17);
   // Row-blocks of G are dealt to the waves in balanced groups -- MT odd: {MT-1}, {MT-2, 0}, {MT-3, 1}, ...; MT even:
@@ -598,33 +667,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       for (int g = 0; g < nrows; ++g) {
         const int ti = rows[g];
-        double af[16];
+        double af[RW];
 #pragma unroll
-        for (int nk = 0; nk < 16; ++nk) af[nk] = tile[(16 * ti + nl) * LD + 4 * nk + q];
+        for (int nk = 0; nk < RW; ++nk) af[nk] = tile[(16 * ti + nl) * LD + 4 * nk + q];
         {  // s = A mubar (B operand = mubar in column 0)
           d4 c = {0, 0, 0, 0};
-          double bm[16];
+          double bm[RW];
 #pragma unroll
-          for (int nk = 0; nk < 16; ++nk) bm[nk] = nl == 0 ? mbs[4 * nk + q] : 0.0;
+          for (int nk = 0; nk < RW; ++nk) bm[nk] = nl == 0 ? mbs[4 * nk + q] : 0.0;
 #pragma unroll
-          for (int nk = 0; nk < 16; ++nk) c = TGP_MFMA(af[nk], bm[nk], c);
+          for (int nk = 0; nk < RW; ++nk) c = TGP_MFMA(af[nk], bm[nk], c);
           if (nl == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
           }
         }
 #pragma unroll
-        for (int nk = 0; nk < 16; ++nk) af[nk] *= vbs[4 * nk + q];
+        for (int nk = 0; nk < RW; ++nk) af[nk] *= vbs[4 * nk + q];
         for (int tj = 0; tj <= ti; ++tj) {
           const int t = ti * (ti + 1) / 2 + tj;
           d4 c = {0, 0, 0, 0};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            double bv[8];
+            constexpr int HB = (RW + 1) / 2;   // k-steps per batch (two batches cover the RW k-steps of the workgroup's columns)
+            double bv[HB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bv[u] = tile[(16 * tj + nl) * LD + 4 * (8 * h + u) + q];
+            for (int u = 0; u < HB; ++u)
+              if (HB * h + u < RW) bv[u] = tile[(16 * tj + nl) * LD + 4 * (HB * h + u) + q];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c = TGP_MFMA(af[8 * h + u], bv[u], c);
+            for (int u = 0; u < HB; ++u)
+              if (HB * h + u < RW) c = TGP_MFMA(af[HB * h + u], bv[u], c);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];

@@ -12,10 +12,10 @@
 
 namespace tgp {
 
-template <int DP, int MODE>
+template <int DP, int MODE, int RW = 16>
 static int launch_one(const RowArgs& a, size_t lds, hipStream_t st) {
   constexpr bool TRAIN = MODE != 0;
-  auto kern = k_rows<TGP_MT, DP, MODE>;
+  auto kern = k_rows<TGP_MT, DP, MODE, RW>;
   static size_t lds_cur = 48 * 1024;
   if (int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, &lds_cur)) return rc;
   // the row blocks, then (training) the MT passenger blocks
@@ -45,6 +45,7 @@ static int launch_dp(const RowArgs& a, int mode, size_t lds, hipStream_t st) {
   switch (mode) {
     case 150 + 4: return launch_one4<DP, true, 4>(a, st);
     case 150 + 8: return launch_one4<DP, true, 8>(a, st);
+    case 200: return launch_one<DP, 1, TGP_RW_SMALL>(a, lds, st);
     case 0: return launch_one<DP, 0>(a, lds, st);
     case 1: return launch_one<DP, 1>(a, lds, st);
     default: return launch_one<DP, 2>(a, lds, st);
