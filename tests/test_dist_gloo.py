@@ -62,3 +62,72 @@ def test_shard_rows_partition():
         spans = [shard_rows(N, W, r) for r in range(W)]
         assert spans[0][0] == 0 and spans[-1][1] == N
         assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+
+
+def _bootstrap_worker(rank, world, port, ret):
+    """RcclComm's guarded bootstrap over gloo: rank 1's local step fails (a library that refuses tgp_comm_load); BOTH
+    ranks must raise RcclUnavailable -- nobody is left in the id broadcast or in ncclCommInitRank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from tgp.pytorch_amd import engine, lib as L
+
+    class FakeLib:
+        def tgp_comm_load(self, path):
+            return -104 if rank == 1 else 0
+
+        def tgp_comm_unique_id(self, p):
+            return 0
+
+        def tgp_last_error(self):
+            return b"no RCCL here"
+
+        def tgp_comm_init(self, *a):
+            raise AssertionError("tgp_comm_init must not be reached when a rank failed its bootstrap")
+    real = L.load
+    L.load = lambda: FakeLib()
+    try:
+        engine.RcclComm(world, rank, None, timeout_s=20)
+        ret[rank] = "built"
+    except engine.RcclUnavailable as e:
+        ret[rank] = "unavailable: " + str(e)
+    finally:
+        L.load = real
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_bootstrap_fails_on_every_rank_together():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bootstrap_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0].startswith("unavailable") and "another rank" in ret[0], ret[0]
+    assert ret[1].startswith("unavailable") and "this rank" in ret[1], ret[1]
+
+
+def _rendezvous_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from tgp.pytorch_amd import engine
+    import time
+    t0 = time.time()
+    try:
+        if rank == 0:
+            engine._store_rendezvous("tgp_test_rendezvous/late", world, 1.0)     # rank 1 never arrives at this tag
+            ret[rank] = "passed"
+        else:
+            ret[rank] = "absent"
+    except TimeoutError as e:
+        ret[rank] = "timeout after %.1f s: %s" % (time.time() - t0, e)
+    engine._store_rendezvous("tgp_test_rendezvous/both", world, 30.0)            # both arrive: returns
+    torch.distributed.destroy_process_group()
+
+
+def test_store_rendezvous_times_out_instead_of_hanging():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rendezvous_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0].startswith("timeout") and "1 of 2 ranks" in ret[0], ret[0]
+    assert ret[1] == "absent"

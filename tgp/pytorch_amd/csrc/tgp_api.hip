@@ -156,7 +156,7 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   if (const int nw4 = choose_rows4(p, true)) {
     if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, nw4)) return rc;
     p.nslots = fp.nslots;
-  } else if (const int rw = rows_per_wave(p, true); rw != 16) {
+  } else if (const int rw = rows_per_wave(p, fp, true); rw != 16) {
     if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, 0, rw)) return rc;
     p.nslots = fp.nslots;
   }

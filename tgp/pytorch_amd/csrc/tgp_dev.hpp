@@ -728,9 +728,13 @@ __host__ __device__ inline int flow_slots(const int32_t* prog, int nblk) {
   return s;
 }
 
-template <int NB>
+// PN (k_rows<.., RW < 16>: a lane's NB nodes belong to DIFFERENT data rows): the per-row parameters of node u come from
+// rpn[u], an LDS table of the row's TRANSFORMED parameters the caller staged -- entry 2 c = value of column c (softplus
+// already applied where the block restricts it), entry 2 c + 1 = d(value)/d(raw) -- so the sweeps neither wait for global
+// memory nor evaluate a softplus per node.  Supported for SAL blocks (the per-row flows of this package); `rp` is unused.
+template <int NB, bool PN = false>
 __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], const double* __restrict__ rp,
-                                          double* stack, int sstride) {
+                                          double* stack, int sstride, const double* const* rpn = nullptr) {
   int sl = 0;
   FlowBlk nx = flow_blk(F.prog, 0);
   for (int b = 0; b < F.nblk; ++b) {
@@ -748,9 +752,18 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       }
       sl += 1;
     } else if (kind == TGP_FLOW_SAL) {
-      const double a = flow_param(F, rp, poff, pr);
-      double bb = flow_param(F, rp, poff + 1, pr);
-      if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
+      double av[NB], bv[NB];
+      if constexpr (PN) {
+        TGP_EACH(u, NB) {
+          av[u] = pr ? rpn[u][2 * poff] : F.tp[poff];
+          bv[u] = pr ? rpn[u][2 * (poff + 1)] : F.tp[poff + 1];
+        }
+      } else {
+        const double a = flow_param(F, rp, poff, pr);
+        double bb = flow_param(F, rp, poff + 1, pr);
+        if (pr && (flags & TGP_FLAG_RESTRICT)) bb = softplus_d(bb);
+        TGP_EACH(u, NB) { av[u] = a; bv[u] = bb; }
+      }
       const bool addf = flags & TGP_FLAG_ADD_F0;
       // sqrt(f^2+1) and its reciprocal from one v_rsq_f64 + Newton (1/sf is needed anyway); asinh keeps the
       // reference's log(f + sqrt(f^2+1)) form (flow.py:904-905) on the short-chain log.  Stage by stage over the nodes.
@@ -761,13 +774,13 @@ __device__ inline void flow_forward_store(const FlowDev& F, double (&f)[NB], con
       TGP_EACH(u, NB) sf[u] = fma(fma(-sf[u], sf[u], q1[u]), 0.5 * isf[u], sf[u]);
       TGP_EACH(u, NB) uu[u] = f[u] + sf[u];
       log_fast_n<NB>(uu);
-      TGP_EACH(u, NB) e[u] = bb * uu[u] - a;
+      TGP_EACH(u, NB) e[u] = bv[u] * uu[u] - av[u];
       exp_fast_n<NB>(e);
       TGP_EACH(u, NB) ei[u] = e[u];
       rcp_fast_n<NB>(ei);
       TGP_EACH(u, NB) {
         const double ch = 0.5 * (e[u] + ei[u]);
-        double g = 0.5 * (e[u] - ei[u]), gp = bb * ch * isf[u];
+        double g = 0.5 * (e[u] - ei[u]), gp = bv[u] * ch * isf[u];
         if (addf) { g += f[u]; gp += 1.0; }
         stack[((sl + 0) * NB + u) * sstride] = uu[u];
         stack[((sl + 1) * NB + u) * sstride] = ch;
@@ -850,10 +863,14 @@ __device__ __forceinline__ double flow_red(double x) {
   if constexpr (RED == 2) return wave_sum(x);
   else return quad_sum(x);
 }
-template <int NB, int RED = 0>
+// PN (see flow_forward_store): the per-row partials of a SAL block are PER NODE -- each node of a lane belongs to another data
+// row -- and go to the block's own, now dead, stack slots (slot + 0: d/da, slot + 1: d/db of node u) through `gst`, the
+// writable alias of `stack`; the caller gathers them per row afterwards.  accr is unused then.
+template <int NB, int RED = 0, bool PN = false>
 __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], const double* __restrict__ rp,
                                            const double* stack, int sstride, int nslots, double* accq, int qstride,
-                                           bool qlead, double* accr, int rstride) {
+                                           bool qlead, double* accr, int rstride, const double* const* rpn = nullptr,
+                                           double* gst = nullptr) {
   // (accq / accr live in LDS: lds_acc.  Every block reads all its LDS operands -- parameters AND stack slots -- before
   //  the first use: one exposed LDS round trip per block step instead of three or four.)
   int sl = nslots;
@@ -899,6 +916,17 @@ __device__ inline void flow_backward_store(const FlowDev& F, double (&c)[NB], co
         uu[u] = stack[((sl + 0) * NB + u) * sstride];
         ch[u] = stack[((sl + 1) * NB + u) * sstride];
         gp[u] = stack[((sl + 2) * NB + u) * sstride];
+      }
+      if constexpr (PN) {
+        if (pr) {
+          TGP_EACH(u, NB) {
+            const double fbu = rpn[u][2 * (poff + 1) + 1];
+            gst[((sl + 0) * NB + u) * sstride] = -c[u] * ch[u];
+            gst[((sl + 1) * NB + u) * sstride] = c[u] * uu[u] * ch[u] * fbu;
+            c[u] *= gp[u];
+          }
+          continue;
+        }
       }
       double fb = 1.0;
       if (pr) {

@@ -53,7 +53,7 @@ int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* st
 // which row kernel a plan gets: 0 = k_rows (16 rows per wave), else the waves per workgroup of k_rows4 (4 rows per wave)
 int choose_rows4(const Plan& p, bool train);
 // data rows per wave of k_rows for this plan (16, or 10: training with the flow likelihood at Power-like sizes)
-int rows_per_wave(const Plan& p, bool train);
+int rows_per_wave(const Plan& p, const FlowProg& fp, bool train);
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 

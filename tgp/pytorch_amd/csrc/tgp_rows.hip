@@ -29,12 +29,14 @@ int choose_rows4(const Plan& p, bool train) {
   return nw;
 }
 
-// Rows per wave of k_rows: TGP_RW_SMALL (10) for a training launch with the flow likelihood and shared flow parameters whose
+// Rows per wave of k_rows: TGP_RW_SMALL (10) for a training launch with the flow likelihood and whose
 // (row, node) pairs fill the lanes in one trip (10 S <= 64 x 5) at the sizes rows_rw() names, if the LDS plan fits; else 16.
 // TGP_ROWS_RW=16 forces 16 (A/B measurements).
-int rows_per_wave(const Plan& p, bool train) {
+int rows_per_wave(const Plan& p, const FlowProg& fp, bool train) {
   static const int env = [] { const char* e = getenv("TGP_ROWS_RW"); return e ? atoi(e) : 0; }();
-  if (!train || env == 16 || p.lik != TGP_LIK_FLOW || p.RP > 0 || p.nblk < 1) return 16;
+  if (!train || env == 16 || p.lik != TGP_LIK_FLOW || p.nblk < 1) return 16;
+  for (int b = 0; b < fp.nblk; ++b)      // per-row parameters: SAL blocks only (their per-pair partials use the block's own stack slots)
+    if ((fp.blk[4 * b + 3] & TGP_FLAG_PER_ROW) && fp.blk[4 * b] != TGP_FLOW_SAL) return 16;
   if (rows_rw(p.N) != TGP_RW_SMALL || TGP_RW_SMALL * p.S > 64 * TGP_RW_NODES) return 16;
   if (row_lds(p, 1, p.nslots, TGP_RW_SMALL).total * sizeof(double) > 160 * 1024 - 1024) return 16;
   return TGP_RW_SMALL;

@@ -49,7 +49,7 @@ struct RowArgs {
 
 // LDS carve-up (offsets in doubles)
 struct RowLds {
-  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, ti, xs, wn, stack, acc, red, prog, rin, cbuf, total;
+  size_t zs, ils, mv, tile, xt, vbs, mbs, tp, tg, ti, xs, wn, stack, acc, red, prog, rin, cbuf, rpl, total;
 };
 #define TGP_RW_SMALL 10          /* data rows per wave of the k_rows<.., RW = 10> variant (see the kernel) */
 #define TGP_RW_NODES 5           /* its quadrature nodes in flight per lane: 10 rows x 32 nodes = 64 lanes x 5 */
@@ -83,14 +83,15 @@ __host__ __device__ inline RowLds row_lds(const Plan& p, int mode, int nslots, i
     if (L.tile + st > o) take(L.tile + st - o);
     L.stack = L.tile;
     L.acc = take((size_t)(p.P > 0 ? p.P : 1) * 64 + (size_t)p.RP * 256);  // [P][64] quad-reduced + [RP][256] per lane
-    L.rin = L.cbuf = o;
+    L.rin = L.cbuf = L.rpl = o;
     if (rw < 16) {   // the quadrature's (row, node) pairs are dealt over all 64 lanes: per-wave row inputs and pair results
       L.rin = take(4 * 48);
       L.cbuf = take((size_t)4 * 64 * TGP_RW_NODES);
+      L.rpl = take((size_t)4 * 16 * 2 * p.RP);   // per wave and row: (transformed value, d value / d raw) of every per-row column
     }
   } else {
     L.tile = take((size_t)p.MP * 32);  // only the two operand panels (2 x MP x 16)
-    L.xt = L.vbs = L.mbs = L.stack = L.acc = L.rin = L.cbuf = o;
+    L.xt = L.vbs = L.mbs = L.stack = L.acc = L.rin = L.cbuf = L.rpl = o;
   }
   L.total = o;
   return L;
@@ -315,6 +316,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int d = 0; d < DP; ++d) xraw[d] = d < D ? a.X[(size_t)nc * D + d] : 0.0;
   const double y = TRAIN ? a.Y[nc] : 0.0;
+  // (RW < 16 with per-row flow parameters: this lane's columns q, q + 4 of its row, requested with the first loads of the
+  //  kernel -- at the head of the quadrature they cost a memory round trip of their own)
+  double rraw[2] = {0.0, 0.0};
+  if constexpr (RW < 16) {
+    if (a.rowp != nullptr && RP > 0 && RP <= 8) {
+      rraw[0] = q < RP ? a.rowp[(size_t)nc * RP + q] : 0.0;
+      rraw[1] = q + 4 < RP ? a.rowp[(size_t)nc * RP + q + 4] : 0.0;
+    }
+  }
   const double s2 = *(ws + p.hdr + H_S2), eta = *(ws + p.hdr + H_ETA),
                einv = *(ws + p.hdr + H_EINV);
 
@@ -491,20 +501,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       double* rin = sm + L.rin + wave * 48;
       double* cb = sm + L.cbuf + wave * (64 * NB);
       if (q == 0) { rin[nl] = mu; rin[16 + nl] = sq; rin[32 + nl] = y; }
+      double* rpl = sm + L.rpl + wave * (16 * 2 * RP);
+      if (a.rowp != nullptr && RP > 0 && nl < RW) {
+        // this row's per-row flow parameters, transformed ONCE (lane q takes the columns q, q + 4, ...)
+        for (int col = q; col < RP; col += 4) {
+          const double raw = RP <= 8 ? rraw[col >> 2] : a.rowp[(size_t)nc * RP + col];
+          double val = raw, der = 1.0;
+          for (int b = 0; b < p.nblk; ++b) {
+            const int kind = progL[4 * b], poff = progL[4 * b + 2], flags = progL[4 * b + 3];
+            if ((flags & TGP_FLAG_PER_ROW) && (flags & TGP_FLAG_RESTRICT) && col == poff + (kind == TGP_FLOW_AFFINE ? 0 : 1)) {
+              val = softplus_d(raw);
+              der = sigmoid_d(raw);
+            }
+          }
+          rpl[(nl * RP + col) * 2] = val;
+          rpl[(nl * RP + col) * 2 + 1] = der;
+        }
+      }
       double* accq = acc + wave * 16 + nl;
       double* accr = acc + (size_t)P * 64 + tid;
       lds_barrier();  // the stack aliases the operand panels: all waves must be done with GEMM 2 (and rin is visible)
       double xn[NB], wq[NB], f[NB], c[NB], yv[NB];
+      const double* rpn[NB];   // LDS table of each pair's row (ID_TGP; the launcher admits per-row SAL blocks only)
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int pp = lane + 64 * u, row = pp % RW, sn = pp / RW;
-        const bool ok = sn < p.S && bid * RBK + wave * RW + row < N;
+        const int nr = bid * RBK + wave * RW + row;
+        const bool ok = sn < p.S && nr < N;
         xn[u] = xsL[sn < p.S ? sn : 0];
         wq[u] = ok ? wnL[sn < p.S ? sn : 0] : 0.0;
         f[u] = rin[row] + rin[16 + row] * xn[u];
         yv[u] = rin[32 + row];
+        rpn[u] = rpl + row * RP * 2;
       }
-      flow_forward_store<NB>(F, f, nullptr, stack + tid, 256);
+      flow_forward_store<NB, true>(F, f, nullptr, stack + tid, 256, rpn);
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const double r = yv[u] - f[u];
@@ -512,11 +542,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         etap += wq[u] * (-0.5 + 0.5 * einv * r * r);
         c[u] = a.scale * einv * wq[u] * r;
       }
-      flow_backward_store<NB>(F, c, nullptr, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256);
+      flow_backward_store<NB, 0, true>(F, c, nullptr, stack + tid, 256, a.prog.nslots, accq, 64, q == 0, accr, 256, rpn, stack + tid);
 #pragma unroll
       for (int u = 0; u < NB; ++u) cb[lane + 64 * u] = c[u];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (a.g_rowp != nullptr && RP > 0) {
+        // per-row parameter gradients: the pairs of a per-row SAL block left (d/da, d/db) in the block's two first stack
+        // slots; row lane (nl, q) adds the nodes q, q + 4, ... of its row, the quad completes the sum (fixed order)
+        int sl = 0;
+        for (int b = 0; b < p.nblk; ++b) {
+          const int kind = progL[4 * b], K = progL[4 * b + 1], poff = progL[4 * b + 2], flags = progL[4 * b + 3];
+          if (kind == TGP_FLOW_SAL && (flags & TGP_FLAG_PER_ROW)) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              double gsum = 0.0;
+              if (nl < RW) {
+                for (int sn = q; sn < p.S; sn += 4) {
+                  const int pp = sn * RW + nl;
+                  gsum += stack[((sl + jj) * NB + (pp >> 6)) * 256 + wave * 64 + (pp & 63)];
+                }
+              }
+              gsum = quad_sum(gsum);
+              if (q == 0 && valid) a.g_rowp[(size_t)n * RP + poff + jj] = gsum;
+            }
+          }
+          sl += kind == TGP_FLOW_AFFINE ? 1 : (kind == TGP_FLOW_SAL ? 3 : 1 + K);
+        }
+      }
       // row lane (nl, q): the nodes q, q + 4, ... of row nl (pair index node * RW + row)
       double cm = 0.0, cv = 0.0;
       if (nl < RW) {
@@ -726,7 +779,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (bid == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 23] = (double)clock64();
 #endif
   for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
-  if (a.g_rowp != nullptr && q == 0 && valid) {
+  if (RW == 16 && a.g_rowp != nullptr && q == 0 && valid) {
     const double* rbase = acc + (size_t)P * 64;
     for (int jr = 0; jr < RP; ++jr) {
       const double* ap = rbase + (size_t)jr * 256 + wave * 64 + nl;

@@ -1,5 +1,6 @@
 """Per-wave phase timeline of k_rows4 (stamped build, tools/probes/build_stamp.sh): s_memrealtime (100 MHz) at the phase
-boundaries of every wave of workgroup 0 of the training launch.  Usage: python tools/probes/stamp_rows4.py [flow]"""
+boundaries of every wave of workgroup 0 of the training launch, at N = 4306 rows (half of Power: where the library selects
+k_rows4 with 8-wave workgroups).  Usage: python tools/probes/stamp_rows4.py [flow]"""
 import os, sys, torch
 os.environ.setdefault("TGP_ALLOW_STALE_LIB", "1")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -8,12 +9,12 @@ import tgp.pytorch_amd.lib as L
 L.LIB_PATH = os.path.join(ROOT, "tools/probes/stamp/libtgp_hip.so")
 from tgp.pytorch_amd.engine import ElboEngine
 from tgp.pytorch_amd import synthetic
-flows = sys.argv[1:] or ["tanh3x2", "sal2", "none"]
+flows = sys.argv[1:] or ["tanh3x2", "sal2"]
 names = ["stage", "K strip", "gemm1", "gemm2", "mu/v", "flow", "gemm3", "gemm4", "stats", "tail"]
 for flow in flows:
     flow = None if flow == "none" else flow
-    prob = synthetic.synthetic_problem(8611, 4, 100, seed=0, flow=flow, S=32)
-    eng = ElboEngine(prob["X"], prob["Y"], prob["params"], N_total=8611.0, flow_blocks=prob["program"], S=32)
+    prob = synthetic.synthetic_problem(4306, 4, 100, seed=0, flow=flow, S=32)
+    eng = ElboEngine(prob["X"], prob["Y"], prob["params"], N_total=4306.0, flow_blocks=prob["program"], S=32)
     for _ in range(5):
         eng.elbo()
     torch.cuda.synchronize()
@@ -26,7 +27,7 @@ for flow in flows:
     slab_len = rup(ntri * 256 + MP * 16 + MP + 4 + P, 16)
     o = 64 + 16 + 16 + MP * DP + MP + MP + 2 * rup(P + 1, 16) + 9 * mm + MT * 256 + 4 * mm + 4 * slab_len + MT * MP * (DP + 2)
     d = eng.ws[o:o + 256].cpu().tolist()
-    nw = 12
+    nw = 8
     t0 = min(d[w * 20] for w in range(nw))
     print("== %s" % flow)
     for w in range(nw):
