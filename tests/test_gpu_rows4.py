@@ -1,6 +1,6 @@
 """The 4-rows-per-wave row kernel (csrc/tgp_rows4.hpp, v_mfma_f64_4x4x4_4b) against the 16-rows-per-wave one on the same
-inputs: which of the two a training launch gets is decided inside the library (flow likelihood and at most 4 306 rows ->
-k_rows4), `TGP_ROWS4=0` (read once per process) forces k_rows -- so the reference side runs in a child process.  Also:
+inputs: which of the two a training launch gets is decided inside the library (row blocks + passenger blocks at most one per
+CU -> k_rows4), `TGP_ROWS4=0` (read once per process) forces k_rows -- so the reference side runs in a child process.  Also:
 bit reproducibility of k_rows4, and the oracle at a size where k_rows4 runs with 8-wave workgroups."""
 import os
 import subprocess
@@ -15,7 +15,10 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 CASES = [(455, 13, 5, "tanh3x2", 32), (1077, 4, 100, "tanh3x2", 32), (2153, 4, 100, "sal2", 32), (4306, 4, 100, "tanh3x2", 32),
-         (1000, 8, 37, "idsal3", 20), (3001, 16, 128, "sal2", 32), (37, 3, 16, "tanh3x2", 7)]
+         (1000, 8, 37, "idsal3", 20), (3001, 16, 128, "sal2", 32), (37, 3, 16, "tanh3x2", 7),
+         (3984, 4, 100, "tanh3x2", 32),      # the last size with 4-wave workgroups at MT = 7 (249 row blocks + 7 passengers)
+         (7968, 4, 100, "sal2", 32),         # ... with 8-wave workgroups
+         (2153, 4, 100, None, 32), (6000, 8, 64, None, 32)]      # closed-form likelihood (SVGP)
 
 
 def _run(case):
@@ -25,10 +28,10 @@ def _run(case):
     prob = synthetic.synthetic_problem(N, D, M, seed=11, flow=flow, S=S)
     p = {k: v.to(dev) for k, v in prob["params"].items()}
     rowp = prob["rowp"].to(dev) if prob["rowp"] is not None else None
-    fs = ops.FlowSpec(prob["program"], p["theta"].numel(), 0 if rowp is None else rowp.shape[1], dev)
+    fs = ops.FlowSpec(prob["program"], p["theta"].numel(), 0 if rowp is None else rowp.shape[1], dev) if flow else None
     out, g, status, (mu, v) = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
                                             p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], prob["N_total"],
-                                            flow=fs, theta=p["theta"], rowp=rowp, S=S, want_moments=True)
+                                            flow=fs, theta=p.get("theta"), rowp=rowp, S=S, want_moments=True)
     torch.cuda.synchronize()
     assert int(status[0]) == 0 and int(status[1]) == 0
     res = {"out": out.cpu(), "mu": mu.cpu(), "v": v.cpu()}

@@ -73,21 +73,26 @@ enum { C_ELL = 0, C_ETAB = 1, C_SVB = 2, C_PAD = 3, C_THETA = 4 };
 
 inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Waves per workgroup the 4-rows-per-wave row kernel (tgp_rows4.hpp) uses at N rows, 0 = not a candidate.  MEASURED
-// (profiles/r05_rows4_vs_rows16.txt, ROWS phase alone, M = 100, StepTanhL 3 x 2): it wins where the 16-row kernel has fewer
-// waves than the chip has SIMDs to spare -- 43.5-44.5 us against 52.1-52.4 for N <= 2 153 with 4-wave workgroups, 45-47
-// against 52.8 up to 4 306 rows with 8-wave ones (the row shards of a 2-, 4- or 8-GPU Power run, Boston) -- and loses
-// from 8 192 rows on (59.7 / 72.9 us against 53.7 / 54.0 at 8 192 / 8 611 rows: three waves per SIMD leave 168 registers
-// and the flow stack leaves no LDS to prefetch the operand images into), so the full Power batch stays on k_rows.
-inline int rows4_waves(int N) { return N <= 2153 ? 4 : (N <= 4306 ? 8 : 0); }
+// Waves per workgroup the 4-rows-per-wave row kernel (tgp_rows4.hpp) uses at N rows, 0 = not a candidate: the smallest
+// workgroup (4 waves = 16 rows, then 8 waves = 32 rows) for which the row blocks AND the MT passenger blocks of the launch
+// are at most one per CU -- one more and the passengers wait for a row block to retire (measured: 34.3 -> 44.1 us from 3 500 to
+// 4 096 rows with 4-wave workgroups, 42.1 -> 54.1 us from 7 000 to 8 192 rows with 8-wave ones).  MEASURED (ROWS phase alone,
+// M = 100, StepTanhL 3 x 2, profiles/r05_rows4_vs_rows16.txt): 32-34 us with 4-wave workgroups and 40-42 us with 8-wave ones
+// against 52-53 us for the 16-row kernel; with 12-wave workgroups (three waves per SIMD: 168 registers, spills) it loses
+// (67 us at the full Power batch), so beyond 32 (256 - MT) rows the launch stays on k_rows.
+inline int rows4_waves(int N, int MT) {
+  if ((N + 15) / 16 + MT <= 256) return 4;
+  if ((N + 31) / 32 + MT <= 256) return 8;
+  return 0;
+}
 // Data rows per wave k_rows uses at N rows when the launch qualifies (training, flow likelihood, shared flow parameters;
 // tgp_rows.hip rows_per_wave): 10 where 4 x 10-row workgroups still number at most one per CU and 16-row waves would leave
 // SIMDs idle (Power: 862 waves in 216 workgroups instead of 539 in 135), else 16.
-inline int rows_rw(int N) { return (N > 4306 && (N + 39) / 40 <= 256) ? 10 : 16; }
+inline int rows_rw(int N) { return (N > 4000 && (N + 39) / 40 <= 256) ? 10 : 16; }
 // slabs a workspace must hold whichever row kernel runs
 inline int plan_alloc_blocks(int N) {
   int nb = (N + TGP_ROWS_PER_BLOCK - 1) / TGP_ROWS_PER_BLOCK;
-  const int nw = rows4_waves(N);
+  const int nw = rows4_waves(N, 1);      // (MT = 1: the most blocks any model of this N can get)
   if (nw > 0 && (N + 4 * nw - 1) / (4 * nw) > nb) nb = (N + 4 * nw - 1) / (4 * nw);
   const int rw = rows_rw(N);
   if ((N + 4 * rw - 1) / (4 * rw) > nb) nb = (N + 4 * rw - 1) / (4 * rw);

@@ -11,14 +11,14 @@ DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7) DECL(8)
 #undef DECL
 size_t rows4_lds_bytes(const Plan& p, bool train, int nw);   // tgp_rows_inst.hip (needs tgp_rows4.hpp)
 
-// Which row kernel: the 4-rows-per-wave kernel (tgp_rows4.hpp) where it measured faster -- a training launch with the
-// Gauss-Hermite (flow) likelihood on at most 4 306 rows (rows4_waves, tgp_dev.hpp; the closed-form likelihoods have no
-// quadrature to spread and stay on k_rows: 36 us against 34) -- and where its LDS plan fits a CU.  TGP_ROWS4=0 forces the
+// Which row kernel: the 4-rows-per-wave kernel (tgp_rows4.hpp) where it measured faster -- a training launch (any
+// likelihood) whose row blocks and passenger blocks number at most one per CU (rows4_waves, tgp_dev.hpp: up to 32 (256 - MT)
+// rows) -- and where its LDS plan fits a CU.  TGP_ROWS4=0 forces the
 // 16-row kernel, TGP_ROWS4=<4|8> a workgroup size (A/B measurements, tools/probes/rows_kernel_time.py).
 int choose_rows4(const Plan& p, bool train) {
   static const int env = [] { const char* e = getenv("TGP_ROWS4"); return e ? atoi(e) : -1; }();
   if (env == 0 || !train) return 0;
-  int nw = p.lik == TGP_LIK_FLOW ? rows4_waves(p.N) : 0;
+  int nw = rows4_waves(p.N, p.MT);
   if (env == 4 || env == 8) nw = env;
   if (nw == 0) return 0;
   if ((p.N + 4 * nw - 1) / (4 * nw) > plan_alloc_blocks(p.N)) return 0;   // (a forced size the workspace has no slabs for)

@@ -237,15 +237,18 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ LqT = ws + p.LqT;
   auto col_off = [](int t) { return t * MT - t * (t - 1) / 2; };
-  // A wave stages WHOLE tiles (256 threads = one tile per step): the tile index, its (tt, t) and every base address are wave-
-  // uniform (scalar registers), a lane adds three constants of its own -- the first version derived (tt, t) per element in
-  // vector registers and spent more on the index arithmetic of its ten loads than on the K strip.
-  constexpr int TPW = NT / 256, NSTG = (NTRI + TPW - 1) / TPW;   // tiles per step of the workgroup; steps (= staging registers) per image
-  const int tw = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int srr = (tid >> 4) & 15, sc = tid & 15;
+  // Staging in 16-byte loads: 128 threads per tile (row rr, column pair 2 cp), so a wave-instruction covers 8 rows x 128 B and
+  // an image is half the load instructions of the 8-byte version -- what a CU pulls per microsecond is set by its requests in
+  // flight, not by bytes.  The tile index, its (tt, t) and every base address are wave-uniform (scalar registers); a lane adds
+  // constants of its own.  (The transposed diagonal tiles of kind 3 are two 8-byte loads: their pair is 16 doubles apart.)
+  constexpr int TPW = NT / 128, NSTG = (NTRI + TPW - 1) / TPW;   // tiles per step of the workgroup; steps per image
+  const int tw = __builtin_amdgcn_readfirstlane(tid >> 7);
+  const int srr = (tid >> 3) & 15, sc = 2 * (tid & 7);          // row, first column of the pair
   const int s_reg = srr * MP + sc, s_d0 = srr * 16 + sc, s_d3 = sc * 16 + srr;
-  const int s_dst = (sc >> 3) * 128 + (16 * (sc & 3) + srr) * 2 + ((sc >> 2) & 1);
-  auto issue = [&](int kind, double (&st)[NSTG]) {
+  const int s_dst0 = (sc >> 3) * 128 + (16 * (sc & 3) + srr) * 2 + ((sc >> 2) & 1);                   // column sc
+  const int s_dst1 = ((sc + 1) >> 3) * 128 + (16 * ((sc + 1) & 3) + srr) * 2 + (((sc + 1) >> 2) & 1);   // column sc + 1
+  auto ld2 = [](const double* ptr) { return *reinterpret_cast<const d2v*>(ptr); };
+  auto issue = [&](int kind, d2v (&st)[NSTG]) {
     const bool up = kind == 0 || kind == 2;   // tiles (tt >= t, t)
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
@@ -256,27 +259,30 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
         for (int v = 1; v < MT; ++v) t += idx >= (up ? col_off(v) : v * (v + 1) / 2) ? 1 : 0;
         const int tt = up ? t + idx - col_off(t) : idx - t * (t + 1) / 2;
         const int base = 16 * tt * MP + 16 * t;
-        double val;
-        if (kind == 0) val = tt == t ? nD[t * 256 + s_d0] : Lm[base + s_reg];
-        else if (kind == 1) val = LqT[base + s_reg];
-        else if (kind == 2) val = Lq[base + s_reg];
-        else val = tt == t ? nD[t * 256 + s_d3] : LTm[base + s_reg];
+        d2v val;
+        if (kind == 0) val = tt == t ? ld2(nD + t * 256 + s_d0) : ld2(Lm + base + s_reg);
+        else if (kind == 1) val = ld2(LqT + base + s_reg);
+        else if (kind == 2) val = ld2(Lq + base + s_reg);
+        else if (tt == t) { val.x = nD[t * 256 + s_d3]; val.y = nD[t * 256 + s_d3 + 16]; }
+        else val = ld2(LTm + base + s_reg);
         st[u] = val;
       }
     }
   };
-  auto commit = [&](double* im, const double (&st)[NSTG]) {
+  auto commit = [&](double* im, const d2v (&st)[NSTG]) {
 #pragma unroll
     for (int u = 0; u < NSTG; ++u) {
       const int idx = tw + TPW * u;
-      if (idx < NTRI) im[idx * 256 + s_dst] = st[u];
+      if (idx < NTRI) { im[idx * 256 + s_dst0] = st[u].x; im[idx * 256 + s_dst1] = st[u].y; }
     }
   };
   double* imgA = img;
   double* imgB = img + NIMG;
-  double stgA[NSTG], stgB[NSTG];
+  d2v stgA[NSTG], stgB[NSTG];
   issue(0, stgA);
-  issue(1, stgB);
+  issue(1, stgB);         // (both forward images are in flight from the first instruction: a CU pulls a 57 KB image from the other
+                          //  XCDs' L2 in 5-7 us -- its outstanding-miss budget, not bandwidth -- so every image is requested one
+                          //  phase before its commit and lands under the phase in between)
 
   // ---- stage the small shared operands: every load requested before the first LDS store ----
   {
@@ -307,7 +313,6 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
     }
   }
   commit(imgA, stgA);
-  commit(imgB, stgB);
   lds_barrier();
   R4_STAMP(1);
 
@@ -385,7 +390,13 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
     }
   }
   R4_STAMP(3);
-  // ---- B = Lq^T A as outer products: source group t updates B[tt], tt <= t (second image: no barrier in between) ----
+  commit(imgB, stgB);     // (its own buffer: nobody reads it yet; one barrier makes it visible)
+  if constexpr (TRAIN) {  // both backward images: requested now, they land under B = Lq^T A and the quadrature
+    issue(2, stgA);
+    issue(3, stgB);
+  }
+  lds_barrier();
+  // ---- B = Lq^T A as outer products: source group t updates B[tt], tt <= t ----
   TGP_EACH(t, MT) Ba[t] = 0.0;
 #pragma unroll
   for (int t = 0; t < MT; ++t) push_group(imgB, Aa[t], Ba, 0, t + 1, t * (t + 1) / 2);
@@ -464,10 +475,8 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
     R4_STAMP(6);
 
     // ---- Abar = m mubar^T - 2 A vbar + 2 Lq (B vbar) ;  Kbar = L^-T Abar ----
-    issue(2, stgA);         // (requested before the barrier: the waves that finish their quadrature first wait here anyway)
-    issue(3, stgB);
     lds_barrier();          // every wave is done with the flow stack
-    commit(imgA, stgA);
+    commit(imgA, stgA);     // (requested before the quadrature)
     commit(imgB, stgB);
     lds_barrier();
     double Ca[MT];
