@@ -23,13 +23,15 @@
  *   - return value: 0 = launched; <0 = -(index of the offending argument) or TGP_E_*;
  *     numerical failure is reported ASYNCHRONOUSLY through `status` (device int32[8], ZERO before its first use):
  *       status[0] = LAPACK-style info of the Cholesky of K_MM (0 ok, j>0 = pivot j not positive;
- *                   TGP_STATUS_SYNC_TIMEOUT: a workgroup of the prepare launch gave up waiting for a hand-off word --
+ *                   TGP_STATUS_SYNC_TIMEOUT: a workgroup of the prepare or of the M x M backward launch gave up waiting for a hand-off word --
  *                   the hand-off words were not zero, or its producers never became resident; results invalid),
  *       status[1] = 1 if K_MM contained a NaN (the reference raises NanError, dsp/utils.py:241-254),
  *       status[2] = level of the on-device jitter ladder that succeeded (tgp_model.jitter_ladder), status[3] reserved,
  *       status[4..7] = hand-off words between workgroups of ONE launch (M <= 128: the tile blocks of the prepare
  *                   launch count themselves in status[4] once their tile of K_MM is in global memory, status[5] counts
- *                   the blocks that have left; [6], [7] reserved); the library leaves them zero at the end of every
+ *                   the blocks that have left; the M x M backward launch counts its finished column blocks (low 16 bits)
+ *                   and row blocks (high 16 bits) in status[6] and the blocks that have left in status[7]);
+ *                   the library leaves them zero at the end of every
  *                   call, the caller must not touch them while a call is in flight.  A caller built against the
  *                   int32[4] status of ABI versions <= 100 must grow the buffer: check tgp_version() >= 101,
  *     so the host can replay with the reference's jitter ladder (dsp/utils.py:256-269) without a

@@ -1,0 +1,67 @@
+"""In-launch hand-offs (include/tgp_hip.h status[4..7]; csrc/tgp_prep.hpp): the prepare launch and the M x M backward launch pass
+results between their workgroups through counted words with BOUNDED waits.  A wait that runs to its bound costs ~0.9 s and, when
+the giving-up wave is not the one that reports, leaves no trace but the time -- so this test holds the eager path (no Adam in the
+launch), the fused-Adam path and two engines on two streams to a time budget and to zero words afterwards."""
+import os
+import sys
+import time
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(N, D, M, flow, seed, stream=None):
+    from tgp.pytorch_amd import ops, synthetic
+    from tgp.pytorch_amd.engine import ElboEngine
+    prob = synthetic.synthetic_problem(N, D, M, seed=seed, flow=flow, S=32)
+    ops._ws_cache.clear()
+    return ElboEngine(prob["X"], prob["Y"], prob["params"], N_total=float(N), flow_blocks=prob["program"], S=32,
+                      rowp=prob["rowp"], device=torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("flow", ["tanh3x2", "idsal3", None])
+def test_no_hand_off_wait_runs_to_its_bound(flow):
+    eng = _engine(2153, 4, 100, flow, seed=3)
+    eng.elbo()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(20):
+        eng.elbo()                      # eager, gradients only
+    for ph in (1, 2, 4):
+        eng.elbo(ph)
+    if eng.fused_adam:
+        for _ in range(20):
+            eng.step_adam()             # the update inside the backward launch
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    st = eng.status.cpu().tolist()
+    assert st[0] == 0 and st[4:] == [0, 0, 0, 0], st
+    assert dt < 0.5, "43 launches took %.2f s: a hand-off wait ran to its bound" % dt
+
+
+def test_two_engines_on_two_streams():
+    engs, sts = [], []
+    for k in range(2):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            e = _engine(8611, 4, 100, "tanh3x2", seed=k)
+            e.step()
+        engs.append(e)
+        sts.append(st)
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(30):
+        for e, st in zip(engs, sts):
+            with torch.cuda.stream(st):
+                e.step()
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    for e in engs:
+        st = e.status.cpu().tolist()
+        assert st[0] == 0 and st[4:] == [0, 0, 0, 0], st
+    assert dt < 0.5, "2 x 30 concurrent steps took %.2f s" % dt

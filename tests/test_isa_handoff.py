@@ -1,7 +1,8 @@
 """Disassembly check of the in-launch hand-off protocol: on gfx950 hipcc's `__syncthreads()` is a
 bare `s_barrier` -- no `s_waitcnt vmcnt(0)` -- so a hand-off word set behind it could overtake another wave's `sc1`
 stores.  The producers of `tgp_prep.hpp` use `handoff_barrier()` (inline asm: `s_waitcnt vmcnt(0) lgkmcnt(0)`, then
-`s_barrier`); this test reads the ISA of the built `k_prep_a` and holds every publication of SY_TILES to that form.
+`s_barrier`); this test reads the ISA of the built `k_prep_a` and `k_bwd` and holds every publication of a progress
+word (SY_TILES = status[4]; the backward launch's column / row block counts = status[6]) to that form.
 CPU-only: it disassembles the object the Makefile built (skipped when the build directory or llvm-objdump is absent)."""
 import os
 import re
@@ -46,4 +47,18 @@ def test_prepare_launch_publishes_behind_a_store_drain(tmp_path):
         assert wait and bar - wait[-1] <= 2, ("the barrier in front of the SY_TILES add is not preceded by "
                                               "s_waitcnt vmcnt(0): a wave's sc1 stores may still be in flight")
         # nothing that stores to global memory sits between the drain and the publication
+        assert not any("global_store" in l for l in window[wait[-1]:]), "a global store between the drain and the add"
+
+
+def test_backward_launch_publishes_behind_a_store_drain(tmp_path):
+    body = _function(_device_isa(tmp_path), "_ZN3tgp5k_bwdE")
+    # status[6] (byte offset 24): +1 by a finished column block (its Q tiles are out), +0x10000 by a finished row block (PP)
+    pubs = [i for i, l in enumerate(body) if "global_atomic_add " in l and "offset:24" in l]
+    assert len(pubs) >= 2, "k_bwd no longer publishes its progress counts with global atomic adds at status[6]: update this check"
+    for i in pubs:
+        window = [l.split("//")[0] for l in body[max(0, i - 40):i]]
+        bar = max((k for k, l in enumerate(window) if "s_barrier" in l), default=-1)
+        assert bar >= 0, "a progress count is published with no workgroup barrier in front of it"
+        wait = [k for k, l in enumerate(window[:bar]) if "s_waitcnt" in l and "vmcnt(0)" in l]
+        assert wait and bar - wait[-1] <= 2, "the barrier in front of a progress add is not preceded by s_waitcnt vmcnt(0)"
         assert not any("global_store" in l for l in window[wait[-1]:]), "a global store between the drain and the add"

@@ -1,6 +1,6 @@
 // tgp_api.hip -- the extern "C" surface of libtgp_hip.so (declared in include/tgp_hip.h).
 // Argument checking, plan/workspace bookkeeping and the launch sequence of one ELBO step:
-//   M <= 128 : k_prep_a -> k_rows<MT,DP,MODE> -> k_reduce -> k_bwd12 -> k_bwd34 -> k_bwd5   (6 launches, no host sync)
+//   M <= 128 : k_prep_a -> row kernel (k_rows / k_rows4) -> k_reduce -> k_bwd   (4 launches, no host sync)
 //   M  > 128 : the chunked GEMM pipeline of tgp_big.hip (same entry points, chosen by M / kernel)
 #include <cstdarg>
 #include <cstdio>
@@ -166,7 +166,7 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   if (phases & TGP_PHASE_ROWS)
     if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
   if (phases & TGP_PHASE_BACKWARD)
-    if (int rc = launch_backward_mm(p, md, *grads, out, ws, st, adam != nullptr ? &ad : nullptr)) return rc;
+    if (int rc = launch_backward_mm(p, md, *grads, out, ws, status, st, adam != nullptr ? &ad : nullptr)) return rc;
   return 0;
 }
 
@@ -242,7 +242,7 @@ int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
   if (int rc = launch_rows(p, md, fp, X, mu_bar, v_bar, nullptr, nullptr, nullptr, ws, true, st)) return rc;
-  return launch_backward_mm(p, md, g, ws + p.hdr + H_OUT, ws, st);
+  return launch_backward_mm(p, md, g, ws + p.hdr + H_OUT, ws, status, st);
 }
 
 int tgp_kmm_f64(const double* Z, const double* raw_ls, const double* raw_os, int32_t M, int32_t D, double jitter,

@@ -38,8 +38,8 @@ struct AdamDev {
   double lr = 0, b1 = 0, b2 = 0, eps = 0, ln_b1 = 0, ln_b2 = 0, sign = 1;
   int32_t* step_dev = nullptr;
 };
-int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st,
-                       const AdamDev* adam = nullptr);
+int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, int32_t* status,
+                       hipStream_t st, const AdamDev* adam = nullptr);
 int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
                hipStream_t st);
 int launch_knm(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int N, int M, int D,

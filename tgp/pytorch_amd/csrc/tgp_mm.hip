@@ -448,39 +448,53 @@ __device__ __forceinline__ double red_tail(const Plan& p, const double* __restri
   return s;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_bwd12 (grid = 2 MT workgroups of 8 waves: two per column block c -- one forms Lbar(:, c) and Q(:, c), the other the
-//          L_q-gradient tiles of block row c; both need only G(:, c).  With one workgroup per c the 2 MT - c tiles of the
-//          first phase took two rounds of the 8 waves on the critical block c = 0)
-//   Gs    = G(:, c)  (sum of the partials, staged in LDS)
-//   Lbar(:, c) = -tril(w s^T + 2 H' G)(:, c)                      -> LDS
-//   dELBO/dLam(c-rows, :) = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)) -> final gradient (strict upper = 0)
-//   Q(i, c) = [Phi(L^T Lbar) + Phi(L^T Lbar)^T](i, c), i >= c      -> HBM, mirrored
-// ---------------------------------------------------------------------------------------------------
 #define BWD_THREADS 512
 #define TGP_PF2 32 /* >= MP / 4 k-steps */
 
-// PF = number of second-phase L fragments a wave requests early (TGP_PF2: all of them; 0: none).  The early request buys
-// 0.6 us when the kernel has the chip to itself but costs 58 VGPRs (222 instead of 164), and at 2 waves per SIMD a
-// workgroup above 168 VGPRs no longer fits a CU beside two k_mlp_bwd workgroups (2 x 88): under ID_TGP, where the
-// per-row networks' backward runs on the second stream at the same time, the 222-register form waited for whole CUs
-// to drain (26 -> 50 us).  launch_backward_mm picks PF = 0 for models with per-row flow parameters.
-template <int PF>
-__global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp_grads g, double* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* sm = reinterpret_cast<double*>(smem_raw);
+// Adam on element i of the flat buffers (torch.optim.Adam; k_adam_dev's arithmetic, tgp_lik.hip)
+__device__ __forceinline__ void adam_elem(const AdamDev& A, long i, double g, double pi, double mi, double vi, double bc1,
+                                          double bc2s) {
+  const double gi = A.sign * g;
+  const double m1 = A.b1 * mi + (1.0 - A.b1) * gi;
+  const double v1 = A.b2 * vi + (1.0 - A.b2) * gi * gi;
+  A.m[i] = m1;
+  A.v[i] = v1;
+  A.p[i] = pi - (A.lr / bc1) * m1 / (sqrt(v1) / bc2s + A.eps);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_bwd (round 5; rounds 2-4 ran it as three launches k_bwd12 -> k_bwd34 -> k_bwd5): the M x M backward chain as ONE launch of
+// 3 MT + 1 workgroups (8 waves) that hand their results on through global memory inside the launch (the protocol of tgp_prep.hpp: agent-scope stores,
+// every storing wave drains, barrier, one thread moves the word; producers carry the lower block indices):
+//   [0, MT)       column block c : G(:, c) -> LDS, Lbar(:, c) -> LDS, Q(i >= c, c) -> global (mirrored);   Q count += 1
+//   [MT, 2 MT)    column block c : the L_q-gradient tiles of block row c, Adam on those rows of Lam in the same threads
+//   [2 MT, 3 MT)  row block i    : J(:, i) -> LDS and its second-phase J fragments -> registers BEFORE it waits for
+//                                  Q count == MT;  Y(i, :) = (J^T Q)(i, :) -> LDS, Ks = 1/2 Y J, PP partials;   PP count += 1
+//   3 MT          waits for PP count == MT; remaining gradients, scalars, Adam on everything but Lam; the last to leave
+//                 (it waits for the others' exit count, zeroes the words, advances the Adam step counter)
+// Words: status[6] = Q count (low 16 bits) | PP count (high 16 bits), status[7] = workgroups that left.  What the merge
+// buys: two launch boundaries (dispatch + cache write-back / invalidate, 2-3 us each) and every load a consumer can issue
+// before its producer is done (J, K_MM, Zs, optimiser state).
+// ---------------------------------------------------------------------------------------------------
+enum { SB_PROG = 0, SB_LEFT = 1 };
+
+__device__ __forceinline__ void bwd_leave(int32_t* sb) {
+  __syncthreads();
+  if (threadIdx.x == 0) sync_add(sb + SB_LEFT, 1);
+}
+
+// column block c: Lbar(:, c) and Q(:, c) (lam_block = false) or the L_q-gradient tiles of block row c (true)
+__device__ __forceinline__ void bwd_col_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ ws,
+                                             const AdamDev& ad, double* sm, int c, bool lam_block, int32_t* sb) {
   const int MP = p.MP, MT = p.MT, M = p.M;
-  double* Gs = sm;                   // MP x 16
+  double* Gs = sm;                     // MP x 16
   double* LbL = Gs + (size_t)MP * 16;  // MP x 16
   double* svL = LbL + (size_t)MP * 16; // 16
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const bool lam_block = (int)blockIdx.x >= MT;
-  const int c = blockIdx.x % MT, c0 = 16 * c;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int c0 = 16 * c;
   const double* __restrict__ Gp = ws + p.Gp;
   const size_t mm = (size_t)MP * MP;
   {
-    // G(:, c) = sum of the partials: all (<= 4 rows of the loop) x TGP_RSPLIT loads of a thread are requested before the
-    // first add (the rolled loop paid one L2 round trip per trip: its loads depend on nothing but were not hoisted)
     constexpr int NIT = (16 * TGP_MAX_MT * 16 + BWD_THREADS - 1) / BWD_THREADS;
     double gv[NIT][TGP_RSPLIT];
 #pragma unroll
@@ -509,80 +523,85 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
   const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ Lm = ws + p.L;
   const double* __restrict__ w = ws + p.w;
-  // A fragments of this wave's Q tile (second phase, rows of L from its diagonal block down): requested now, so that
-  // they land under the first phase's MFMAs instead of costing a round trip of their own after the second barrier
-  // (requesting them -- and the first phase's -- before the staging loads above was slower: the workgroup is bound by what
-  //  one CU pulls from L2, and the staging loads then queue behind 96 fragment loads per wave)
-  double pq[PF > 0 ? PF : 1];
-  const bool has2 = !lam_block && wave < MT - c;
-  const int i2 = 16 * (c + wave), n2 = has2 ? (MP - i2) / 4 : 0;
-  if constexpr (PF > 0) {
-#pragma unroll
-    for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
-  }
-  // ---- Lbar tiles (i >= c) / Lam-gradient tiles (all j) ----
-  const int t_lo = lam_block ? MT - c : 0, t_hi = lam_block ? (MT - c) + MT : MT - c;
-  for (int t = t_lo + wave; t < t_hi; t += BWD_THREADS / 64) {
-    if (t < MT - c) {
-      const int i0 = 16 * (c + t);
-      d4 acc = {0, 0, 0, 0};
-      acc = tile_mm_f<TGP_GBATCH>([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
-                      [&](int k) { return Gs[(k + q) * 16 + r]; }, 0, MP, acc);
+  if (lam_block) {
+    // X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
+    const bool upd = ad.p != nullptr;
+    const double step = upd ? (double)(ad.step_dev[0] + 1) : 1.0;
+    for (int j = wave; j < MT; j += BWD_THREADS / 64) {
+      const int j0 = 16 * j;
+      // this thread's four elements of the factor and their optimiser state: requested before the product
+      double lamv[4], am[4], av[4];
+      long ei[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const int row = i0 + q + 4 * rr, col = c0 + r;
-        LbL[row * 16 + r] = (col <= row) ? -(w[row] * svL[r] + 2.0 * acc[rr]) : 0.0;
+        const int row = c0 + r, col = j0 + q + 4 * rr;
+        const bool in = row < M && col < M;
+        const size_t e = in ? (size_t)row * M + col : 0;
+        ei[rr] = in ? (long)e : -1;
+        lamv[rr] = md.Lam[e];
+        if (upd) { am[rr] = ad.m[ad.lam_off + e]; av[rr] = ad.v[ad.lam_off + e]; }
       }
-    } else {
-      // X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
-      const int j = t - (MT - c), j0 = 16 * j;
       d4 acc = {0, 0, 0, 0};
       if (j <= c)
         acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lq[(size_t)(k + q) * MP + j0 + r]; },
                         [&](int k) { return Gs[(k + q) * 16 + r]; }, j0, MP, acc);
+      const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
+        if (ei[rr] < 0) continue;
         const int row = c0 + r, col = j0 + q + 4 * rr;  // transposed store
-        if (row < M && col < M) {
-          double x = 0.0;
-          if (col <= row) {
-            const double lam = md.Lam[(size_t)row * M + col];
-            x = 2.0 * acc[rr] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);
-          }
-          g.Lam[(size_t)row * M + col] = x;
-        }
+        double x = 0.0;
+        if (col <= row) x = 2.0 * acc[rr] - md.kl_scale * (col == row ? lamv[rr] - 1.0 / lamv[rr] : lamv[rr]);
+        g.Lam[ei[rr]] = x;
+        if (upd) adam_elem(ad, ad.lam_off + ei[rr], x, ad.p[ad.lam_off + ei[rr]], am[rr], av[rr], bc1, bc2s);
       }
     }
+    return;
   }
-  if (lam_block) return;
+  // A fragments of this wave's Q tile (second phase, rows of L from its diagonal block down): requested now, so that they
+  // land under the first phase's MFMAs instead of costing a round trip of their own after the second barrier (requesting
+  // them before the staging loads above was slower: the workgroup is bound by what one CU pulls from L2)
+  constexpr int PF = TGP_PF2;
+  double pq[PF];
+  const bool has2 = wave < MT - c;
+  const int i2 = 16 * (c + wave), n2 = has2 ? (MP - i2) / 4 : 0;
+#pragma unroll
+  for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
+  // ---- Lbar tiles (i >= c) ----
+  for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
+    const int i0 = 16 * (c + t);
+    d4 acc = {0, 0, 0, 0};
+    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
+                    [&](int k) { return Gs[(k + q) * 16 + r]; }, 0, MP, acc);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = i0 + q + 4 * rr, col = c0 + r;
+      LbL[row * 16 + r] = (col <= row) ? -(w[row] * svL[r] + 2.0 * acc[rr]) : 0.0;
+    }
+  }
   __syncthreads();
   // ---- Q(i, c) = Phi(M1) + Phi(M1)^T with M1 = L^T Lbar ;  (L^T)[i,k] = L[k,i] = 0 for k < i ----
   double* Q = ws + p.Q;
   for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
     const int i = c + t, i0 = 16 * i;
     d4 acc = {0, 0, 0, 0};
-    if constexpr (PF > 0) {
 #pragma unroll
-      for (int s0 = 0; s0 < PF; s0 += 8) {
-        if (s0 < n2) {
-          double o[8];
+    for (int s0 = 0; s0 < PF; s0 += 8) {
+      if (s0 < n2) {
+        double o[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
+        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
-        }
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
       }
-    } else {
-      acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lm[(size_t)(k + q) * MP + i0 + r]; },
-                      [&](int k) { return LbL[(k + q) * 16 + r]; }, i0, MP, acc);
     }
     if (i != c) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int row = i0 + q + 4 * rr, col = c0 + r;
-        Q[(size_t)row * MP + col] = acc[rr];
-        Q[(size_t)col * MP + row] = acc[rr];
+        st_agent(Q + (size_t)row * MP + col, acc[rr]);
+        st_agent(Q + (size_t)col * MP + row, acc[rr]);
       }
     } else {
       d4 tr = {0, 0, 0, 0};  // M1^T tile = Lbar^T L
@@ -591,110 +610,115 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd12(Plan p, tgp_model md, tgp
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int rl = q + 4 * rr;
-        Q[(size_t)(c0 + rl) * MP + c0 + r] = (r <= rl) ? acc[rr] : tr[rr];
+        st_agent(Q + (size_t)(c0 + rl) * MP + c0 + r, (r <= rl) ? acc[rr] : tr[rr]);
       }
     }
   }
+  handoff_barrier();   // every wave's Q stores have landed before the count moves
+  if (tid == 0) sync_add(sb + SB_PROG, 1);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_bwd34 (grid = MT workgroups, one per row block i; 8 waves)
-//   Y(i, :) = (J^T Q)(i, :)                  -> LDS
-//   Ks(i, j) = 1/2 (Y J)(i, j)  = dELL/dK_MM  (never stored)
-//   PP[i][col][d] = sum_{rows in block i} (Ks o K_MM)[row][col] * [Zs[row][d], 1]   (ARD-RBF parameter partials)
-// ---------------------------------------------------------------------------------------------------
-// Adam on element i of the flat buffers (torch.optim.Adam; k_adam_dev's arithmetic, tgp_lik.hip)
-__device__ __forceinline__ void adam_elem(const AdamDev& A, long i, double g, double pi, double mi, double vi, double bc1,
-                                          double bc2s) {
-  const double gi = A.sign * g;
-  const double m1 = A.b1 * mi + (1.0 - A.b1) * gi;
-  const double v1 = A.b2 * vi + (1.0 - A.b2) * gi * gi;
-  A.m[i] = m1;
-  A.v[i] = v1;
-  A.p[i] = pi - (A.lr / bc1) * m1 / (sqrt(v1) / bc2s + A.eps);
-}
-
-__global__ __launch_bounds__(BWD_THREADS) void k_bwd34(Plan p, double* __restrict__ ws, AdamDev ad) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* Yl = reinterpret_cast<double*>(smem_raw);  // MT x 256
+// row block i: Y(i, :) = (J^T Q)(i, :) -> LDS;  Ks(i, j) = 1/2 (Y J)(i, j) = dELL/dK_MM (never stored);
+// PP[i][col][d] = sum_{rows in block i} (Ks o K_MM)[row][col] * [Zs[row][d], 1]   (ARD-RBF parameter partials)
+__device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__ ws, double* sm, int i, int32_t* sb,
+                                             int32_t* __restrict__ status) {
+  static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one Y tile and one Ks tile per wave");
   const int MP = p.MP, MT = p.MT, DP = p.DP, PPW = p.PPW;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  if ((int)blockIdx.x >= MT) {
-    // passenger workgroups (tgp_elbo_step_adam_f64): the Adam update of the q(u) factor, whose gradient the previous
-    // launch (k_bwd12) finished -- 10^4 of the step's ~10.5 k parameters, off every chain, on CUs this launch leaves idle.
-    // The step counter is read here and advanced by the NEXT launch (k_bwd5), after every reader.
-    const double step = (double)(ad.step_dev[0] + 1);
-    const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
-    for (long k = (long)(blockIdx.x - MT) * BWD_THREADS + tid; k < ad.lam_n; k += (long)(gridDim.x - MT) * BWD_THREADS) {
-      const long i = ad.lam_off + k;
-      adam_elem(ad, i, ad.g[i], ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
-    }
-    return;
-  }
-  const int i = blockIdx.x, i0 = 16 * i;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  double* Yl = sm;                               // MT x 256
+  double* zsL = Yl + (size_t)MT * 256;           // 16 x DP
+  double* Ja = zsL + 16 * DP;                    // (MP - i0) x 16: block column i of J from its diagonal tile down
+  const int i0 = 16 * i;
   const double* __restrict__ J = ws + p.J;
   const double* __restrict__ Q = ws + p.Q;
-  // operands of the epilogue (K_MM entries of this wave's second-phase tile, the 16 Zs rows of the block): requested with
-  // the first phase's loads instead of after the second phase's MFMAs (one L2 round trip less on the chain)
-  double* zsL = Yl + (size_t)MT * 256;                       // 16 x DP
+  // ---- everything that does not depend on this launch's Q: requested before the wait ----
   double kmv[4];
+  const int jbw = wave < MT ? wave : 0, j0w = 16 * jbw;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) kmv[rr] = (ws + p.Kmm)[(size_t)(i0 + q + 4 * rr) * MP + j0w + r];
+  if (tid < 16 * DP) zsL[tid] = (ws + p.Zs)[(size_t)i0 * DP + tid];
+  for (int e = tid; e < (MP - i0) * 16; e += BWD_THREADS) Ja[e] = J[(size_t)(i0 + (e >> 4)) * MP + i0 + (e & 15)];
+  const int n1 = wave < MT ? (MP - i0) / 4 : 0, n2 = wave < MT ? (MP - j0w) / 4 : 0;
+  constexpr int PF = TGP_PF2;
+  double jb2[PF];
+#pragma unroll
+  for (int s_ = 0; s_ < PF; ++s_) jb2[s_] = s_ < n2 ? J[(size_t)(j0w + 4 * s_ + q) * MP + j0w + r] : 0.0;   // J[k, j] = 0 for k < j
+  __syncthreads();
   {
-    const int jbw = wave < MT ? wave : 0;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) kmv[rr] = (ws + p.Kmm)[(size_t)(i0 + q + 4 * rr) * MP + 16 * jbw + r];
-    if (tid < 16 * DP) zsL[tid] = (ws + p.Zs)[(size_t)i0 * DP + tid];
+    const int v = sync_wait(sb + SB_PROG, [&](int x) { return (x & 0xffff) >= MT; });
+    if (v == (int)0x80000000 && lane == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
   }
-  for (int kb = wave; kb < MT; kb += BWD_THREADS / 64) {
+  if (wave < MT) {
+    // Y tile (i, kb = wave): all of the wave's Q fragments in one round trip
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return J[(size_t)(k + q) * MP + i0 + r]; },
-                    [&](int k) { return Q[(size_t)(k + q) * MP + 16 * kb + r]; }, i0, MP, acc);
+    double qv[PF];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Yl[kb * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
+    for (int s_ = 0; s_ < PF; ++s_) qv[s_] = s_ < n1 ? ld_agent(Q + (size_t)(i0 + 4 * s_ + q) * MP + 16 * wave + r) : 0.0;
+#pragma unroll
+    for (int s0 = 0; s0 < PF; s0 += 8) {
+      if (s0 < n1) {
+        double o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n1 ? Ja[(4 * (s0 + u) + q) * 16 + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < n1) acc = TGP_MFMA(o[u], qv[s0 + u], acc);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Yl[wave * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
   }
   __syncthreads();
-  const double* __restrict__ Kmm = ws + p.Kmm;
-  const double* __restrict__ Zs = ws + p.Zs;
-  for (int jb = wave; jb < MT; jb += BWD_THREADS / 64) {
-    const int j0 = 16 * jb;
+  if (wave < MT) {
+    const int j0 = j0w;
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q]; },
-                    [&](int k) { return J[(size_t)(k + q) * MP + j0 + r]; }, j0, MP, acc);  // J[k,j] = 0 for k < j
+#pragma unroll
+    for (int s0 = 0; s0 < PF; s0 += 8) {
+      if (s0 < n2) {
+        double o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = j0 + 4 * (s0 + u);
+          o[u] = s0 + u < n2 ? Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < n2) acc = TGP_MFMA(o[u], jb2[s0 + u], acc);
+      }
+    }
     double ep[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) ep[rr] = 0.5 * acc[rr] * kmv[rr];
     double cs = quad_sum((ep[0] + ep[1]) + (ep[2] + ep[3]));
     double* out = ws + p.PP + ((size_t)i * MP + j0 + r) * PPW;
-    if (q == 0) out[DP] = cs;
+    if (q == 0) st_agent(out + DP, cs);
     for (int d = 0; d < DP; ++d) {
       double s = 0.0;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) s += ep[rr] * zsL[(q + 4 * rr) * DP + d];
       s = quad_sum(s);
-      if (q == 0) out[d] = s;
+      if (q == 0) st_agent(out + d, s);
     }
   }
+  handoff_barrier();
+  if (tid == 0) sync_add(sb + SB_PROG, 0x10000);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_bwd5: assemble the remaining gradients + the scalars (single block; everything here is O(M D))
-// ---------------------------------------------------------------------------------------------------
-#define BWD5_ADAM_PER_THREAD 4 /* (n - M^2) / 256 rounded up: 530 at Power; more falls back to a loop */
-__global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g, double* __restrict__ out,
-                                               double* __restrict__ ws, AdamDev ad) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* term = reinterpret_cast<double*>(smem_raw);  // M x (D+1): per-(j,d) lengthscale terms, column D = cs_j + T0_j
+// the remaining gradients + the scalars + Adam on everything but the q(u) factor (everything here is O(M D))
+#define BWDF_ADAM_PER_THREAD 2 /* (n - M^2) / BWD_THREADS rounded up: 530 at Power; more falls back to a loop */
+__device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ out,
+                                               double* __restrict__ ws, const AdamDev& ad, double* term, int32_t* sb,
+                                               int32_t* __restrict__ status, int nb_total) {
+  constexpr int NT = BWD_THREADS;
   const int tid = threadIdx.x;
-  // tgp_elbo_step_adam_f64: this workgroup also applies Adam to everything but the q(u) factor (k_bwd34's passengers
-  // took that).  The optimiser state of a thread's elements is requested NOW, at the top: the loads land under the
-  // gradient assembly below instead of costing a round trip of their own after it.
   const long n_rest = ad.p != nullptr ? ad.n - ad.lam_n : 0;
-  double ap[BWD5_ADAM_PER_THREAD], am[BWD5_ADAM_PER_THREAD], av[BWD5_ADAM_PER_THREAD];
+  double ap[BWDF_ADAM_PER_THREAD], am[BWDF_ADAM_PER_THREAD], av[BWDF_ADAM_PER_THREAD];
   double a_step = 0.0;
   if (ad.p != nullptr) {
     a_step = (double)(ad.step_dev[0] + 1);
 #pragma unroll
-    for (int u = 0; u < BWD5_ADAM_PER_THREAD; ++u) {
-      const long k = tid + 256L * u;
+    for (int u = 0; u < BWDF_ADAM_PER_THREAD; ++u) {
+      const long k = tid + (long)NT * u;
       const long i = k < n_rest ? (k < ad.lam_off ? k : k + ad.lam_n) : 0;
       ap[u] = ad.p[i]; am[u] = ad.m[i]; av[u] = ad.v[i];
     }
@@ -703,17 +727,23 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
   const double* hdr = ws + p.hdr;
   const double s2 = hdr[H_S2];
   const double* Zs = ws + p.Zs;
-  for (int it = tid; it < M * (D + 1); it += 256) {
+  // m, theta: nothing of this launch in them
+  for (int i = tid; i < M; i += NT) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
+  if (g.theta != nullptr)
+    for (int i = tid; i < p.P; i += NT) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
+  {
+    const int v = sync_wait(sb + SB_PROG, [&](int x) { return (x >> 16) >= MT; });
+    if (v == (int)0x80000000 && (tid & 63) == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
+  }
+  for (int it = tid; it < M * (D + 1); it += NT) {
     const int j = it / (D + 1), d = it % (D + 1);
-    // all 26 partials of this item are requested before the first one is used (a loop over the MT row blocks with a
-    // runtime bound pays one L2 round trip per element)
     const int dd = d < D ? d : 0;
     double csv[TGP_MAX_MT], Rv[TGP_MAX_MT];
 #pragma unroll
     for (int ib = 0; ib < TGP_MAX_MT; ++ib) {
       const size_t base = p.PP + ((size_t)(ib < MT ? ib : 0) * MP + j) * PPW;
-      csv[ib] = ws[base + DP];
-      Rv[ib] = ws[base + dd];
+      csv[ib] = ld_agent(ws + base + DP);
+      Rv[ib] = ld_agent(ws + base + dd);
     }
     const double t0 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
     const double t1v = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
@@ -735,13 +765,9 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
       term[it] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
     }
   }
-  // m, theta first: their loads are independent of the reduction below and overlap with it
-  for (int i = tid; i < M; i += 256) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
-  if (g.theta != nullptr)
-    for (int i = tid; i < p.P; i += 256) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
   __syncthreads();
-  // column sums of term[M][D+1]: one wave per column (a single thread per column walked M LDS reads in a chain)
-  for (int d = tid >> 6; d <= D; d += 4) {
+  // column sums of term[M][D+1]: one wave per column
+  for (int d = tid >> 6; d <= D; d += NT / 64) {
     double s = 0.0;
     for (int j = tid & 63; j < M; j += 64) s += term[j * (D + 1) + d];
     s = wave_sum(s);
@@ -760,11 +786,11 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
     }
   }
   if (ad.p != nullptr) {
-    __syncthreads();  // (drains this workgroup's gradient stores: vmcnt(0) + barrier)
+    handoff_barrier();  // this workgroup's gradient stores have landed
     const double bc1 = 1.0 - exp_fast(a_step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(a_step * ad.ln_b2));
 #pragma unroll
-    for (int u = 0; u < BWD5_ADAM_PER_THREAD; ++u) {
-      const long k = tid + 256L * u;
+    for (int u = 0; u < BWDF_ADAM_PER_THREAD; ++u) {
+      const long k = tid + (long)NT * u;
       if (k < n_rest) {
         const long i = k < ad.lam_off ? k : k + ad.lam_n;
         // the gradient was stored by another thread of this workgroup a moment ago: read it past the CU's L1
@@ -772,13 +798,39 @@ __global__ __launch_bounds__(256) void k_bwd5(Plan p, tgp_model md, tgp_grads g,
         adam_elem(ad, i, gi, ap[u], am[u], av[u], bc1, bc2s);
       }
     }
-    for (long k = tid + 256L * BWD5_ADAM_PER_THREAD; k < n_rest; k += 256) {
+    for (long k = tid + (long)NT * BWDF_ADAM_PER_THREAD; k < n_rest; k += NT) {
       const long i = k < ad.lam_off ? k : k + ad.lam_n;
       const double gi = __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       adam_elem(ad, i, gi, ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
     }
-    // every reader of the step counter (this workgroup above, k_bwd34's passengers in the previous launch) is done
-    if (tid == 0) atomicAdd(&ad.step_dev[0], 1);
+  }
+  // the last to leave: every other workgroup of the launch has counted itself out (the Lam blocks have read the Adam step
+  // counter long ago, nobody polls the words any more) -> zero the words for the next launch, advance the counter
+  {
+    const int v = sync_wait(sb + SB_LEFT, [&](int x) { return x >= nb_total - 1; });
+    if (v == (int)0x80000000 && (tid & 63) == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
+  }
+  __syncthreads();   // EVERY wave of this workgroup has seen the count before it is zeroed (a wave still polling would never see it again)
+  if (tid == 0) {
+    sync_st(sb + SB_PROG, 0); sync_st(sb + SB_LEFT, 0);
+    if (ad.p != nullptr) atomicAdd(&ad.step_dev[0], 1);
+  }
+}
+
+__global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_grads g, double* __restrict__ out,
+                                                     double* __restrict__ ws, AdamDev ad, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const int MT = p.MT, b = (int)blockIdx.x;
+  int32_t* sb = status + 6;
+  if (b < 2 * MT) {
+    bwd_col_role(p, md, g, ws, ad, sm, b % MT, b >= MT, sb);
+    bwd_leave(sb);
+  } else if (b < 3 * MT) {
+    bwd_row_role(p, ws, sm, b - 2 * MT, sb, status);
+    bwd_leave(sb);
+  } else {
+    bwd_final_role(p, md, g, out, ws, ad, sm, sb, status, 3 * MT + 1);
   }
 }
 
@@ -1066,20 +1118,15 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
   return 0;
 }
 
-int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, hipStream_t st,
-                       const AdamDev* adam) {
+int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, int32_t* status,
+                       hipStream_t st, const AdamDev* adam) {
   const AdamDev ad = adam != nullptr ? *adam : AdamDev();
-  const int npass = adam != nullptr ? (int)((ad.lam_n + BWD_THREADS - 1) / BWD_THREADS) : 0;
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
-  const size_t lds12 = (size_t)(2 * p.MP * 16 + 16) * sizeof(double);
-  if (md.RP > 0) hipLaunchKernelGGL(k_bwd12<0>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
-  else hipLaunchKernelGGL(k_bwd12<TGP_PF2>, dim3(2 * p.MT), dim3(BWD_THREADS), lds12, st, p, md, g, ws);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd34, dim3(p.MT + (npass < 64 ? npass : 64)), dim3(BWD_THREADS), ((size_t)p.MT * 256 + 16 * p.DP) * sizeof(double), st,
-                     p, ws, ad);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bwd5, dim3(1), dim3(256), (size_t)p.M * (p.D + 1) * sizeof(double), st, p, md, g, out, ws, ad);
+  const size_t lds_col = (size_t)(2 * p.MP * 16 + 16), lds_row = (size_t)p.MT * 256 + 16 * p.DP + (size_t)p.MP * 16,
+               lds_fin = (size_t)p.M * (p.D + 1);
+  const size_t lds = sizeof(double) * (lds_col > lds_row ? (lds_col > lds_fin ? lds_col : lds_fin) : (lds_row > lds_fin ? lds_row : lds_fin));
+  hipLaunchKernelGGL(k_bwd, dim3(3 * p.MT + 1), dim3(BWD_THREADS), lds, st, p, md, g, out, ws, ad, status);
   LAUNCH_CHECK();
   return 0;
 }

@@ -1,5 +1,5 @@
 // tgp_prep.hpp -- the tile and transform roles of the prepare launch (k_prep_a, tgp_mm.hip) as device functions, and the
-// cross-workgroup hand-off primitives that launch uses.
+// cross-workgroup hand-off primitives that launch and the M x M backward launch (k_bwd, tgp_mm.hip) use.
 //
 // Reference: models/sparse_MF_SP.py:316 (K_MM), :344-346 (masked L_q, S = L_q L_q^T), :406-431 (whitened KL); flow
 // parameter restrictions models/flow.py:1075.

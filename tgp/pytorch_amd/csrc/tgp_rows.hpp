@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   if (TRAIN && bid >= p.nblocks) {
     // ---- passenger blocks (one per 16-column block c of J): what only the backward M x M chain needs -- J = L^-1
-    //      (k_bwd34), H'^T = (J^T (S - I))^T (k_bwd12) and w = J^T m -- formed on CUs the row tiles leave idle instead
+    //      (k_bwd's row blocks), H'^T = (J^T (S - I))^T (its column blocks) and w = J^T m -- formed on CUs the row tiles leave idle instead
     //      of on the prepare launch's critical chain.  Column block c of J is the forward substitution with the unit
     //      columns 16c .. 16c+15 as right-hand side, J_cc = Dinv_c, J_ic = -Dinv_i sum_{c<=kb<i} L_i,kb J_kb,c : the same
     //      register chain as the row waves' (a finished tile IS the next product's B operand), every L fragment it

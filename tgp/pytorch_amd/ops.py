@@ -23,7 +23,7 @@ STATUS_SYNC_TIMEOUT = -77   # include/tgp_hip.h TGP_STATUS_SYNC_TIMEOUT: status[
 
 
 class HandoffTimeoutError(RuntimeError):
-    """A workgroup of the prepare launch gave up waiting for a hand-off word (status[0] == TGP_STATUS_SYNC_TIMEOUT):
+    """A workgroup of the prepare or of the M x M backward launch gave up waiting for a hand-off word (status[0] == TGP_STATUS_SYNC_TIMEOUT):
     the status buffer's hand-off words (status[4..7]) were not zero at the call, or the launch's producer workgroups
     never became resident.  The results of that call are invalid; this is NOT a Cholesky failure."""
 
@@ -177,7 +177,7 @@ def raise_for_status(status, retrying=False):
     jitter is needed."""
     info, nan = int(status[0]), int(status[1])
     if info == STATUS_SYNC_TIMEOUT:
-        raise HandoffTimeoutError("a hand-off wait inside the prepare launch expired (status[0] = %d): status[4..7] "
+        raise HandoffTimeoutError("a hand-off wait inside the prepare / backward launch expired (status[0] = %d): status[4..7] "
                                   "must be zero before the first call and untouched while a call is in flight" % info)
     if nan:
         raise NanError("cholesky: K_MM contains NaN")
