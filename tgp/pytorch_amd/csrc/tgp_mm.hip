@@ -4,7 +4,7 @@
 //          J = L^-1, masked L_q, S = L_q L_q^T, H' = J^T (S - I), w = J^T m, KL, flow parameter transforms.
 //          Replaces models/sparse_MF_SP.py:316,330,344-346,406-431 and dsp/utils.py:222-270 (the retry
 //          ladder itself stays on the host, driven by status[]).
-// Backward (k_reduce, k_bwd12, k_bwd34, k_bwd5): slab reduction of the row statistics, then the hand-derived adjoint
+// Backward (k_reduce, then k_bwd: one launch, roles handing on inside it): slab reduction of the row statistics, then the hand-derived adjoint
 //          (restructured -- see DESIGN.md section 3):
 //            Lbar   = -tril(w s^T + 2 H' G)            Lambar = 2 tril(G L_q) - kl (L_q - diag(1/Lam_ii))
 //            Q      = Phi(L^T Lbar) + Phi(.)^T         Kbar_MM = 1/2 J^T Q J
@@ -401,6 +401,9 @@ size_t prep_a_lds_bytes(const Plan& p) {
 // the G tiles are expanded to full symmetric matrices.  Consumers add the partials (fixed order).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws) {
+#ifdef TGP_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[p.dbg + 200 + 16] = (double)__builtin_amdgcn_s_memrealtime();
+#endif
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= p.slab_len) return;
   const int part = blockIdx.y;
@@ -463,140 +466,210 @@ __device__ __forceinline__ void adam_elem(const AdamDev& A, long i, double g, do
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_bwd (round 5; rounds 2-4 ran it as three launches k_bwd12 -> k_bwd34 -> k_bwd5): the M x M backward chain as ONE launch of
-// 3 MT + 1 workgroups (8 waves) that hand their results on through global memory inside the launch (the protocol of tgp_prep.hpp: agent-scope stores,
-// every storing wave drains, barrier, one thread moves the word; producers carry the lower block indices):
-//   [0, MT)       column block c : G(:, c) -> LDS, Lbar(:, c) -> LDS, Q(i >= c, c) -> global (mirrored);   Q count += 1
-//   [MT, 2 MT)    column block c : the L_q-gradient tiles of block row c, Adam on those rows of Lam in the same threads
+// k_bwd (round 5; rounds 2-4 ran it as three launches k_bwd12 -> k_bwd34 -> k_bwd5): the M x M backward chain behind the slab
+// reduction as ONE launch of 3 MT + 1 workgroups (8 waves) that hand their results on through global memory inside the launch
+// (the protocol of tgp_prep.hpp: agent-scope stores, every storing wave drains, barrier, one thread moves the word; producers
+// carry the lower block indices; all 22 workgroups at Power size are resident from the start):
+//   [0, MT)       column block c : G(:, c) -> LDS, Lbar(:, c) -> LDS, Q(i >= c, c) -> global (mirrored);           Q count += 1
+//   [MT, 2 MT)    Lam block c    : the L_q-gradient tiles of block row c, Adam on those rows of Lam in the same threads
 //   [2 MT, 3 MT)  row block i    : J(:, i) -> LDS and its second-phase J fragments -> registers BEFORE it waits for
-//                                  Q count == MT;  Y(i, :) = (J^T Q)(i, :) -> LDS, Ks = 1/2 Y J, PP partials;   PP count += 1
+//                                  Q count == MT;  Y(i, :) = (J^T Q)(i, :) -> LDS, Ks = 1/2 Y J, PP partials;       PP count += 1
 //   3 MT          waits for PP count == MT; remaining gradients, scalars, Adam on everything but Lam; the last to leave
 //                 (it waits for the others' exit count, zeroes the words, advances the Adam step counter)
-// Words: status[6] = Q count (low 16 bits) | PP count (high 16 bits), status[7] = workgroups that left.  What the merge
-// buys: two launch boundaries (dispatch + cache write-back / invalidate, 2-3 us each) and every load a consumer can issue
-// before its producer is done (J, K_MM, Zs, optimiser state).
+// Words: status[6] = Q count (bits 16-23) | PP count (bits 24-31), status[7] = workgroups that left.  What the merge buys: two
+// launch boundaries and every load a consumer can issue before its producer is done (J, K_MM, Zs, optimiser state).
+// The slab reduction stays a launch of its own: as a fourth role (144 producers, the column blocks prefetching H'^T and L
+// under it) it ran 11 us instead of 5.8 -- its 15.5 MB want every CU and full occupancy, not 144 eight-wave workgroups at
+// this kernel's register count, and its hand-off (drain + count + poll + uncached G loads) costs more than the boundary.
 // ---------------------------------------------------------------------------------------------------
 enum { SB_PROG = 0, SB_LEFT = 1 };
+// diagnostic build (-DTGP_STAMPS): thread 0 of ONE block per role stamps the 100 MHz clock (tools/probes/stamp_bwd.py)
+#ifdef TGP_STAMPS
+#define BW_STAMP(on, i) do { if ((on) && threadIdx.x == 0) ws[p.dbg + 200 + (i)] = (double)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BW_STAMP(on, i) do { } while (0)
+#endif
 
 __device__ __forceinline__ void bwd_leave(int32_t* sb) {
   __syncthreads();
   if (threadIdx.x == 0) sync_add(sb + SB_LEFT, 1);
 }
 
-// column block c: Lbar(:, c) and Q(:, c) (lam_block = false) or the L_q-gradient tiles of block row c (true)
-__device__ __forceinline__ void bwd_col_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ ws,
-                                             const AdamDev& ad, double* sm, int c, bool lam_block, int32_t* sb) {
+// Bounded wait of a WORKGROUP for a count of this launch: wave 0 polls, the others wait at the barrier (every polling wave is
+// one more uncached request stream to the same line, and the producers' traffic shares that channel).  A wait that runs to
+// its bound is reported in status[0].
+template <class P>
+__device__ __forceinline__ void bwd_wait(const int32_t* w, P pred, int32_t* __restrict__ status) {
+  if (threadIdx.x < 64) {
+    const int v = sync_wait(w, pred);
+    if (v == (int)0x80000000 && threadIdx.x == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
+  }
+  __syncthreads();
+}
+
+// G(:, c) = sum of k_reduce's partials -> LDS, s(c-block) -> LDS, Lbar block zeroed (both column roles), in two steps so that
+// the caller can put its own operand requests BEHIND these loads and in front of their first use
+// (16-byte loads: two adjacent columns per thread -- what a CU pulls from the Infinity Cache is counted in requests)
+typedef double bwd_d2 __attribute__((ext_vector_type(2)));
+#define BWD_G_NIT ((8 * TGP_MAX_MT * 16 + BWD_THREADS - 1) / BWD_THREADS)
+__device__ __forceinline__ void bwd_g_issue(const Plan& p, const double* __restrict__ ws, int c0,
+                                            bwd_d2 (&gv)[BWD_G_NIT][TGP_RSPLIT], double& sv0) {
+  const int MP = p.MP, tid = threadIdx.x;
+  const double* __restrict__ Gp = ws + p.Gp;
+  const size_t mm = (size_t)MP * MP;
+#pragma unroll
+  for (int u = 0; u < BWD_G_NIT; ++u) {
+    const int i = tid + u * BWD_THREADS;
+    const int ic = i < MP * 8 ? i : 0;
+#pragma unroll
+    for (int part = 0; part < TGP_RSPLIT; ++part)
+      gv[u][part] = *reinterpret_cast<const bwd_d2*>(Gp + part * mm + (size_t)(ic >> 3) * MP + c0 + 2 * (ic & 7));
+  }
+  sv0 = tid < 16 ? red_tail(p, ws, p.slab_S + c0 + tid) : 0.0;
+}
+__device__ __forceinline__ void bwd_g_commit(const Plan& p, double* Gs, double* LbL, double* svL,
+                                             const bwd_d2 (&gv)[BWD_G_NIT][TGP_RSPLIT], double sv0) {
+  const int MP = p.MP, tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < BWD_G_NIT; ++u) {
+    const int i = tid + u * BWD_THREADS;
+    if (i < MP * 8) {
+      bwd_d2 s = {0.0, 0.0};
+#pragma unroll
+      for (int part = 0; part < TGP_RSPLIT; ++part) s += gv[u][part];
+      reinterpret_cast<bwd_d2*>(Gs)[i] = s;
+      reinterpret_cast<bwd_d2*>(LbL)[i] = bwd_d2{0.0, 0.0};
+    }
+  }
+  if (tid < 16) svL[tid] = sv0;
+}
+
+// 16 x 16 tile product on one wave: A fragments `a` (registers, k-step s_ = a[s_]), B fragments from LDS through fb(s_);
+// SWAP: the register fragments are the B operand, the LDS ones the A operand
+template <int PF, bool SWAP = false, class FB>
+__device__ __forceinline__ d4 tile_mm_regA(const double (&a)[PF], FB fb, int n, d4 acc) {
+#pragma unroll
+  for (int s0 = 0; s0 < PF; s0 += 8) {
+    if (s0 < n) {
+      double o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = s0 + u < n ? fb(s0 + u) : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < n) acc = SWAP ? TGP_MFMA(o[u], a[s0 + u], acc) : TGP_MFMA(a[s0 + u], o[u], acc);
+    }
+  }
+  return acc;
+}
+
+// Lam block c: dELBO/dLam(c-rows, :) = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)) (strict upper = 0), and Adam on those rows
+//   X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
+__device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ ws,
+                                             const AdamDev& ad, double* sm, int c) {
+  static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one tile per wave");
   const int MP = p.MP, MT = p.MT, M = p.M;
+  double* Gs = sm;                     // MP x 16
+  double* LbL = Gs + (size_t)MP * 16;  // MP x 16 (unused here)
+  double* svL = LbL + (size_t)MP * 16; // 16
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int c0 = 16 * c;
+  BW_STAMP(c == 0, 4);
+  bwd_d2 gv[BWD_G_NIT][TGP_RSPLIT];
+  double sv0;
+  bwd_g_issue(p, ws, c0, gv, sv0);
+  // ---- behind the G requests: this wave's L_q fragments, its four elements of the factor, their optimiser state ----
+  constexpr int PF = TGP_PF2;
+  const double* __restrict__ Lq = ws + p.Lq;
+  const int j = wave, j0 = 16 * j;
+  const bool has = j < MT;
+  const int n = has && j <= c ? (MP - j0) / 4 : 0;
+  double lq[PF];
+#pragma unroll
+  for (int s_ = 0; s_ < PF; ++s_) lq[s_] = s_ < n ? Lq[(size_t)(j0 + 4 * s_ + q) * MP + j0 + r] : 0.0;
+  const bool upd = ad.p != nullptr;
+  const double step = upd ? (double)(ad.step_dev[0] + 1) : 1.0;
+  double lamv[4], am[4], av[4];
+  long ei[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = c0 + r, col = j0 + q + 4 * rr;
+    const bool in = has && row < M && col < M;
+    const size_t e = in ? (size_t)row * M + col : 0;
+    ei[rr] = in ? (long)e : -1;
+    lamv[rr] = md.Lam[e];
+    if (upd) { am[rr] = ad.m[ad.lam_off + e]; av[rr] = ad.v[ad.lam_off + e]; }
+  }
+  bwd_g_commit(p, Gs, LbL, svL, gv, sv0);
+  __syncthreads();
+  d4 acc = {0, 0, 0, 0};
+  acc = tile_mm_regA<PF>(lq, [&](int s_) { return Gs[(j0 + 4 * s_ + q) * 16 + r]; }, n, acc);
+  const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    if (ei[rr] < 0) continue;
+    const int row = c0 + r, col = j0 + q + 4 * rr;  // transposed store
+    double x = 0.0;
+    if (col <= row) x = 2.0 * acc[rr] - md.kl_scale * (col == row ? lamv[rr] - 1.0 / lamv[rr] : lamv[rr]);
+    g.Lam[ei[rr]] = x;
+    if (upd) adam_elem(ad, ad.lam_off + ei[rr], x, ad.p[ad.lam_off + ei[rr]], am[rr], av[rr], bc1, bc2s);
+  }
+  BW_STAMP(c == 0, 5);
+}
+
+// column block c:  Lbar(:, c) = -tril(w s^T + 2 H' G)(:, c) -> LDS;  Q(i, c) = [Phi(L^T Lbar) + Phi(L^T Lbar)^T](i, c), i >= c
+// -> global, mirrored
+__device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ ws, double* sm, int c, int32_t* sb) {
+  static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one tile per wave");
+  const int MP = p.MP, MT = p.MT;
   double* Gs = sm;                     // MP x 16
   double* LbL = Gs + (size_t)MP * 16;  // MP x 16
   double* svL = LbL + (size_t)MP * 16; // 16
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
   const int c0 = 16 * c;
-  const double* __restrict__ Gp = ws + p.Gp;
-  const size_t mm = (size_t)MP * MP;
-  {
-    constexpr int NIT = (16 * TGP_MAX_MT * 16 + BWD_THREADS - 1) / BWD_THREADS;
-    double gv[NIT][TGP_RSPLIT];
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      const int i = tid + u * BWD_THREADS;
-      const int ic = i < MP * 16 ? i : 0;
-#pragma unroll
-      for (int part = 0; part < TGP_RSPLIT; ++part) gv[u][part] = Gp[part * mm + (size_t)(ic >> 4) * MP + c0 + (ic & 15)];
-    }
-    const double sv0 = tid < 16 ? red_tail(p, ws, p.slab_S + c0 + tid) : 0.0;
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      const int i = tid + u * BWD_THREADS;
-      if (i < MP * 16) {
-        double s = 0.0;
-#pragma unroll
-        for (int part = 0; part < TGP_RSPLIT; ++part) s += gv[u][part];
-        Gs[i] = s;
-        LbL[i] = 0.0;
-      }
-    }
-    if (tid < 16) svL[tid] = sv0;
-  }
-  __syncthreads();
+  BW_STAMP(c == 0, 0);
+  bwd_d2 gv[BWD_G_NIT][TGP_RSPLIT];
+  double sv0;
+  bwd_g_issue(p, ws, c0, gv, sv0);
+  // ---- behind the G requests and in front of their first use: the operands of BOTH products of this wave's tile (rows
+  //      i0 = 16 (c + wave)) -- 100 KB of H'^T and L fragments per workgroup at ~30 GB/s per CU from the Infinity Cache used to
+  //      sit on the chain behind the staging barrier
+  constexpr int PF = TGP_PF2;
   const double* __restrict__ HpT = ws + p.HpT;
-  const double* __restrict__ Lq = ws + p.Lq;
   const double* __restrict__ Lm = ws + p.L;
   const double* __restrict__ w = ws + p.w;
-  if (lam_block) {
-    // X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
-    const bool upd = ad.p != nullptr;
-    const double step = upd ? (double)(ad.step_dev[0] + 1) : 1.0;
-    for (int j = wave; j < MT; j += BWD_THREADS / 64) {
-      const int j0 = 16 * j;
-      // this thread's four elements of the factor and their optimiser state: requested before the product
-      double lamv[4], am[4], av[4];
-      long ei[4];
+  // wave t < MT - c owns tile row c + t; the first wave without a tile (there is one unless MT - c = 8) takes the TRANSPOSED
+  // product of the diagonal tile off wave 0, which would otherwise run two products back to back on the chain
+  const bool has = wave < MT - c;
+  const bool spare = MT - c < BWD_THREADS / 64, tw = spare && wave == MT - c;
+  const int i0 = tw ? c0 : 16 * (c + wave);
+  const int n1 = has ? MP / 4 : 0, n2 = has || tw ? (MP - i0) / 4 : 0;
+  double hp[PF], pq[PF], wv[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int row = c0 + r, col = j0 + q + 4 * rr;
-        const bool in = row < M && col < M;
-        const size_t e = in ? (size_t)row * M + col : 0;
-        ei[rr] = in ? (long)e : -1;
-        lamv[rr] = md.Lam[e];
-        if (upd) { am[rr] = ad.m[ad.lam_off + e]; av[rr] = ad.v[ad.lam_off + e]; }
-      }
-      d4 acc = {0, 0, 0, 0};
-      if (j <= c)
-        acc = tile_mm_f<TGP_GBATCH>([&](int k) { return Lq[(size_t)(k + q) * MP + j0 + r]; },
-                        [&](int k) { return Gs[(k + q) * 16 + r]; }, j0, MP, acc);
-      const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
+  for (int s_ = 0; s_ < PF; ++s_) hp[s_] = s_ < n1 ? HpT[(size_t)(4 * s_ + q) * MP + i0 + r] : 0.0;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        if (ei[rr] < 0) continue;
-        const int row = c0 + r, col = j0 + q + 4 * rr;  // transposed store
-        double x = 0.0;
-        if (col <= row) x = 2.0 * acc[rr] - md.kl_scale * (col == row ? lamv[rr] - 1.0 / lamv[rr] : lamv[rr]);
-        g.Lam[ei[rr]] = x;
-        if (upd) adam_elem(ad, ad.lam_off + ei[rr], x, ad.p[ad.lam_off + ei[rr]], am[rr], av[rr], bc1, bc2s);
-      }
-    }
-    return;
-  }
-  // A fragments of this wave's Q tile (second phase, rows of L from its diagonal block down): requested now, so that they
-  // land under the first phase's MFMAs instead of costing a round trip of their own after the second barrier (requesting
-  // them before the staging loads above was slower: the workgroup is bound by what one CU pulls from L2)
-  constexpr int PF = TGP_PF2;
-  double pq[PF];
-  const bool has2 = wave < MT - c;
-  const int i2 = 16 * (c + wave), n2 = has2 ? (MP - i2) / 4 : 0;
+  for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i0 + 4 * s_ + q) * MP + i0 + r] : 0.0;
 #pragma unroll
-  for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i2 + 4 * s_ + q) * MP + i2 + r] : 0.0;
-  // ---- Lbar tiles (i >= c) ----
-  for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
-    const int i0 = 16 * (c + t);
+  for (int rr = 0; rr < 4; ++rr) wv[rr] = has ? w[i0 + q + 4 * rr] : 0.0;
+  bwd_g_commit(p, Gs, LbL, svL, gv, sv0);
+  __syncthreads();
+  BW_STAMP(c == 0, 1);
+  if (has) {
     d4 acc = {0, 0, 0, 0};
-    acc = tile_mm_f<TGP_GBATCH>([&](int k) { return HpT[(size_t)(k + q) * MP + i0 + r]; },
-                    [&](int k) { return Gs[(k + q) * 16 + r]; }, 0, MP, acc);
+    acc = tile_mm_regA<PF>(hp, [&](int s_) { return Gs[(4 * s_ + q) * 16 + r]; }, n1, acc);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int row = i0 + q + 4 * rr, col = c0 + r;
-      LbL[row * 16 + r] = (col <= row) ? -(w[row] * svL[r] + 2.0 * acc[rr]) : 0.0;
+      LbL[row * 16 + r] = (col <= row) ? -(wv[rr] * svL[r] + 2.0 * acc[rr]) : 0.0;
     }
   }
   __syncthreads();
+  BW_STAMP(c == 0, 2);
   // ---- Q(i, c) = Phi(M1) + Phi(M1)^T with M1 = L^T Lbar ;  (L^T)[i,k] = L[k,i] = 0 for k < i ----
   double* Q = ws + p.Q;
-  for (int t = wave; t < MT - c; t += BWD_THREADS / 64) {
-    const int i = c + t, i0 = 16 * i;
+  if (has) {
     d4 acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int s0 = 0; s0 < PF; s0 += 8) {
-      if (s0 < n2) {
-        double o[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n2 ? LbL[(i0 + 4 * (s0 + u) + q) * 16 + r] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < n2) acc = TGP_MFMA(pq[s0 + u], o[u], acc);
-      }
-    }
-    if (i != c) {
+    acc = tile_mm_regA<PF>(pq, [&](int s_) { return LbL[(i0 + 4 * s_ + q) * 16 + r]; }, n2, acc);
+    if (wave != 0) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int row = i0 + q + 4 * rr, col = c0 + r;
@@ -604,18 +677,27 @@ __device__ __forceinline__ void bwd_col_role(const Plan& p, const tgp_model& md,
         st_agent(Q + (size_t)col * MP + row, acc[rr]);
       }
     } else {
-      d4 tr = {0, 0, 0, 0};  // M1^T tile = Lbar^T L
-      tr = tile_mm_f<TGP_GBATCH>([&](int k) { return LbL[(k + q) * 16 + r]; },
-                     [&](int k) { return Lm[(size_t)(k + q) * MP + c0 + r]; }, c0, MP, tr);
+      d4 tr = {0, 0, 0, 0};  // M1^T tile = Lbar^T L: the same L fragments as the B operand
+      if (!spare) tr = tile_mm_regA<PF, true>(pq, [&](int s_) { return LbL[(c0 + 4 * s_ + q) * 16 + r]; }, n2, tr);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int rl = q + 4 * rr;
-        st_agent(Q + (size_t)(c0 + rl) * MP + c0 + r, (r <= rl) ? acc[rr] : tr[rr]);
+        if (r <= rl) st_agent(Q + (size_t)(c0 + rl) * MP + c0 + r, acc[rr]);
+        else if (!spare) st_agent(Q + (size_t)(c0 + rl) * MP + c0 + r, tr[rr]);
       }
+    }
+  } else if (tw) {
+    d4 tr = {0, 0, 0, 0};
+    tr = tile_mm_regA<PF, true>(pq, [&](int s_) { return LbL[(c0 + 4 * s_ + q) * 16 + r]; }, n2, tr);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int rl = q + 4 * rr;
+      if (r > rl) st_agent(Q + (size_t)(c0 + rl) * MP + c0 + r, tr[rr]);
     }
   }
   handoff_barrier();   // every wave's Q stores have landed before the count moves
-  if (tid == 0) sync_add(sb + SB_PROG, 1);
+  if (tid == 0) sync_add(sb + SB_PROG, 1 << 16);
+  BW_STAMP(c == 0, 3);
 }
 
 // row block i: Y(i, :) = (J^T Q)(i, :) -> LDS;  Ks(i, j) = 1/2 (Y J)(i, j) = dELL/dK_MM (never stored);
@@ -632,6 +714,7 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
   const double* __restrict__ J = ws + p.J;
   const double* __restrict__ Q = ws + p.Q;
   // ---- everything that does not depend on this launch's Q: requested before the wait ----
+  BW_STAMP(i == 0, 6);
   double kmv[4];
   const int jbw = wave < MT ? wave : 0, j0w = 16 * jbw;
 #pragma unroll
@@ -644,10 +727,9 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
 #pragma unroll
   for (int s_ = 0; s_ < PF; ++s_) jb2[s_] = s_ < n2 ? J[(size_t)(j0w + 4 * s_ + q) * MP + j0w + r] : 0.0;   // J[k, j] = 0 for k < j
   __syncthreads();
-  {
-    const int v = sync_wait(sb + SB_PROG, [&](int x) { return (x & 0xffff) >= MT; });
-    if (v == (int)0x80000000 && lane == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
-  }
+  BW_STAMP(i == 0, 7);
+  bwd_wait(sb + SB_PROG, [&](int x) { return ((x >> 16) & 0xff) >= MT; }, status);
+  BW_STAMP(i == 0, 8);
   if (wave < MT) {
     // Y tile (i, kb = wave): all of the wave's Q fragments in one round trip
     d4 acc = {0, 0, 0, 0};
@@ -669,6 +751,7 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
     for (int rr = 0; rr < 4; ++rr) Yl[wave * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
   }
   __syncthreads();
+  BW_STAMP(i == 0, 9);
   if (wave < MT) {
     const int j0 = j0w;
     d4 acc = {0, 0, 0, 0};
@@ -701,7 +784,8 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
     }
   }
   handoff_barrier();
-  if (tid == 0) sync_add(sb + SB_PROG, 0x10000);
+  if (tid == 0) sync_add(sb + SB_PROG, 1 << 24);
+  BW_STAMP(i == 0, 10);
 }
 
 // the remaining gradients + the scalars + Adam on everything but the q(u) factor (everything here is O(M D))
@@ -711,6 +795,7 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
                                                int32_t* __restrict__ status, int nb_total) {
   constexpr int NT = BWD_THREADS;
   const int tid = threadIdx.x;
+  BW_STAMP(true, 11);
   const long n_rest = ad.p != nullptr ? ad.n - ad.lam_n : 0;
   double ap[BWDF_ADAM_PER_THREAD], am[BWDF_ADAM_PER_THREAD], av[BWDF_ADAM_PER_THREAD];
   double a_step = 0.0;
@@ -727,14 +812,11 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   const double* hdr = ws + p.hdr;
   const double s2 = hdr[H_S2];
   const double* Zs = ws + p.Zs;
-  // m, theta: nothing of this launch in them
+  bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= MT; }, status);   // (the row blocks are behind the column blocks, those behind the reduction)
+  BW_STAMP(true, 12);
   for (int i = tid; i < M; i += NT) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
   if (g.theta != nullptr)
     for (int i = tid; i < p.P; i += NT) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
-  {
-    const int v = sync_wait(sb + SB_PROG, [&](int x) { return (x >> 16) >= MT; });
-    if (v == (int)0x80000000 && (tid & 63) == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
-  }
   for (int it = tid; it < M * (D + 1); it += NT) {
     const int j = it / (D + 1), d = it % (D + 1);
     const int dd = d < D ? d : 0;
@@ -766,6 +848,7 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
     }
   }
   __syncthreads();
+  BW_STAMP(true, 13);
   // column sums of term[M][D+1]: one wave per column
   for (int d = tid >> 6; d <= D; d += NT / 64) {
     double s = 0.0;
@@ -804,17 +887,16 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
       adam_elem(ad, i, gi, ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
     }
   }
+  BW_STAMP(true, 14);
   // the last to leave: every other workgroup of the launch has counted itself out (the Lam blocks have read the Adam step
   // counter long ago, nobody polls the words any more) -> zero the words for the next launch, advance the counter
-  {
-    const int v = sync_wait(sb + SB_LEFT, [&](int x) { return x >= nb_total - 1; });
-    if (v == (int)0x80000000 && (tid & 63) == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
-  }
+  bwd_wait(sb + SB_LEFT, [&](int x) { return x >= nb_total - 1; }, status);
   __syncthreads();   // EVERY wave of this workgroup has seen the count before it is zeroed (a wave still polling would never see it again)
   if (tid == 0) {
     sync_st(sb + SB_PROG, 0); sync_st(sb + SB_LEFT, 0);
     if (ad.p != nullptr) atomicAdd(&ad.step_dev[0], 1);
   }
+  BW_STAMP(true, 15);
 }
 
 __global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_grads g, double* __restrict__ out,
@@ -823,8 +905,11 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_g
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int MT = p.MT, b = (int)blockIdx.x;
   int32_t* sb = status + 6;
-  if (b < 2 * MT) {
-    bwd_col_role(p, md, g, ws, ad, sm, b % MT, b >= MT, sb);
+  if (b < MT) {
+    bwd_q_role(p, ws, sm, b, sb);
+    bwd_leave(sb);
+  } else if (b < 2 * MT) {
+    bwd_lam_role(p, md, g, ws, ad, sm, b - MT);
     bwd_leave(sb);
   } else if (b < 3 * MT) {
     bwd_row_role(p, ws, sm, b - 2 * MT, sb, status);
