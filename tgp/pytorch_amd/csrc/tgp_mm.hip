@@ -812,14 +812,45 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   const double* hdr = ws + p.hdr;
   const double s2 = hdr[H_S2];
   const double* Zs = ws + p.Zs;
-  bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= MT; }, status);   // (the row blocks are behind the column blocks, those behind the reduction)
-  BW_STAMP(true, 12);
-  for (int i = tid; i < M; i += NT) g.m[i] = red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i];
+  // The gradients this workgroup forms are mirrored in LDS at their position in the flat buffer, so that the update below reads
+  // them from there instead of draining its stores and fetching them back past the L1 (1.3 us of the chain).  Only when every
+  // element of the flat buffer outside Lam is one of them (the engine's layout); any other caller keeps the global round trip.
+  double* gl = term + (size_t)M * (D + 1);
+  const long nz = (long)M * D, npar = nz + D + 1 + M + 1 + (g.theta != nullptr ? p.P : 0);
+  auto inside = [&](const double* q_, long len) { return q_ >= ad.g && q_ + len <= ad.g + ad.n; };
+  const bool mirror = ad.p != nullptr && npar == n_rest && inside(g.Z, nz) && inside(g.raw_ls, D) && inside(g.raw_os, 1) &&
+                      inside(g.m, M) && inside(g.log_var_noise, 1) && (g.theta == nullptr || inside(g.theta, p.P));
+  auto put = [&](double* base, long i, double val) {
+    base[i] = val;
+    if (mirror) {
+      const long idx = (base + i) - ad.g;
+      gl[idx < ad.lam_off ? idx : idx - ad.lam_n] = val;
+    }
+  };
+  // ---- everything that depends on k_reduce only: before the wait ----
+  for (int i = tid; i < M; i += NT) put(g.m, i, red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i]);
   if (g.theta != nullptr)
-    for (int i = tid; i < p.P; i += NT) g.theta[i] = red_tail(p, ws, p.slab_C + C_THETA + i);
-  for (int it = tid; it < M * (D + 1); it += NT) {
+    for (int i = tid; i < p.P; i += NT) put(g.theta, i, red_tail(p, ws, p.slab_C + C_THETA + i));
+  // (the scalars of the last column sum and the lengthscale factors of the others: wave d, lane 0 uses them)
+  const int dcol = tid >> 6;
+  const double c_svb = red_tail(p, ws, p.slab_C + C_SVB), c_etab = red_tail(p, ws, p.slab_C + C_ETAB),
+               c_ell = red_tail(p, ws, p.slab_C + C_ELL), c_kl = hdr[H_KL], c_sig = hdr[H_SIG_OS];
+  const double c_ils = ws[p.ils + (dcol < D ? dcol : 0)], c_rls = md.raw_ls[dcol < D ? dcol : 0];
+  const int nitems = M * (D + 1);
+  double t0f = 0.0, t1f = 0.0, t2f = 0.0, zjf = 0.0;
+  if (tid < nitems) {       // the first item of this thread (the only one up to 512 items)
+    const int j = tid / (D + 1), d = tid % (D + 1), dd = d < D ? d : 0;
+    t0f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
+    t1f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
+    t2f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
+    zjf = Zs[j * DP + dd];
+  }
+  bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= MT; }, status);
+  BW_STAMP(true, 12);
+  for (int it = tid; it < nitems; it += NT) {
     const int j = it / (D + 1), d = it % (D + 1);
     const int dd = d < D ? d : 0;
+    // all 2 MT partials of this item are requested before the first one is used
     double csv[TGP_MAX_MT], Rv[TGP_MAX_MT];
 #pragma unroll
     for (int ib = 0; ib < TGP_MAX_MT; ++ib) {
@@ -827,9 +858,10 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
       csv[ib] = ld_agent(ws + base + DP);
       Rv[ib] = ld_agent(ws + base + dd);
     }
-    const double t0 = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
-    const double t1v = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
-    const double t2v = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
+    const bool first = it == tid;
+    const double t0 = first ? t0f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
+    const double t1 = first ? t1f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
+    const double t2 = first ? t2f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
     double cs = 0.0;
 #pragma unroll
     for (int ib = 0; ib < TGP_MAX_MT; ++ib) cs += ib < MT ? csv[ib] : 0.0;
@@ -839,10 +871,9 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
       double R = 0.0;
 #pragma unroll
       for (int ib = 0; ib < TGP_MAX_MT; ++ib) R += ib < MT ? Rv[ib] : 0.0;
-      const double t1 = t1v, t2 = t2v;
-      const double zj = Zs[j * DP + d];
+      const double zj = first ? zjf : Zs[j * DP + d];
       // dELL/dzs_jd = [T1 - zs T0] (rows) + 2 sum_i Ep_ij (zs_id - zs_jd) (K_MM, Ep symmetric)
-      g.Z[j * D + d] = (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d];
+      put(g.Z, j * D + d, (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d]);
       // lengthscale: sum_n E (xs - zs)^2 + sum_ij Ep_ij (zs_id - zs_jd)^2 ; second = 2 sum_j zs_jd (zs_jd cs_j - R_jd)
       term[it] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
     }
@@ -856,12 +887,13 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
     s = wave_sum(s);
     if ((tid & 63) != 0) continue;
     if (d < D) {
-      g.raw_ls[d] = s * ws[p.ils + d] * sigmoid_d(md.raw_ls[d]);
+      const bool mine = d == dcol;      // (D > 8: a wave takes more than one column; only its first is prefetched)
+      put(g.raw_ls, d, s * (mine ? c_ils : ws[p.ils + d]) * sigmoid_d(mine ? c_rls : md.raw_ls[d]));
     } else {
-      const double s2b = red_tail(p, ws, p.slab_C + C_SVB) + s / s2;
-      g.raw_os[0] = s2b * hdr[H_SIG_OS];
-      g.log_var_noise[0] = red_tail(p, ws, p.slab_C + C_ETAB);
-      const double ell = red_tail(p, ws, p.slab_C + C_ELL), kl = hdr[H_KL];
+      const double s2b = c_svb + s / s2;
+      put(g.raw_os, 0, s2b * c_sig);
+      put(g.log_var_noise, 0, c_etab);
+      const double ell = c_ell, kl = c_kl;
       out[0] = ell - kl;
       out[1] = ell;
       out[2] = kl;
@@ -869,22 +901,22 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
     }
   }
   if (ad.p != nullptr) {
-    handoff_barrier();  // this workgroup's gradient stores have landed
+    if (mirror) __syncthreads();
+    else handoff_barrier();  // this workgroup's gradient stores have landed
     const double bc1 = 1.0 - exp_fast(a_step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(a_step * ad.ln_b2));
+    // (without the mirror: the gradient was stored by another thread of this workgroup a moment ago -- read it past the CU's L1)
+    auto grad = [&](long k, long i) { return mirror ? gl[k] : __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 #pragma unroll
     for (int u = 0; u < BWDF_ADAM_PER_THREAD; ++u) {
       const long k = tid + (long)NT * u;
       if (k < n_rest) {
         const long i = k < ad.lam_off ? k : k + ad.lam_n;
-        // the gradient was stored by another thread of this workgroup a moment ago: read it past the CU's L1
-        const double gi = __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        adam_elem(ad, i, gi, ap[u], am[u], av[u], bc1, bc2s);
+        adam_elem(ad, i, grad(k, i), ap[u], am[u], av[u], bc1, bc2s);
       }
     }
     for (long k = tid + (long)NT * BWDF_ADAM_PER_THREAD; k < n_rest; k += NT) {
       const long i = k < ad.lam_off ? k : k + ad.lam_n;
-      const double gi = __hip_atomic_load(ad.g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      adam_elem(ad, i, gi, ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
+      adam_elem(ad, i, grad(k, i), ad.p[i], ad.m[i], ad.v[i], bc1, bc2s);
     }
   }
   BW_STAMP(true, 14);
@@ -1209,7 +1241,7 @@ int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, d
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   const size_t lds_col = (size_t)(2 * p.MP * 16 + 16), lds_row = (size_t)p.MT * 256 + 16 * p.DP + (size_t)p.MP * 16,
-               lds_fin = (size_t)p.M * (p.D + 1);
+               lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr ? (size_t)(ad.n - ad.lam_n) : 0);   // + the LDS mirror of the gradients
   const size_t lds = sizeof(double) * (lds_col > lds_row ? (lds_col > lds_fin ? lds_col : lds_fin) : (lds_row > lds_fin ? lds_row : lds_fin));
   hipLaunchKernelGGL(k_bwd, dim3(3 * p.MT + 1), dim3(BWD_THREADS), lds, st, p, md, g, out, ws, ad, status);
   LAUNCH_CHECK();
