@@ -96,8 +96,8 @@ def rows_kernel_flops(w):
 # microseconds) + a stated estimate of the collective, so that the first SCALE record can be judged against a number.
 # Every multi-GPU entry is UNMEASURED ON HARDWARE: no multi-GPU node was available to the builder in any round.
 EXPECT = {
-    # fused path (M <= 128): prepare + [rows(N_rank)] + slab reduction + the M x M adjoint chain; with more than one rank the
-    # Adam update is a launch of its own behind the collective (one rank: folded into the last two backward launches)
+    # fused path (M <= 128): prepare + [rows(N_rank)] + slab reduction + the M x M adjoint launch; with more than one rank the
+    # Adam update is a launch of its own behind the collective (one rank: inside the adjoint launch)
     "tgp_power_tanh3x2": dict(prep=24.8, rows={8611: 49.5, 4306: 50.6, 2153: 48.5, 1077: 47.9}, reduce=5.9, bwd=27.9, adam=4.6),
     "tgp_power_sal2": dict(prep=24.8, rows={8611: 45.0, 4306: 46.0, 2153: 44.0, 1077: 43.5}, reduce=5.9, bwd=27.9, adam=4.6),
     "svgp_power": dict(prep=24.8, rows={8611: 37.5, 4306: 36.5, 2153: 36.0, 1077: 35.8}, reduce=5.0, bwd=27.9, adam=4.6),
@@ -126,7 +126,7 @@ def expected_line(workload, w, world, scaling, n_doubles, measured_ms_1gpu=None)
         nr = -(-w["N"] // world)
         key = min(e["rows"], key=lambda k: abs(k - nr))
         us = e["prep"] + e["rows"][key] + e["reduce"] + e["bwd"] + (e["adam"] if world > 1 else 0.0) + ar
-        basis = ("k_prep_a %.1f + row kernel at %d rows/rank %.1f + k_reduce %.1f + k_bwd12/34/5 %.1f%s + all-reduce of %d doubles "
+        basis = ("k_prep_a %.1f + row kernel at %d rows/rank %.1f + k_reduce %.1f + k_bwd %.1f%s + all-reduce of %d doubles "
                  "%.1f us (ESTIMATE: 8 us + 2 us per ring step + wire time; unmeasured on hardware)"
                  % (e["prep"], nr, e["rows"][key], e["reduce"], e["bwd"], " + k_adam_dev %.1f" % e["adam"] if world > 1 else "",
                     n_doubles, ar))

@@ -18,7 +18,7 @@ cp $O/big_pmc_mfma_util_per_kernel.csv $P/${TAG}_big_pmc_mfma_util_per_kernel.cs
 [ -s $O/pmc_mfma_util_per_kernel.csv ] && cp $O/pmc_mfma_util_per_kernel.csv $P/${TAG}_pmc_mfma_util_per_kernel.csv
 [ -s $O/pmc_hbm_big.csv ] && cp $O/pmc_hbm_big.csv $P/${TAG}_pmc_hbm_big_airline_tanh5x6.csv
 [ -s $O/pmc_hbm_standalone.csv ] && cp $O/pmc_hbm_standalone.csv $P/${TAG}_pmc_hbm_standalone_distance_flow.csv
-for f in hbm_standalone bayes_eval_timing prep_phase_stamps rows_phase_stamps potrf_panel_rate gemm_bench wg_placement big_potrf_window_timeline rows4_phase_stamps rows_kernel_time; do [ -s $O/$f.txt ] && cp $O/$f.txt $P/${TAG}_$f.txt; done
+for f in hbm_standalone bayes_eval_timing prep_phase_stamps rows_phase_stamps potrf_panel_rate gemm_bench wg_placement big_potrf_window_timeline rows4_phase_stamps rows_kernel_time bwd_role_stamps; do [ -s $O/$f.txt ] && cp $O/$f.txt $P/${TAG}_$f.txt; done
 for w in tgp_airline_mb10k tgp_airline_mb10k_rank8 idtgp_power_sal3 tgp_power_tanh3x2; do [ -s $O/timeline_$w.txt ] && cp $O/timeline_$w.txt $P/${TAG}_timeline_$w.txt; done
 cp $O/tests.log $P/${TAG}_gpu_tests.log
 [ -s $O/pmc_valu_standalone.csv ] && cp $O/pmc_valu_standalone.csv $P/${TAG}_pmc_valu_standalone_distance_flow.csv
