@@ -20,7 +20,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define TGP_TILE_LD 66        /* LDS row stride (f64) of the [m][64 rows] transposition tile: conflict-free ds_read_b64 */
 #define TGP_MAX_MT 8
 #ifndef TGP_RSPLIT
-#define TGP_RSPLIT 4 /* the slab reduction is split in this many independent partial sums */
+#define TGP_RSPLIT 4 /* the slab reduction sums every element in this many contiguous shares of the slabs (k_reduce) */
 #endif
 #define TGP_LOG_2PI_REF 1.8378770942368803 /* log(2*float32(pi)): the reference's cg.pi is a float32 tensor (dsp/config.py:71) */
 
@@ -56,8 +56,8 @@ struct Plan {
   size_t hdr, ils, ls, Zs, mpad, w, tp, tg;
   size_t Kmm, L, J, LT, Lq, LqT, S_, HpT, Q;
   size_t nD;     // MT x 256: minus the inverses of the diagonal tiles of L (row-major 16 x 16, zero above the diagonal)
-  size_t Gp;     // TGP_RSPLIT partial sums of G, each expanded to a full symmetric MP x MP matrix
-  size_t redp;   // TGP_RSPLIT partial sums of the slab tail (T, s, scalars); slab layout, G part unused
+  size_t Gp;     // G = sum over the row blocks' slabs, expanded to a full symmetric MP x MP matrix
+  size_t redp;   // the sum of the slab tail (T, s, scalars); slab layout, G part unused
   size_t PP;     // MT x MP x PPW per-row-block partials of (Kbar_MM o K_MM) [Zs, 1]
   int PPW;
   size_t dbg;    // 256 doubles for the diagnostic (-DTGP_STAMPS) builds
@@ -130,8 +130,8 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.Kmm = o; o += mm; p.L = o; o += mm; p.J = o; o += mm; p.LT = o; o += mm;
   p.Lq = o; o += mm; p.LqT = o; o += mm; p.S_ = o; o += mm; p.HpT = o; o += mm; p.Q = o; o += mm;
   p.nD = o; o += (size_t)p.MT * 256;
-  p.Gp = o; o += TGP_RSPLIT * mm;
-  p.redp = o; o += TGP_RSPLIT * p.slab_len;
+  p.Gp = o; o += mm;
+  p.redp = o; o += p.slab_len;
   p.PPW = p.DP + 2;
   p.PP = o; o += (size_t)p.MT * p.MP * p.PPW;
   p.dbg = o; o += 256;

@@ -397,21 +397,26 @@ size_t prep_a_lds_bytes(const Plan& p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_reduce: sum the per-block slabs of the row kernel in TGP_RSPLIT independent partial sums (grid.y);
-// the G tiles are expanded to full symmetric matrices.  Consumers add the partials (fixed order).
+// k_reduce: sum the per-block slabs of the row kernel; the G tiles are expanded to full symmetric matrices.
+// A workgroup owns 256 / TGP_RSPLIT slab elements; thread group `sh` of it sums the sh-th contiguous share of the row
+// blocks' slabs (the partial sums rounds 1-4 wrote to memory: same shares, same order inside a share), the groups are
+// combined through LDS in share order -- bit-identical to the old four-partial form, but the consumers load one value per
+// element instead of four (57 -> 14 KB of G per column block of k_bwd, whose CU pulls ~45 GB/s).
 // ---------------------------------------------------------------------------------------------------
+#define RED_ELEMS (256 / TGP_RSPLIT)
 __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws) {
 #ifdef TGP_STAMPS
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ws[p.dbg + 200 + 16] = (double)__builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws[p.dbg + 200 + 16] = (double)__builtin_amdgcn_s_memrealtime();
 #endif
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= p.slab_len) return;
-  const int part = blockIdx.y;
-  const int b0 = (int)((long long)p.nblocks * part / TGP_RSPLIT), b1 = (int)((long long)p.nblocks * (part + 1) / TGP_RSPLIT);
-  const double* sl = ws + p.slabs + e;
-  // TGP_RBATCH slabs per batch, all requested before the first add, the ragged end inside the batch (clamped index, zero
+  __shared__ double part_s[TGP_RSPLIT][RED_ELEMS];
+  const int tid = threadIdx.x, sh = tid / RED_ELEMS, el = tid % RED_ELEMS;
+  const size_t e = (size_t)blockIdx.x * RED_ELEMS + el;
+  const bool in = e < p.slab_len;
+  const int b0 = (int)((long long)p.nblocks * sh / TGP_RSPLIT), b1 = (int)((long long)p.nblocks * (sh + 1) / TGP_RSPLIT);
+  const double* sl = ws + p.slabs + (in ? e : 0);
+  // RB slabs per batch, all requested before the first add, the ragged end inside the batch (clamped index, zero
   // weight): the slabs come from the Infinity Cache / HBM at 1-2 us per dependent round trip.  Round 5: 28 per batch (was
-  // 16) -- the 10-rows-per-wave row kernel writes 216 slabs at Power size, 54 per partial sum: two round trips, not four.
+  // 16) -- the 10-rows-per-wave row kernel writes 216 slabs at Power size, 54 per share: two round trips, not four.
   constexpr int RB = 28;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int b = b0; b < b1; b += RB) {
@@ -426,30 +431,30 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
 #pragma unroll
     for (int u = 0; u < RB; u += 4) { s0 += t[u]; s1 += t[u + 1]; s2 += t[u + 2]; s3 += t[u + 3]; }
   }
-  const double s = (s0 + s1) + (s2 + s3);
+  part_s[sh][el] = b1 > b0 ? (s0 + s1) + (s2 + s3) : 0.0;
+  __syncthreads();
+  if (sh != 0 || !in) return;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < TGP_RSPLIT; ++k) s += part_s[k][el];      // share order, as the consumers of rounds 1-4 added the partials
   if (e < p.slab_T) {
     // tile t = (ti,tj), ti >= tj, row-major over the lower triangle of tiles
-    const int t = (int)(e >> 8), in = (int)(e & 255), row = in >> 4, col = in & 15;
+    const int t = (int)(e >> 8), in_t = (int)(e & 255), row = in_t >> 4, col = in_t & 15;
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
     // Diagonal tiles: the MFMA result (a_i vbar) . a_j is not bitwise equal to (a_j vbar) . a_i, so keep the lower
     // half and mirror it -- G is then exactly symmetric and no element has two writers (run-to-run reproducible).
     if (ti == tj && col > row) return;
-    double* G = ws + p.Gp + (size_t)part * p.MP * p.MP;
+    double* G = ws + p.Gp;
     G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col] = s;
     G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row] = s;
   } else {
-    ws[p.redp + (size_t)part * p.slab_len + e] = s;
+    ws[p.redp + e] = s;
   }
 }
 
-__device__ __forceinline__ double red_tail(const Plan& p, const double* __restrict__ ws, size_t e) {
-  double s = 0.0;
-#pragma unroll
-  for (int part = 0; part < TGP_RSPLIT; ++part) s += ws[p.redp + (size_t)part * p.slab_len + e];
-  return s;
-}
+__device__ __forceinline__ double red_tail(const Plan& p, const double* __restrict__ ws, size_t e) { return ws[p.redp + e]; }
 
 #define BWD_THREADS 512
 #define TGP_PF2 32 /* >= MP / 4 k-steps */
@@ -507,37 +512,31 @@ __device__ __forceinline__ void bwd_wait(const int32_t* w, P pred, int32_t* __re
   __syncthreads();
 }
 
-// G(:, c) = sum of k_reduce's partials -> LDS, s(c-block) -> LDS, Lbar block zeroed (both column roles), in two steps so that
+// G(:, c) -> LDS, s(c-block) -> LDS, Lbar block zeroed (both column roles), in two steps so that
 // the caller can put its own operand requests BEHIND these loads and in front of their first use
 // (16-byte loads: two adjacent columns per thread -- what a CU pulls from the Infinity Cache is counted in requests)
 typedef double bwd_d2 __attribute__((ext_vector_type(2)));
 #define BWD_G_NIT ((8 * TGP_MAX_MT * 16 + BWD_THREADS - 1) / BWD_THREADS)
 __device__ __forceinline__ void bwd_g_issue(const Plan& p, const double* __restrict__ ws, int c0,
-                                            bwd_d2 (&gv)[BWD_G_NIT][TGP_RSPLIT], double& sv0) {
+                                            bwd_d2 (&gv)[BWD_G_NIT], double& sv0) {
   const int MP = p.MP, tid = threadIdx.x;
   const double* __restrict__ Gp = ws + p.Gp;
-  const size_t mm = (size_t)MP * MP;
 #pragma unroll
   for (int u = 0; u < BWD_G_NIT; ++u) {
     const int i = tid + u * BWD_THREADS;
     const int ic = i < MP * 8 ? i : 0;
-#pragma unroll
-    for (int part = 0; part < TGP_RSPLIT; ++part)
-      gv[u][part] = *reinterpret_cast<const bwd_d2*>(Gp + part * mm + (size_t)(ic >> 3) * MP + c0 + 2 * (ic & 7));
+    gv[u] = *reinterpret_cast<const bwd_d2*>(Gp + (size_t)(ic >> 3) * MP + c0 + 2 * (ic & 7));
   }
   sv0 = tid < 16 ? red_tail(p, ws, p.slab_S + c0 + tid) : 0.0;
 }
 __device__ __forceinline__ void bwd_g_commit(const Plan& p, double* Gs, double* LbL, double* svL,
-                                             const bwd_d2 (&gv)[BWD_G_NIT][TGP_RSPLIT], double sv0) {
+                                             const bwd_d2 (&gv)[BWD_G_NIT], double sv0) {
   const int MP = p.MP, tid = threadIdx.x;
 #pragma unroll
   for (int u = 0; u < BWD_G_NIT; ++u) {
     const int i = tid + u * BWD_THREADS;
     if (i < MP * 8) {
-      bwd_d2 s = {0.0, 0.0};
-#pragma unroll
-      for (int part = 0; part < TGP_RSPLIT; ++part) s += gv[u][part];
-      reinterpret_cast<bwd_d2*>(Gs)[i] = s;
+      reinterpret_cast<bwd_d2*>(Gs)[i] = gv[u];
       reinterpret_cast<bwd_d2*>(LbL)[i] = bwd_d2{0.0, 0.0};
     }
   }
@@ -574,7 +573,7 @@ __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md,
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
   const int c0 = 16 * c;
   BW_STAMP(c == 0, 4);
-  bwd_d2 gv[BWD_G_NIT][TGP_RSPLIT];
+  bwd_d2 gv[BWD_G_NIT];
   double sv0;
   bwd_g_issue(p, ws, c0, gv, sv0);
   // ---- behind the G requests: this wave's L_q fragments, its four elements of the factor, their optimiser state ----
@@ -627,7 +626,7 @@ __device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ w
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
   const int c0 = 16 * c;
   BW_STAMP(c == 0, 0);
-  bwd_d2 gv[BWD_G_NIT][TGP_RSPLIT];
+  bwd_d2 gv[BWD_G_NIT];
   double sv0;
   bwd_g_issue(p, ws, c0, gv, sv0);
   // ---- behind the G requests and in front of their first use: the operands of BOTH products of this wave's tile (rows
@@ -789,6 +788,7 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
 }
 
 // the remaining gradients + the scalars + Adam on everything but the q(u) factor (everything here is O(M D))
+#define BWD_MIRROR_MAX 4096 /* doubles of LDS the final role may spend on the gradient mirror (host sizing and device test agree) */
 #define BWDF_ADAM_PER_THREAD 2 /* (n - M^2) / BWD_THREADS rounded up: 530 at Power; more falls back to a loop */
 __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ out,
                                                double* __restrict__ ws, const AdamDev& ad, double* term, int32_t* sb,
@@ -818,7 +818,7 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   double* gl = term + (size_t)M * (D + 1);
   const long nz = (long)M * D, npar = nz + D + 1 + M + 1 + (g.theta != nullptr ? p.P : 0);
   auto inside = [&](const double* q_, long len) { return q_ >= ad.g && q_ + len <= ad.g + ad.n; };
-  const bool mirror = ad.p != nullptr && npar == n_rest && inside(g.Z, nz) && inside(g.raw_ls, D) && inside(g.raw_os, 1) &&
+  const bool mirror = ad.p != nullptr && npar == n_rest && n_rest <= BWD_MIRROR_MAX && inside(g.Z, nz) && inside(g.raw_ls, D) && inside(g.raw_os, 1) &&
                       inside(g.m, M) && inside(g.log_var_noise, 1) && (g.theta == nullptr || inside(g.theta, p.P));
   auto put = [&](double* base, long i, double val) {
     base[i] = val;
@@ -1238,10 +1238,10 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, int32_t* status,
                        hipStream_t st, const AdamDev* adam) {
   const AdamDev ad = adam != nullptr ? *adam : AdamDev();
-  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + 255) / 256), TGP_RSPLIT), dim3(256), 0, st, p, ws);
+  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + RED_ELEMS - 1) / RED_ELEMS)), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   const size_t lds_col = (size_t)(2 * p.MP * 16 + 16), lds_row = (size_t)p.MT * 256 + 16 * p.DP + (size_t)p.MP * 16,
-               lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr ? (size_t)(ad.n - ad.lam_n) : 0);   // + the LDS mirror of the gradients
+               lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr && ad.n - ad.lam_n <= BWD_MIRROR_MAX ? (size_t)(ad.n - ad.lam_n) : 0);   // + the LDS mirror of the gradients
   const size_t lds = sizeof(double) * (lds_col > lds_row ? (lds_col > lds_fin ? lds_col : lds_fin) : (lds_row > lds_fin ? lds_row : lds_fin));
   hipLaunchKernelGGL(k_bwd, dim3(3 * p.MT + 1), dim3(BWD_THREADS), lds, st, p, md, g, out, ws, ad, status);
   LAUNCH_CHECK();
