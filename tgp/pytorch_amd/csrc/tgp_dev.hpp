@@ -133,7 +133,7 @@ inline int make_plan(Plan& p, int N, int D, int M, int S, int nblk, int P, int R
   p.Gp = o; o += mm;
   p.redp = o; o += p.slab_len;
   p.PPW = p.DP + 2;
-  p.PP = o; o += (size_t)p.MT * p.MP * p.PPW;
+  p.PP = o; o += (size_t)2 * p.MT * p.MP * p.PPW;   // two partials per row block (k_bwd's row role is split in two)
   p.dbg = o; o += 256;
   p.slabs = o; o += (size_t)p.nblocks * p.slab_len;
   p.total = o;

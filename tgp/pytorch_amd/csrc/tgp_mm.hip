@@ -472,14 +472,15 @@ __device__ __forceinline__ void adam_elem(const AdamDev& A, long i, double g, do
 
 // ---------------------------------------------------------------------------------------------------
 // k_bwd (round 5; rounds 2-4 ran it as three launches k_bwd12 -> k_bwd34 -> k_bwd5): the M x M backward chain behind the slab
-// reduction as ONE launch of 3 MT + 1 workgroups (8 waves) that hand their results on through global memory inside the launch
+// reduction as ONE launch of 4 MT + 1 workgroups (8 waves) that hand their results on through global memory inside the launch
 // (the protocol of tgp_prep.hpp: agent-scope stores, every storing wave drains, barrier, one thread moves the word; producers
-// carry the lower block indices; all 22 workgroups at Power size are resident from the start):
+// carry the lower block indices; all 29 workgroups at Power size are resident from the start):
 //   [0, MT)       column block c : G(:, c) -> LDS, Lbar(:, c) -> LDS, Q(i >= c, c) -> global (mirrored);           Q count += 1
 //   [MT, 2 MT)    Lam block c    : the L_q-gradient tiles of block row c, Adam on those rows of Lam in the same threads
-//   [2 MT, 3 MT)  row block i    : J(:, i) -> LDS and its second-phase J fragments -> registers BEFORE it waits for
-//                                  Q count == MT;  Y(i, :) = (J^T Q)(i, :) -> LDS, Ks = 1/2 Y J, PP partials;       PP count += 1
-//   3 MT          waits for PP count == MT; remaining gradients, scalars, Adam on everything but Lam; the last to leave
+//   [2 MT, 4 MT)  row block i, half h : J(:, i) -> LDS and its second-phase J fragments -> registers BEFORE it waits for
+//                                  Q count == MT;  its half of the column tiles of Y(i, :) = (J^T Q)(i, :) -> LDS, the part of
+//                                  Ks = 1/2 Y J that contracts over those columns, PP partials;                    PP count += 1
+//   4 MT          waits for PP count == 2 MT; remaining gradients, scalars, Adam on everything but Lam; the last to leave
 //                 (it waits for the others' exit count, zeroes the words, advances the Adam step counter)
 // Words: status[6] = Q count (bits 16-23) | PP count (bits 24-31), status[7] = workgroups that left.  What the merge buys: two
 // launch boundaries and every load a consumer can issue before its producer is done (J, K_MM, Zs, optimiser state).
@@ -701,90 +702,74 @@ __device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ w
 
 // row block i: Y(i, :) = (J^T Q)(i, :) -> LDS;  Ks(i, j) = 1/2 (Y J)(i, j) = dELL/dK_MM (never stored);
 // PP[i][col][d] = sum_{rows in block i} (Ks o K_MM)[row][col] * [Zs[row][d], 1]   (ARD-RBF parameter partials)
-__device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__ ws, double* sm, int i, int32_t* sb,
+__device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__ ws, double* sm, int i, int h, int32_t* sb,
                                              int32_t* __restrict__ status) {
   static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one Y tile and one Ks tile per wave");
   const int MP = p.MP, MT = p.MT, DP = p.DP, PPW = p.PPW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-  double* Yl = sm;                               // MT x 256
+  // Two workgroups per row block (h = 0, 1): each forms HALF of the column tiles of Y(i, :) -- half of the 100 KB of Q that
+  // row block 0 pulls at ~45 GB/s per CU -- and contracts the second product over exactly those columns; the two partial
+  // results are two partials more for the final block's sum.
+  const int KH = (MT + 1) / 2, kb0 = h ? KH : 0, kb1 = h ? MT : KH, nk = kb1 - kb0;
+  double* Yl = sm;                               // nk x 256 (<= MT x 256 reserved)
   double* zsL = Yl + (size_t)MT * 256;           // 16 x DP
   double* Ja = zsL + 16 * DP;                    // (MP - i0) x 16: block column i of J from its diagonal tile down
   const int i0 = 16 * i;
   const double* __restrict__ J = ws + p.J;
   const double* __restrict__ Q = ws + p.Q;
   // ---- everything that does not depend on this launch's Q: requested before the wait ----
-  BW_STAMP(i == 0, 6);
+  BW_STAMP(i == 0 && h == 0, 6);
   double kmv[4];
   const int jbw = wave < MT ? wave : 0, j0w = 16 * jbw;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) kmv[rr] = (ws + p.Kmm)[(size_t)(i0 + q + 4 * rr) * MP + j0w + r];
   if (tid < 16 * DP) zsL[tid] = (ws + p.Zs)[(size_t)i0 * DP + tid];
   for (int e = tid; e < (MP - i0) * 16; e += BWD_THREADS) Ja[e] = J[(size_t)(i0 + (e >> 4)) * MP + i0 + (e & 15)];
-  const int n1 = wave < MT ? (MP - i0) / 4 : 0, n2 = wave < MT ? (MP - j0w) / 4 : 0;
-  constexpr int PF = TGP_PF2;
-  double jb2[PF];
+  // second product of wave j: k over the rows of this half's column tiles at or below tile j (J[k, j] = 0 for k < j)
+  const int ks0 = 16 * (jbw > kb0 ? jbw : kb0), ks1 = 16 * kb1;
+  const int n1 = wave < nk ? (MP - i0) / 4 : 0, n2 = wave < MT && ks1 > ks0 ? (ks1 - ks0) / 4 : 0;
+  constexpr int PF = TGP_PF2, PFH = 2 * TGP_MAX_MT;      // k-steps of a full column / of half of the tile rows
+  double jb2[PFH];
 #pragma unroll
-  for (int s_ = 0; s_ < PF; ++s_) jb2[s_] = s_ < n2 ? J[(size_t)(j0w + 4 * s_ + q) * MP + j0w + r] : 0.0;   // J[k, j] = 0 for k < j
+  for (int s_ = 0; s_ < PFH; ++s_) jb2[s_] = s_ < n2 ? J[(size_t)(ks0 + 4 * s_ + q) * MP + j0w + r] : 0.0;
   __syncthreads();
-  BW_STAMP(i == 0, 7);
+  BW_STAMP(i == 0 && h == 0, 7);
   bwd_wait(sb + SB_PROG, [&](int x) { return ((x >> 16) & 0xff) >= MT; }, status);
-  BW_STAMP(i == 0, 8);
-  if (wave < MT) {
-    // Y tile (i, kb = wave): all of the wave's Q fragments in one round trip
+  BW_STAMP(i == 0 && h == 0, 8);
+  if (wave < nk) {
+    // Y tile (i, kb = kb0 + wave): all of the wave's Q fragments in one round trip
     d4 acc = {0, 0, 0, 0};
     double qv[PF];
 #pragma unroll
-    for (int s_ = 0; s_ < PF; ++s_) qv[s_] = s_ < n1 ? ld_agent(Q + (size_t)(i0 + 4 * s_ + q) * MP + 16 * wave + r) : 0.0;
-#pragma unroll
-    for (int s0 = 0; s0 < PF; s0 += 8) {
-      if (s0 < n1) {
-        double o[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) o[u] = s0 + u < n1 ? Ja[(4 * (s0 + u) + q) * 16 + r] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < n1) acc = TGP_MFMA(o[u], qv[s0 + u], acc);
-      }
-    }
+    for (int s_ = 0; s_ < PF; ++s_) qv[s_] = s_ < n1 ? ld_agent(Q + (size_t)(i0 + 4 * s_ + q) * MP + 16 * (kb0 + wave) + r) : 0.0;
+    acc = tile_mm_regA<PF, true>(qv, [&](int s_) { return Ja[(4 * s_ + q) * 16 + r]; }, n1, acc);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Yl[wave * 256 + (q + 4 * rr) * 16 + r] = acc[rr];
   }
   __syncthreads();
-  BW_STAMP(i == 0, 9);
+  BW_STAMP(i == 0 && h == 0, 9);
   if (wave < MT) {
-    const int j0 = j0w;
     d4 acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int s0 = 0; s0 < PF; s0 += 8) {
-      if (s0 < n2) {
-        double o[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int k = j0 + 4 * (s0 + u);
-          o[u] = s0 + u < n2 ? Yl[(k >> 4) * 256 + r * 16 + (k & 15) + q] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < n2) acc = TGP_MFMA(o[u], jb2[s0 + u], acc);
-      }
-    }
+    acc = tile_mm_regA<PFH, true>(jb2, [&](int s_) { const int k = ks0 + 4 * s_; return Yl[((k >> 4) - kb0) * 256 + r * 16 + (k & 15) + q]; }, n2, acc);
     double ep[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) ep[rr] = 0.5 * acc[rr] * kmv[rr];
     double cs = quad_sum((ep[0] + ep[1]) + (ep[2] + ep[3]));
-    double* out = ws + p.PP + ((size_t)i * MP + j0 + r) * PPW;
-    if (q == 0) st_agent(out + DP, cs);
+    // PP[part = 2 i + h][c][col]: c < DP the Zs-weighted sums, c = DP the plain column sum -- columns contiguous, so that the
+    // 16 lanes of a store and the 64 lanes of the final block's loads touch whole lines
+    double* out = ws + p.PP + (size_t)(2 * i + h) * PPW * MP + j0w + r;
+    if (q == 0) st_agent(out + (size_t)DP * MP, cs);
     for (int d = 0; d < DP; ++d) {
       double s = 0.0;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) s += ep[rr] * zsL[(q + 4 * rr) * DP + d];
       s = quad_sum(s);
-      if (q == 0) st_agent(out + d, s);
+      if (q == 0) st_agent(out + (size_t)d * MP, s);
     }
   }
   handoff_barrier();
   if (tid == 0) sync_add(sb + SB_PROG, 1 << 24);
-  BW_STAMP(i == 0, 10);
+  BW_STAMP(i == 0 && h == 0, 10);
 }
 
 // the remaining gradients + the scalars + Adam on everything but the q(u) factor (everything here is O(M D))
@@ -836,46 +821,47 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   const double c_svb = red_tail(p, ws, p.slab_C + C_SVB), c_etab = red_tail(p, ws, p.slab_C + C_ETAB),
                c_ell = red_tail(p, ws, p.slab_C + C_ELL), c_kl = hdr[H_KL], c_sig = hdr[H_SIG_OS];
   const double c_ils = ws[p.ils + (dcol < D ? dcol : 0)], c_rls = md.raw_ls[dcol < D ? dcol : 0];
+  // item it = d' M + j: column j of the plain sums (d' = 0 -> d = D: they come first, the others need their result) or of the
+  // Zs-weighted sums (d = d' - 1)
   const int nitems = M * (D + 1);
   double t0f = 0.0, t1f = 0.0, t2f = 0.0, zjf = 0.0;
   if (tid < nitems) {       // the first item of this thread (the only one up to 512 items)
-    const int j = tid / (D + 1), d = tid % (D + 1), dd = d < D ? d : 0;
+    const int j = tid % M, d = tid / M == 0 ? D : tid / M - 1, dd = d < D ? d : 0;
     t0f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
     t1f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
     t2f = red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
     zjf = Zs[j * DP + dd];
   }
-  bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= MT; }, status);
+  bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= 2 * MT; }, status);
   BW_STAMP(true, 12);
-  for (int it = tid; it < nitems; it += NT) {
-    const int j = it / (D + 1), d = it % (D + 1);
-    const int dd = d < D ? d : 0;
-    // all 2 MT partials of this item are requested before the first one is used
-    double csv[TGP_MAX_MT], Rv[TGP_MAX_MT];
+  double* csL = gl + (mirror ? n_rest : 0);      // M: the plain column sums cs_j, formed by the d = D items for the others
+  for (int base = 0; base < nitems; base += NT) {
+    const int it = base + tid;
+    const bool act = it < nitems;
+    const int j = act ? it % M : 0, d = act ? (it / M == 0 ? D : it / M - 1) : 0;
+    // the 4 MT partials of this item (two per row block), requested before the first one is used: row c = d of the partial
+    // sums (c = DP: the plain sums) -- ONE row per item; cs_j reaches the d < D items through LDS, not through 4 MT more loads
+    double pv[2 * TGP_MAX_MT];
 #pragma unroll
-    for (int ib = 0; ib < TGP_MAX_MT; ++ib) {
-      const size_t base = p.PP + ((size_t)(ib < MT ? ib : 0) * MP + j) * PPW;
-      csv[ib] = ld_agent(ws + base + DP);
-      Rv[ib] = ld_agent(ws + base + dd);
-    }
-    const bool first = it == tid;
+    for (int ib = 0; ib < 2 * TGP_MAX_MT; ++ib)
+      pv[ib] = ld_agent(ws + p.PP + ((size_t)(ib < 2 * MT ? ib : 0) * PPW + (d < D ? d : DP)) * MP + j);
+    const bool first = base == 0;
+    const int dd = d < D ? d : 0;
     const double t0 = first ? t0f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + 2 * DP);
     const double t1 = first ? t1f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + dd);
     const double t2 = first ? t2f : red_tail(p, ws, p.slab_T + (size_t)j * CT16 + DP + dd);
-    double cs = 0.0;
+    double sv = 0.0;
 #pragma unroll
-    for (int ib = 0; ib < TGP_MAX_MT; ++ib) cs += ib < MT ? csv[ib] : 0.0;
-    if (d == D) {
-      term[it] = cs + t0;
-    } else {
-      double R = 0.0;
-#pragma unroll
-      for (int ib = 0; ib < TGP_MAX_MT; ++ib) R += ib < MT ? Rv[ib] : 0.0;
+    for (int ib = 0; ib < 2 * TGP_MAX_MT; ++ib) sv += ib < 2 * MT ? pv[ib] : 0.0;
+    if (act && d == D) { csL[j] = sv; term[d * M + j] = sv + t0; }
+    __syncthreads();
+    if (act && d < D) {
+      const double cs = csL[j], R = sv;
       const double zj = first ? zjf : Zs[j * DP + d];
       // dELL/dzs_jd = [T1 - zs T0] (rows) + 2 sum_i Ep_ij (zs_id - zs_jd) (K_MM, Ep symmetric)
       put(g.Z, j * D + d, (t1 - zj * t0 + 2.0 * (R - zj * cs)) * ws[p.ils + d]);
       // lengthscale: sum_n E (xs - zs)^2 + sum_ij Ep_ij (zs_id - zs_jd)^2 ; second = 2 sum_j zs_jd (zs_jd cs_j - R_jd)
-      term[it] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
+      term[d * M + j] = (t2 - 2.0 * zj * t1 + zj * zj * t0) + 2.0 * zj * (zj * cs - R);
     }
   }
   __syncthreads();
@@ -883,7 +869,7 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   // column sums of term[M][D+1]: one wave per column
   for (int d = tid >> 6; d <= D; d += NT / 64) {
     double s = 0.0;
-    for (int j = tid & 63; j < M; j += 64) s += term[j * (D + 1) + d];
+    for (int j = tid & 63; j < M; j += 64) s += term[d * M + j];
     s = wave_sum(s);
     if ((tid & 63) != 0) continue;
     if (d < D) {
@@ -943,11 +929,11 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_g
   } else if (b < 2 * MT) {
     bwd_lam_role(p, md, g, ws, ad, sm, b - MT);
     bwd_leave(sb);
-  } else if (b < 3 * MT) {
-    bwd_row_role(p, ws, sm, b - 2 * MT, sb, status);
+  } else if (b < 4 * MT) {
+    bwd_row_role(p, ws, sm, (b - 2 * MT) >> 1, (b - 2 * MT) & 1, sb, status);
     bwd_leave(sb);
   } else {
-    bwd_final_role(p, md, g, out, ws, ad, sm, sb, status, 3 * MT + 1);
+    bwd_final_role(p, md, g, out, ws, ad, sm, sb, status, 4 * MT + 1);
   }
 }
 
@@ -1241,9 +1227,9 @@ int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, d
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + RED_ELEMS - 1) / RED_ELEMS)), dim3(256), 0, st, p, ws);
   LAUNCH_CHECK();
   const size_t lds_col = (size_t)(2 * p.MP * 16 + 16), lds_row = (size_t)p.MT * 256 + 16 * p.DP + (size_t)p.MP * 16,
-               lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr && ad.n - ad.lam_n <= BWD_MIRROR_MAX ? (size_t)(ad.n - ad.lam_n) : 0);   // + the LDS mirror of the gradients
+               lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr && ad.n - ad.lam_n <= BWD_MIRROR_MAX ? (size_t)(ad.n - ad.lam_n) : 0) + p.M;   // + the LDS mirror of the gradients + cs
   const size_t lds = sizeof(double) * (lds_col > lds_row ? (lds_col > lds_fin ? lds_col : lds_fin) : (lds_row > lds_fin ? lds_row : lds_fin));
-  hipLaunchKernelGGL(k_bwd, dim3(3 * p.MT + 1), dim3(BWD_THREADS), lds, st, p, md, g, out, ws, ad, status);
+  hipLaunchKernelGGL(k_bwd, dim3(4 * p.MT + 1), dim3(BWD_THREADS), lds, st, p, md, g, out, ws, ad, status);
   LAUNCH_CHECK();
   return 0;
 }

@@ -24,7 +24,7 @@ mm = MP * MP
 ntri = MT * (MT + 1) // 2
 rup = lambda x, a: (x + a - 1) // a * a
 slab_len = rup(ntri * 256 + MP * 16 + MP + 4 + P, 16)
-o = 64 + 16 + 16 + MP * DP + MP + MP + 2 * rup(P + 1, 16) + 9 * mm + MT * 256 + mm + slab_len + MT * MP * (DP + 2)
+o = 64 + 16 + 16 + MP * DP + MP + MP + 2 * rup(P + 1, 16) + 9 * mm + MT * 256 + mm + slab_len + 2 * MT * MP * (DP + 2)
 d = eng.ws[o + 200:o + 200 + 17].cpu().tolist()
 t0 = d[16]
 us = lambda i: (d[i] - t0) * 0.01

@@ -26,7 +26,7 @@ for flow, (NN, nw) in [(f, s_) for f in flows for s_ in SIZES]:
     ntri = MT * (MT + 1) // 2
     rup = lambda x, a: (x + a - 1) // a * a
     slab_len = rup(ntri * 256 + MP * 16 + MP + 4 + P, 16)
-    o = 64 + 16 + 16 + MP * DP + MP + MP + 2 * rup(P + 1, 16) + 9 * mm + MT * 256 + mm + slab_len + MT * MP * (DP + 2)
+    o = 64 + 16 + 16 + MP * DP + MP + MP + 2 * rup(P + 1, 16) + 9 * mm + MT * 256 + mm + slab_len + 2 * MT * MP * (DP + 2)
     d = eng.ws[o:o + 256].cpu().tolist()
     t0 = min(d[w * 20] for w in range(nw))
     print("== %s, N = %d, %d waves per workgroup" % (flow, NN, nw))
