@@ -24,9 +24,11 @@ def _engine(N, D, M, flow, seed, stream=None):
                       rowp=prob["rowp"], device=torch.device("cuda:0"))
 
 
-@pytest.mark.parametrize("flow", ["tanh3x2", "idsal3", None])
-def test_no_hand_off_wait_runs_to_its_bound(flow):
-    eng = _engine(2153, 4, 100, flow, seed=3)
+@pytest.mark.parametrize("flow,M,D", [("tanh3x2", 100, 4), ("idsal3", 100, 4), (None, 100, 4),
+                                      ("sal2", 128, 13),      # MT = 8: no spare wave in the column blocks, 8 + 8 + 16 + 1 blocks
+                                      ("tanh3x2", 5, 3)])     # MT = 1: the second half of the only row block has no tile
+def test_no_hand_off_wait_runs_to_its_bound(flow, M, D):
+    eng = _engine(2153, D, M, flow, seed=3)
     eng.elbo()
     torch.cuda.synchronize()
     t = time.time()
