@@ -40,6 +40,16 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace tgp {
 
+// Write-through store (global_store ... sc1) for results the NEXT launch consumes.  A launch ends with the write-back of every
+// dirty L2 line its workgroups left behind, and that flush sits on the chain between two dependent launches: the row kernel's
+// 15.5 MB of slabs cost ~3 us after its last wave had finished (round 5: step 100.7 -> 95.9 us with the slabs stored this way
+// -- the data leaves while other workgroups still compute, and the consumer finds it in the Infinity Cache).  Measured one
+// group of stores at a time on one box: it pays for the slabs and (a little) for k_reduce's sums; the small outputs (L, J, H'^T,
+// gradients, optimiser state, rowp) are neutral, the MLP's read-modify-written weight-gradient partials lose (ID_TGP 7 250 -> 6 950).
+__device__ __forceinline__ void st_wt(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // problem plan: derived sizes + workspace offsets (in doubles).  Host and device agree through this.
 // ---------------------------------------------------------------------------------------------------

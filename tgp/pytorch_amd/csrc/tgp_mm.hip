@@ -447,10 +447,10 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws)
     // half and mirror it -- G is then exactly symmetric and no element has two writers (run-to-run reproducible).
     if (ti == tj && col > row) return;
     double* G = ws + p.Gp;
-    G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col] = s;
-    G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row] = s;
+    st_wt(&G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col], s);     // (write-through: k_bwd's column blocks start on these)
+    st_wt(&G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row], s);
   } else {
-    ws[p.redp + e] = s;
+    st_wt(&ws[p.redp + e], s);
   }
 }
 

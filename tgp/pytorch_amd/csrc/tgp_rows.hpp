@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     c = tile_mm_f([&](int k) { return tile[(16 * ti + nl) * LD + k + q]; },
                   [&](int k) { return xt[(k + q) * CT16 + 16 * tc + nl]; }, 0, RBK, c);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
+    for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl], c[r]);
   }
   lds_barrier();
 
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int nk = 0; nk < RW; ++nk) c = TGP_MFMA(af[nk], bm[nk], c);
           if (nl == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
+            for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_S + 16 * ti + q + 4 * r], c[r]);
           }
         }
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               if (HB * h + u < RW) c = TGP_MFMA(af[HB * h + u], bv[u], c);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
+          for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl], c[r]);
         }
       }
     }
@@ -765,20 +765,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (lane == 0) { red[wave * 4] = e1; red[wave * 4 + 1] = e2; red[wave * 4 + 2] = e3; }
   lds_barrier();
   if (tid == 0) {
-    slab[p.slab_C + C_ELL] = a.scale * (red[0] + red[4] + red[8] + red[12]);
-    slab[p.slab_C + C_ETAB] = a.scale * (red[1] + red[5] + red[9] + red[13]);
-    slab[p.slab_C + C_SVB] = red[2] + red[6] + red[10] + red[14];
-    slab[p.slab_C + C_PAD] = 0.0;
+    st_wt(&slab[p.slab_C + C_ELL], a.scale * (red[0] + red[4] + red[8] + red[12]));
+    st_wt(&slab[p.slab_C + C_ETAB], a.scale * (red[1] + red[5] + red[9] + red[13]));
+    st_wt(&slab[p.slab_C + C_SVB], red[2] + red[6] + red[10] + red[14]);
+    st_wt(&slab[p.slab_C + C_PAD], 0.0);
   }
   for (int j = wave; j < P; j += 4) {
     const double s = wave_sum(acc[j * 64 + lane]);
-    if (lane == 0) slab[p.slab_C + C_THETA + j] = s;
+    if (lane == 0) st_wt(&slab[p.slab_C + C_THETA + j], s);
   }
   ROW_STAMP(a.ws, p, 10);
 #ifdef TGP_STAMPS
   if (bid == 0 && threadIdx.x == 0) a.ws[p.hdr + H_STAMP + 23] = (double)clock64();
 #endif
-  for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) slab[i] = 0.0;
+  for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += 256) st_wt(&slab[i], 0.0);
   if (RW == 16 && a.g_rowp != nullptr && q == 0 && valid) {
     const double* rbase = acc + (size_t)P * 64;
     for (int jr = 0; jr < RP; ++jr) {

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
 #pragma unroll
           for (int ks = 0; ks < NW; ++ks) c = TGP_MFMA(af[ks], bf[ks], c);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl] = c[r];
+          for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_T + (size_t)(16 * ti + q + 4 * r) * CT16 + 16 * tc + nl], c[r]);
         } else if (it < nT + nG) {
           const int t = it - nT;
           int ti = 0;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
 #pragma unroll
           for (int ks = 0; ks < NW; ++ks) c = TGP_MFMA(af[ks], bf[ks], c);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl] = c[r];
+          for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_G + (size_t)t * 256 + (q + 4 * r) * 16 + nl], c[r]);
         } else {
           const int ti = it - nT - nG;
           double af[NW], bf[NW];
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
           for (int ks = 0; ks < NW; ++ks) c = TGP_MFMA(af[ks], bf[ks], c);
           if (nl == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[p.slab_S + 16 * ti + q + 4 * r] = c[r];
+            for (int r = 0; r < 4; ++r) st_wt(&slab[p.slab_S + 16 * ti + q + 4 * r], c[r]);
           }
         }
       }
@@ -568,18 +568,18 @@ __global__ __launch_bounds__(NW * 64) void k_rows4(RowArgs a) {
       double s1 = 0.0, s2_ = 0.0, s3 = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) { s1 += red[4 * w]; s2_ += red[4 * w + 1]; s3 += red[4 * w + 2]; }
-      slab[p.slab_C + C_ELL] = a.scale * s1;
-      slab[p.slab_C + C_ETAB] = a.scale * s2_;
-      slab[p.slab_C + C_SVB] = s3;
-      slab[p.slab_C + C_PAD] = 0.0;
+      st_wt(&slab[p.slab_C + C_ELL], a.scale * s1);
+      st_wt(&slab[p.slab_C + C_ETAB], a.scale * s2_);
+      st_wt(&slab[p.slab_C + C_SVB], s3);
+      st_wt(&slab[p.slab_C + C_PAD], 0.0);
     }
     for (int jp = tid; jp < P; jp += NT) {
       double s = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += acc[jp * NW + w];
-      slab[p.slab_C + C_THETA + jp] = s;
+      st_wt(&slab[p.slab_C + C_THETA + jp], s);
     }
-    for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += NT) slab[i] = 0.0;
+    for (size_t i = p.slab_C + C_THETA + P + tid; i < p.slab_len; i += NT) st_wt(&slab[i], 0.0);
     if (a.g_rowp != nullptr && RP > 0) {
       const double* rbase = acc + (size_t)P * NW + tid;
       for (int jr = 0; jr < RP; ++jr) {
