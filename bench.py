@@ -99,15 +99,15 @@ EXPECT = {
     # fused path (M <= 128): prepare + [rows(N_rank)] + slab reduction + the M x M adjoint launch; with more than one rank the
     # Adam update is a launch of its own behind the collective (one rank: inside the adjoint launch)
     # rows: in-step duration of the row kernel the library picks at that many rows per rank (k_rows<..,10> at 8611, k_rows4 with
-    # 8-wave workgroups at 4306, 4-wave below; profiles/r05_rows_kernel_time.txt back-to-back + 4.3 us in-step: the kernel
+    # 8-wave workgroups at 4306, 4-wave below; profiles/r05_rows_kernel_time.txt back-to-back + 1.3 us in-step: the kernel
     # statistics of the 1-GPU step); bwd: k_bwd without the update in it
-    "tgp_power_tanh3x2": dict(prep=24.8, rows={8611: 49.6, 4306: 44.9, 2153: 37.5, 1077: 36.8}, reduce=5.2, bwd=20.3, bwd_w=19.5, adam=4.6),
-    "tgp_power_sal2": dict(prep=24.8, rows={8611: 45.5, 4306: 41.3, 2153: 35.1, 1077: 34.3}, reduce=5.2, bwd=20.3, bwd_w=19.5, adam=4.6),
-    "svgp_power": dict(prep=24.8, rows={8611: 37.6, 4306: 34.4, 2153: 29.6, 1077: 28.8}, reduce=4.5, bwd=20.3, bwd_w=19.5, adam=4.6),
+    "tgp_power_tanh3x2": dict(prep=24.5, rows={8611: 46.1, 4306: 41.2, 2153: 33.6, 1077: 33.5}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
+    "tgp_power_sal2": dict(prep=24.5, rows={8611: 42.0, 4306: 37.6, 2153: 31.1, 1077: 30.8}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
+    "svgp_power": dict(prep=24.5, rows={8611: 35.8, 4306: 32.0, 2153: 26.4, 1077: 26.2}, reduce=4.5, bwd=20.2, bwd_w=19.4, adam=4.6),
     # general-M path: the single-GPU step of the workload (weak scaling: every rank runs it on its own shard) and, for the
     # minibatch split 8 ways, the measured per-rank share (tgp_airline_mb10k_rank8)
     "tgp_airline_tanh5x6": dict(ms=31.4),
-    "tgp_airline_mb10k": dict(ms=2.25, strong_ms={8: 1.27}),
+    "tgp_airline_mb10k": dict(ms=2.25, strong_ms={8: 1.26}),
 }
 
 

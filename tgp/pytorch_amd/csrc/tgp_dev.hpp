@@ -89,10 +89,12 @@ inline size_t rup(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // 4 096 rows with 4-wave workgroups, 42.1 -> 54.1 us from 7 000 to 8 192 rows with 8-wave ones).  MEASURED (ROWS phase alone,
 // M = 100, StepTanhL 3 x 2, profiles/r05_rows4_vs_rows16.txt): 32-34 us with 4-wave workgroups and 40-42 us with 8-wave ones
 // against 52-53 us for the 16-row kernel; with 12-wave workgroups (three waves per SIMD: 168 registers, spills) it loses
-// (67 us at the full Power batch), so beyond 32 (256 - MT) rows the launch stays on k_rows.
+// (67 us at the full Power batch), so beyond 32 (255 - MT) rows the launch stays on k_rows.
+// (<= 255, not 256: with every CU needed, one CU that is late -- measured on one box of the pool, +11 us at 249 + 7
+//  workgroups -- costs a second round; one spare CU costs 16 / 32 rows of range)
 inline int rows4_waves(int N, int MT) {
-  if ((N + 15) / 16 + MT <= 256) return 4;
-  if ((N + 31) / 32 + MT <= 256) return 8;
+  if ((N + 15) / 16 + MT <= 255) return 4;
+  if ((N + 31) / 32 + MT <= 255) return 8;
   return 0;
 }
 // Data rows per wave k_rows uses at N rows when the launch qualifies (training, flow likelihood, shared flow parameters;

@@ -86,7 +86,7 @@ python tools/probes/stamp_big.py 2>&1 | grep -v amdgpu > $O/big_potrf_window_tim
 python tools/probes/stamp_rows4.py 2>&1 | grep -v "amdgpu\|^ROCm\|^Hostname\|^Librccl" > $O/rows4_phase_stamps.txt; head -6 $O/rows4_phase_stamps.txt
 # ---- the three row kernels side by side: ROWS phase alone at shard sizes and at the full batch ----
 ( for r in 0 auto; do if [ $r = auto ]; then unset TGP_ROWS4; else export TGP_ROWS4=$r TGP_ROWS_RW=16; fi
-    python tools/probes/rows_kernel_time.py tanh3x2 455 1077 2153 3984 4306 7968 8611 2>&1 | grep "TGP_ROWS4="
+    python tools/probes/rows_kernel_time.py tanh3x2 455 1077 2153 3968 4306 7936 8611 2>&1 | grep "TGP_ROWS4="
     if [ $r = auto ]; then for f in sal2 none; do python tools/probes/rows_kernel_time.py $f 1077 2153 4306 8611 2>&1 | grep "TGP_ROWS4="; done; fi
     unset TGP_ROWS4 TGP_ROWS_RW; done ) > $O/rows_kernel_time.txt; cat $O/rows_kernel_time.txt
 python tools/probes/stamp_bwd.py 2>&1 | grep -v amdgpu > $O/bwd_role_stamps.txt; cat $O/bwd_role_stamps.txt
