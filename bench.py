@@ -493,7 +493,7 @@ def main():
             "repeats": len(dts), "ms_per_step_min": 1e3 * dts[0] / args.steps, "ms_per_step_max": 1e3 * dts[-1] / args.steps,
             "config": {"workload": args.workload, "rows_per_gpu": int(Xr.shape[0]), "D": w["D"], "M": w["M"], "S": w["S"],
                        "flow": w["flow"], "global_rows_per_step": n_global, "parallelism": "row-shard x%d" % world,
-                       "launch": "eager" if args.no_graph else ("hipgraph, %d steps per graph launch" % eng.unroll if many else "hipgraph"), "final_elbo": elbo, "process_group": pg,
+                       "launch": "eager" if args.no_graph else ("hipgraph, %s steps per graph launch" % ("%d / %d" % (eng.unroll_long, eng.unroll) if getattr(eng, "gL", None) is not None else "%d" % eng.unroll) if many else "hipgraph"), "final_elbo": elbo, "process_group": pg,
                        "replicas": 1 + len(extra),
                        "expected": expected_line(args.workload, w, world, args.scaling, eng.fp.n + eng.fp.extra,
                                                  measured_ms_1gpu=(1e3 * dt / args.steps) if world == 1 else None)},

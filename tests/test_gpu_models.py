@@ -615,6 +615,21 @@ def test_unrolled_graph_equals_single_step_replays(flow):
     assert torch.equal(e1.fp.data, eu.fp.data)
     assert torch.equal(e1.fp.out[:3], eu.fp.out[:3]) and torch.equal(hu[-1], eu.fp.out[:3])
     assert float((hu[1:, 0] - hu[:-1, 0]).abs().min()) > 0.0          # eleven different steps, not one step eleven times
+    # the default capture: a U-step graph and a 4 U-step graph for long runs -- 57 steps = 40 + 10 + 7 single ones
+    # (one engine after the other, as above: engines of one shape share the cached workspace, and the rotated ID_TGP unit
+    #  keeps the prepared step in it between capture and replay)
+    n2 = 57
+    ed = make()
+    ed.capture()
+    assert ed.unroll == 10 and ed.unroll_long == 40 and ed.gL is not None
+    hd = torch.zeros(n2, 3, dtype=torch.float64, device=DEV)
+    ed.replay_many(n2, hd)
+    e2 = make()
+    e2.capture(unroll=1)
+    h2 = torch.zeros(n2, 3, dtype=torch.float64, device=DEV)
+    e2.replay_many(n2, h2)
+    torch.cuda.synchronize()
+    assert torch.equal(hd, h2) and torch.equal(ed.fp.data, e2.fp.data)
 
 
 def test_device_jitter_ladder_inside_the_captured_step():

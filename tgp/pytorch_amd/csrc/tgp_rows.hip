@@ -12,7 +12,7 @@ DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7) DECL(8)
 size_t rows4_lds_bytes(const Plan& p, bool train, int nw);   // tgp_rows_inst.hip (needs tgp_rows4.hpp)
 
 // Which row kernel: the 4-rows-per-wave kernel (tgp_rows4.hpp) where it measured faster -- a training launch (any
-// likelihood) whose row blocks and passenger blocks number at most one per CU (rows4_waves, tgp_dev.hpp: up to 32 (256 - MT)
+// likelihood) whose row blocks and passenger blocks number at most one per CU with one to spare (rows4_waves, tgp_dev.hpp: up to 32 (255 - MT)
 // rows) -- and where its LDS plan fits a CU.  TGP_ROWS4=0 forces the
 // 16-row kernel, TGP_ROWS4=<4|8> a workgroup size (A/B measurements, tools/probes/rows_kernel_time.py).
 int choose_rows4(const Plan& p, bool train) {

@@ -345,6 +345,7 @@ class ElboEngine:
         self.unroll = 1                 # steps per replay of self.gU (capture())
         self.gU = None
         self.hist_u = None
+        self.unroll_long, self.gL, self.hist_l = 1, None, None      # a longer unrolled graph for long runs (capture())
         self.graph = None
         self._warm = False
 
@@ -582,41 +583,55 @@ class ElboEngine:
 
     def _capture_unrolled(self, unit, unroll):
         """A second graph of U consecutive steps (one rank only).  Launching a graph costs ~5 us of idle GPU between two
-        replays of the 6-launch chain (14 us with the two-stream ID_TGP unit): U steps per launch pay it once (Power TGP
+        replays of the launch chain (14 us with the two-stream ID_TGP unit): U steps per launch pay it once (Power TGP
         129.5 -> 125 us per step at U = 8-10, ID_TGP 148 -> 141).  The same kernels in the same order: results are
         bit-identical to U single-step replays.  The scalars of the first U - 1 steps go to self.hist_u (the step's `out`
-        argument is redirected: no copy node), the last step's to fp.out as always."""
+        argument is redirected: no copy node), the last step's to fp.out as always.
+        With the default U (no explicit `unroll`) a THIRD graph of 4 U steps serves long runs (round 5, Power TGP at 96 us per
+        step: 10 406 steps/s at 10 steps per launch, 10 470 at 40); replay_many uses the longest graph that still fits, so a
+        20-step run is two replays of the U-step graph as before."""
         U = int(unroll if unroll is not None else os.environ.get("TGP_GRAPH_UNROLL", "10"))
         self.unroll, self.gU = 1, None
+        self.unroll_long, self.gL, self.hist_l = 1, None, None
         if U < 2 or (unroll is None and self.M > 128):      # general-M steps take milliseconds: nothing to gain, ~100 nodes each
             return
-        self.hist_u = torch.zeros(U - 1, 4, dtype=torch.float64, device=self.device)
-        gU = torch.cuda.CUDAGraph()
         # With a collective in the unit the step's scalars must stay where allreduce() / pre_reduce / post_reduce act on
         # them -- behind the gradients in fp.grad -- and reach hist_u by a captured 4-double copy AFTER the reduction; the
         # redirected `out` of the single-rank form would log rank-local, un-reduced values (and re-sum a stale slot).
         reduced = self.comm is not None or self.world_size > 1
-        try:
-            with torch.cuda.graph(gU, capture_error_mode=CAPTURE_MODE):
-                for u in range(U):
-                    self._out = self.hist_u[u] if (u < U - 1 and not reduced) else None
-                    unit()
-                    if reduced and u < U - 1:
-                        self.hist_u[u].copy_(self.fp.out)
-        finally:
-            self._out = None        # a failed capture must not leave later steps writing their scalars into hist_u
-        self.gU, self.unroll = gU, U
+
+        def capture_steps(nsteps):
+            hist = torch.zeros(nsteps - 1, 4, dtype=torch.float64, device=self.device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
+                    for u in range(nsteps):
+                        self._out = hist[u] if (u < nsteps - 1 and not reduced) else None
+                        unit()
+                        if reduced and u < nsteps - 1:
+                            hist[u].copy_(self.fp.out)
+            finally:
+                self._out = None        # a failed capture must not leave later steps writing their scalars into the history
+            return g, hist
+
+        self.gU, self.hist_u = capture_steps(U)
+        self.unroll = U
+        UL = int(os.environ.get("TGP_GRAPH_UNROLL_LONG", str(4 * U))) if unroll is None else 0
+        if UL > U and not reduced:
+            self.gL, self.hist_l = capture_steps(UL)
+            self.unroll_long = UL
 
     def replay_many(self, n, hist=None, row0=0):
-        """n steps: floor(n / U) replays of the unrolled graph, the rest one by one.  hist[row0 + i] <- (ELBO, ELL, KL) of
-        step i (device-to-device copies between replays, nothing synchronises)."""
-        k, U = 0, self.unroll
-        while self.gU is not None and n - k >= U:
-            self.gU.replay()
-            if hist is not None:
-                hist[row0 + k:row0 + k + U - 1].copy_(self.hist_u[:, :3])
-                hist[row0 + k + U - 1].copy_(self.fp.out[:3])
-            k += U
+        """n steps: replays of the longest unrolled graph that fits, then of the U-step one, the rest one by one.
+        hist[row0 + i] <- (ELBO, ELL, KL) of step i (device-to-device copies between replays, nothing synchronises)."""
+        k = 0
+        for g, U, hu in ((self.gL, self.unroll_long, self.hist_l), (self.gU, self.unroll, self.hist_u)):
+            while g is not None and n - k >= U:
+                g.replay()
+                if hist is not None:
+                    hist[row0 + k:row0 + k + U - 1].copy_(hu[:, :3])
+                    hist[row0 + k + U - 1].copy_(self.fp.out[:3])
+                k += U
         while k < n:
             self.replay()
             if hist is not None:
