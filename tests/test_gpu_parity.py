@@ -69,7 +69,10 @@ def test_elbo_step_matches_reference_fixture(name):
                                            # every tile count of the factorisation's panel schedule (MT = 4, 5, 6) and
                                            # M = 128 with D > 8 (no room for Zs in the factorisation block's LDS)
                                            (100, 3, 60, None, 8), (250, 5, 70, "sal1", 8), (250, 4, 90, None, 8),
-                                           (200, 13, 128, "sal2", 16)])
+                                           (200, 13, 128, "sal2", 16),
+                                           # a flow stack that does not fit a CU's LDS beside the fused row kernel's tiles
+                                           # (35 slots, 120 parameters at MT = 8): the step runs on the general-M path
+                                           (767, 5, 127, "tanh5x6", 8)])
 def test_elbo_step_matches_oracle(N, D, M, flow, S):
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(N, D, M, seed=3, flow=flow, S=S)

@@ -89,6 +89,14 @@ size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, in
   size_t d = p.total + (size_t)(plan_alloc_blocks(N) - p.nblocks) * p.slab_len;   // slabs for whichever row kernel runs
   const size_t lik = lik_workspace_doubles(N, P, RP);
   if (lik > d) d = lik;
+  // A training step whose flow stack does not fit a CU's LDS beside the row kernel's tiles (M > 112 with a 5 x 6 tanh flow)
+  // runs on the general-M path (elbo_step_impl): room for that path too.  The program is not known here; an upper bound
+  // of its stack slots (SAL: 3 per block; step-tanh: 1 + K per block with 4 K parameters) decides.
+  const int slots_ub = (nblk + P / 4) > 3 * nblk ? nblk + P / 4 : 3 * nblk;
+  if (nblk > 0 && !rows_train_lds_fits(p, slots_ub)) {
+    const size_t big = big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel);
+    if (big > d) d = big;
+  }
   return d * sizeof(double);
 }
 
@@ -142,7 +150,15 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
     ad.ln_b1 = log(adam->beta1); ad.ln_b2 = log(adam->beta2); ad.sign = adam->maximize ? -1.0 : 1.0;
     ad.step_dev = adam->step_dev;
   }
-  if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) {
+  bool general = model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF;
+  if (!general && fp.nslots > 0) {
+    // the fused path keeps the flow stack of a row block in LDS beside its operand tiles; a program that does not fit even
+    // with one node in flight (TGP_E_LDS until round 5: M > 112 with the 5 x 6 tanh flow) takes the general-M path
+    Plan pl;
+    if (int rc = make_plan(pl, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
+    general = !rows_train_lds_fits(pl, fp.nslots);
+  }
+  if (general) {
     if (int rc = launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st))
       return rc;
     if (adam != nullptr)   // general-M path: the update stays a launch of its own

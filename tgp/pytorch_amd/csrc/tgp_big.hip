@@ -102,7 +102,8 @@ static BigPlan plan_parity(const BigPlan& p, int par) {
 static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int kernel) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
-  if (M <= 16 * TGP_MAX_MT && kernel == TGP_KERNEL_SCALE_RBF) return TGP_E_UNSUPPORTED;  // the fused path owns these
+  // (M <= 128 with the RBF kernel normally takes the fused path; tgp_api.hip sends it here when the flow stack of a training
+  //  step does not fit a CU's LDS beside the fused row kernel's tiles)
   p.kernel = kernel;
   p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
   p.MP = (M + 127) / 128 * 128;

@@ -54,6 +54,8 @@ int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* st
 int choose_rows4(const Plan& p, bool train);
 // data rows per wave of k_rows for this plan (16, or 10: training with the flow likelihood at Power-like sizes)
 int rows_per_wave(const Plan& p, const FlowProg& fp, bool train);
+// does the training launch of the row kernel fit a CU's LDS with `nslots` flow-stack slots (its leanest form: one node in flight)?
+bool rows_train_lds_fits(const Plan& p, int nslots);
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 

@@ -42,6 +42,10 @@ int rows_per_wave(const Plan& p, const FlowProg& fp, bool train) {
   return TGP_RW_SMALL;
 }
 
+bool rows_train_lds_fits(const Plan& p, int nslots) {
+  return row_lds(p, 2, nslots).total * sizeof(double) <= (size_t)160 * 1024 - 1024;
+}
+
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
   RowArgs a;
