@@ -67,3 +67,26 @@ def test_two_engines_on_two_streams():
         st = e.status.cpu().tolist()
         assert st[0] == 0 and st[4:] == [0, 0, 0, 0], st
     assert dt < 0.5, "2 x 30 concurrent steps took %.2f s" % dt
+
+
+@pytest.mark.parametrize("N,D,M,flow", [(2153, 13, 128, "sal2"),      # 1 792 assembly items, 1 815 parameters outside Lam: the loops
+                                        (2153, 4, 100, "tanh3x2"), (700, 16, 60, None), (455, 13, 5, None)])
+def test_update_inside_the_backward_launch_equals_the_separate_update(N, D, M, flow):
+    """tgp_elbo_step_adam_f64 (Adam inside k_bwd: Lam in the threads that form its gradient, the rest from the LDS mirror of the
+    final block) against the same steps as gradients + tgp_adam_dev: parameters, moments and scalars after three steps."""
+    a = _engine(N, D, M, flow, seed=5)
+    assert a.fused_adam
+    for _ in range(3):
+        a.step_adam()
+    torch.cuda.synchronize()
+    pa, ma, va, oa = a.fp.data.clone(), a.fp.exp_avg.clone(), a.fp.exp_avg_sq.clone(), a.fp.out[:3].clone()
+    b = _engine(N, D, M, flow, seed=5)
+    for _ in range(3):
+        b.forward_backward()
+        b.adam()
+    torch.cuda.synchronize()
+    for x, y, what in ((pa, b.fp.data, "parameters"), (ma, b.fp.exp_avg, "exp_avg"), (va, b.fp.exp_avg_sq, "exp_avg_sq"),
+                       (oa, b.fp.out[:3], "scalars")):
+        err = float((x - y).abs().max() / (y.abs().max() + 1e-300))
+        assert err < 1e-13, (what, err)
+    assert a.status.cpu().tolist()[4:] == [0, 0, 0, 0]
