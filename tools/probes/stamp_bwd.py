@@ -6,7 +6,7 @@ os.environ.setdefault("TGP_ALLOW_STALE_LIB", "1")
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 import tgp.pytorch_amd.lib as L
-L.LIB_PATH = os.path.join(ROOT, "tools/probes/stamp/libtgp_hip.so")
+L.LIB_PATH = os.environ.get("TGP_STAMP_LIB", os.path.join(ROOT, "tools/probes/stamp/libtgp_hip.so"))
 from tgp.pytorch_amd.engine import ElboEngine
 from tgp.pytorch_amd import synthetic
 flow = sys.argv[1] if len(sys.argv) > 1 else "tanh3x2"
