@@ -15,7 +15,9 @@
  *     tgp_model.program (a few int32 describing the flow) is a HOST array, read during the call;
  *     outputs and the workspace are pre-allocated by the caller, nothing is allocated inside;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered, safe
- *     to capture into a hipGraph, and re-entrant when callers use distinct streams + workspaces;
+ *     to capture into a hipGraph, and re-entrant when callers use distinct streams + workspaces + status buffers
+ *     (status[4..7] are hand-off words of the launches in flight: two concurrent calls that shared them would pass each
+ *     other's waits early);
  *     the general-M path (M > 128 or a non-RBF kernel) forks independent phases onto helper streams that the
  *     library creates at a host thread's first such call and joins before the call returns (event record / wait:
  *     valid under capture of `stream`, where they become parallel branches of the graph) -- make a thread's first
@@ -26,11 +28,16 @@
  *                   TGP_STATUS_SYNC_TIMEOUT: a workgroup of the prepare or of the M x M backward launch gave up waiting for a hand-off word --
  *                   the hand-off words were not zero, or its producers never became resident; results invalid),
  *       status[1] = 1 if K_MM contained a NaN (the reference raises NanError, dsp/utils.py:241-254),
- *       status[2] = level of the on-device jitter ladder that succeeded (tgp_model.jitter_ladder), status[3] reserved,
+ *       status[2] = level of the on-device jitter ladder that succeeded (tgp_model.jitter_ladder),
+ *       status[3] = STICKY count of expired hand-off waits: incremented by the launch whose wait expired, never cleared by the
+ *                   library (status[0] is rewritten by the next call's prepare launch, so inside a replayed graph of several
+ *                   steps a timeout shows only here); a fused-update call (tgp_elbo_step_adam_f64) whose backward launch sees
+ *                   the timeout skips the update outside Lam and the step counter and returns NaN scalars; the caller
+ *                   zeroes the word after it has handled the event,
  *       status[4..7] = hand-off words between workgroups of ONE launch (M <= 128: the tile blocks of the prepare
  *                   launch count themselves in status[4] once their tile of K_MM is in global memory, status[5] counts
- *                   the blocks that have left; the M x M backward launch counts its finished column blocks (low 16 bits)
- *                   and row blocks (high 16 bits) in status[6] and the blocks that have left in status[7]);
+ *                   the blocks that have left; the M x M backward launch counts its finished column blocks in bits 16-23
+ *                   and its finished row-block halves in bits 24-31 of status[6], and the blocks that have left in status[7]);
  *                   the library leaves them zero at the end of every
  *                   call, the caller must not touch them while a call is in flight.  A caller built against the
  *                   int32[4] status of ABI versions <= 100 must grow the buffer: check tgp_version() >= 101,
@@ -47,8 +54,8 @@
 extern "C" {
 #endif
 
-#define TGP_VERSION 102
-#define TGP_FUSED_MAX_M 128 /* up to here the whole step is 6 fused kernel launches (operators resident in LDS/registers) */
+#define TGP_VERSION 103
+#define TGP_FUSED_MAX_M 128 /* up to here the whole step is 4 fused kernel launches (operators resident in LDS/registers) */
 #define TGP_BIG_MAX_M 4096  /* above: chunked path built on a tiled float64 MFMA GEMM                             */
 
 /* error codes (negative return values below -64 are generic) */
@@ -90,6 +97,26 @@ extern "C" {
 #define TGP_KERNEL_SCALE_RBF 0      /* 'scale_rbf'      utils_models.py:188-193 (what main.py:229 uses) */
 #define TGP_KERNEL_SCALE_MATERN32 1 /* 'scale_matern32' utils_models.py:199-204                          */
 
+/* tgp_model.plan: which of the library's equivalent implementations a call runs (results agree to rounding; speed differs).
+ * The library's own choice (0) depends on the shape only.  A workspace sized by tgp_workspace_bytes[_kernel] holds every
+ * row-kernel variant; a forced chunk size needs tgp_workspace_bytes_plan.
+ *   bits 0-3  row kernel of the fused path (M <= 128):
+ *     TGP_PLAN_ROWS_AUTO  library's choice        TGP_PLAN_ROWS_K16  k_rows, 16 data rows per wave
+ *     TGP_PLAN_ROWS_K     k_rows, rows per wave by the library's rule (16 or 10): never k_rows4
+ *     TGP_PLAN_ROWS4_NW4 / TGP_PLAN_ROWS4_NW8  k_rows4 with 4 / 8 waves per workgroup (ignored where its LDS plan or the
+ *                          workspace's slab count does not allow it)
+ *   bit 4     TGP_PLAN_NO_CHUNK_OVERLAP  general-M path: one set of chunk buffers, forward and backward of the chunks in line
+ *   bits 8-23 TGP_PLAN_CHUNK_ROWS(n)     general-M path: row chunks of at most n rows (rounded up to 128; 0 = 16 384) */
+#define TGP_PLAN_ROWS_AUTO 0
+#define TGP_PLAN_ROWS_K16 1
+#define TGP_PLAN_ROWS_K 2
+#define TGP_PLAN_ROWS4_NW4 3
+#define TGP_PLAN_ROWS4_NW8 4
+#define TGP_PLAN_ROWS_MASK 15
+#define TGP_PLAN_NO_CHUNK_OVERLAP 16
+#define TGP_PLAN_CHUNK_ROWS(n) (((((n) + 127) / 128) & 0xffff) << 8)
+#define TGP_PLAN_CHUNK_OF(plan) ((((plan) >> 8) & 0xffff) * 128)
+
 typedef struct tgp_model {
   int32_t N;       /* rows in this call (this rank's shard of the minibatch)            */
   int32_t D;       /* input dimension (<= 16)                                           */
@@ -100,7 +127,8 @@ typedef struct tgp_model {
   int32_t RP;      /* per-row flow parameter columns in rowp                            */
   int32_t lik;     /* TGP_LIK_*                                                         */
   int32_t kernel;  /* TGP_KERNEL_*                                                      */
-  int32_t reserved0;
+  int32_t plan;    /* kernel-selection overrides of THIS call, TGP_PLAN_* below; 0 = automatic (what every caller but
+                      an A/B measurement or a test of a specific kernel passes).  Was `reserved0` up to ABI 102.  */
   double scale;    /* N_total / MB_global: sparse_MF_SP.ELL, models/sparse_MF_SP.py:623-626 */
   double jitter;   /* added to diag(K_MM) before the Cholesky (0 unless retrying)       */
   double kl_scale; /* weight of the KL gradient in this call: 1/world_size so that an
@@ -145,6 +173,9 @@ size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t n
 /* Same for a given covariance function (tgp_workspace_bytes == TGP_KERNEL_SCALE_RBF). */
 size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
                                   int32_t kernel);
+/* Same for a call that passes tgp_model.plan = `plan` (a forced chunk size changes the general-M path's buffers). */
+size_t tgp_workspace_bytes_plan(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
+                                int32_t kernel, int32_t plan);
 
 /* One fused ELBO evaluation with gradients: replaces sparse_MF_SP.ELBO (models/sparse_MF_SP.py:552-598)
  * + loss.backward() (trainers/trainer_base.py:341) for one minibatch shard.

@@ -1,7 +1,6 @@
 """GPU (-m gpu): the general-M path (M > 128: tiled float64 MFMA GEMM, multi-kernel blocked Cholesky, chunked rows)
 through the C ABI against the oracle, plus the GEMM building block against torch.matmul."""
 import os
-import subprocess
 import sys
 
 import pytest
@@ -166,26 +165,34 @@ def test_big_qf_moments_matches_oracle():
     assert rel_err(v.cpu(), v_o.reshape(-1)) < 1e-7
 
 
-_CHUNK_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from test_gpu_big import _oracle_case
-from test_gpu_parity import run_hip, compare
-for N, D, M, flow, S in [(1000, 6, 160, "sal2", 16), (700, 5, 140, "idsal2", 8), (901, 4, 130, None, 8)]:
-    g = _oracle_case(N, D, M, flow, S, seed=5)
-    out, grads, status, (mu, v) = run_hip(g)
-    assert int(status[0]) == 0
-    compare(out, grads, g)
-print("CHUNKED_OK")
-"""
+def _chunked_cases(cases, chunk_rows):
+    """The cases through the general-M path with row chunks of at most `chunk_rows` rows (tgp_model.plan =
+    TGP_PLAN_CHUNK_ROWS: the chunk size is a property of the call -- it was a process-global environment switch, and these
+    tests child processes, until round 6)."""
+    from tgp.pytorch_amd import lib
+    for N, D, M, flow, S in cases:
+        g = _oracle_case(N, D, M, flow, S, seed=5)
+        out, grads, status, (mu, v) = run_hip(g, plan=lib.plan_chunk_rows(chunk_rows))
+        assert int(status[0]) == 0
+        compare(out, grads, g)
 
 
 def test_big_path_several_row_chunks():
-    """TGP_BIG_CHUNK (read once per process) forces 4 row chunks, the last one ragged: accumulation across chunks."""
-    env = dict(os.environ, TGP_BIG_CHUNK="256")
-    r = subprocess.run([sys.executable, "-c", _CHUNK_SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
-    assert "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    """Chunks of 256 rows: 4 row chunks, the last one ragged -- accumulation across chunks, the two-buffer chunk pipeline."""
+    _chunked_cases([(1000, 6, 160, "sal2", 16), (700, 5, 140, "idsal2", 8), (901, 4, 130, None, 8)], 256)
+
+
+def test_big_path_chunks_in_line_equal_the_overlapped_pipeline():
+    """TGP_PLAN_NO_CHUNK_OVERLAP (one set of chunk buffers, forward and backward of the chunks in line) against the
+    two-buffer pipeline: the same sums in the same order -- bit-identical."""
+    from tgp.pytorch_amd import lib
+    g = _oracle_case(1000, 6, 160, "sal2", 16, seed=5)
+    o1, g1, st1, _ = run_hip(g, plan=lib.plan_chunk_rows(256))
+    o2, g2, st2, _ = run_hip(g, plan=lib.plan_chunk_rows(256) | lib.PLAN_NO_CHUNK_OVERLAP)
+    assert int(st1[0]) == 0 and int(st2[0]) == 0
+    assert torch.equal(o1, o2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -323,15 +330,9 @@ def test_device_jitter_ladder_on_the_general_path():
 
 
 def test_big_path_ragged_last_chunk_in_the_small_problem_likelihood_mode():
-    """TGP_BIG_CHUNK=4224, N=8224: chunks of 4224 rows (4 lanes per row in k_ell_flow, 67 partials) and a ragged last one
+    """Chunks of 4224 rows at N = 8224: 4224 rows (4 lanes per row in k_ell_flow, 67 partials) and a ragged last chunk
     of 4000 rows (<= 4096: 16 lanes per row, 250 partials) -- the likelihood workspace is sized for either mode."""
-    script = _CHUNK_SCRIPT.replace('[(1000, 6, 160, "sal2", 16), (700, 5, 140, "idsal2", 8), (901, 4, 130, None, 8)]',
-                                   '[(8224, 4, 130, "sal2", 16)]')
-    assert "8224" in script
-    env = dict(os.environ, TGP_BIG_CHUNK="4224")
-    r = subprocess.run([sys.executable, "-c", script % (ROOT, os.path.join(ROOT, "tests"))], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
-    assert "CHUNKED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    _chunked_cases([(8224, 4, 130, "sal2", 16)], 4224)
 
 
 @pytest.mark.parametrize("N", [10000, 20000])
@@ -345,17 +346,7 @@ def test_big_airline_recipe_sizes_match_oracle(N):
     assert float(torch.triu(grads["Lam"], 1).abs().max()) == 0.0
 
 
-_SHARD_SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from test_gpu_big import _shard_step
-out, grads = _shard_step(250000)
-torch.save({"out": out, "grads": grads}, sys.argv[1])
-print("SHARD_OK")
-"""
-
-
-def _shard_step(N, lo=0, hi=None, mb_global=None):
+def _shard_step(N, lo=0, hi=None, mb_global=None, plan=0):
     """One ELBO step of configs[4]'s per-GPU shard shape (rows [lo, hi) of the seeded N-row problem) through the C ABI."""
     from tgp.pytorch_amd import ops
     from tgp.pytorch_amd.synthetic import synthetic_problem
@@ -366,7 +357,8 @@ def _shard_step(N, lo=0, hi=None, mb_global=None):
     flow = ops.FlowSpec(prob["program"], p["theta"].numel(), 0, dev)
     out, g, st, _ = ops.elbo_step(prob["X"][lo:hi].to(dev), prob["Y"][lo:hi].to(dev), p["Z"], p["raw_lengthscale"],
                                   p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], float(N), flow=flow,
-                                  theta=p["theta"], S=32, kl_scale=1.0 if mb_global is None else 0.5, mb_global=mb_global)
+                                  theta=p["theta"], S=32, kl_scale=1.0 if mb_global is None else 0.5, mb_global=mb_global,
+                                  plan=plan)
     torch.cuda.synchronize()
     assert int(st[0]) == 0 and int(st[1]) == 0
     return out.cpu(), {k: t.cpu() for k, t in g.items()}
@@ -383,11 +375,11 @@ def test_big_minibatch_step_is_bit_reproducible():
             assert torch.equal(g1[k], g2[k]), k
 
 
-def test_big_full_shard_properties(tmp_path):
+def test_big_full_shard_properties():
     """The real per-GPU shard of BASELINE configs[4]: N = 250 000 rows, D = 8, M = 1000, StepTanhL 5x6, S = 32 (16 natural
     row chunks).  Too large for the CPU oracle, so the size-independent properties: bit reproducibility; shard additivity
     (the whole shard == its two 125 000-row halves summed, each with KL weight 1/2 -- what two ranks would all-reduce);
-    natural chunking == chunking forced to 8 192 rows (TGP_BIG_CHUNK, read once per process: a child process)."""
+    natural chunking == chunking forced to 8 192 rows (tgp_model.plan)."""
     N = 250000
     out, grads = _shard_step(N)
     out2, grads2 = _shard_step(N)
@@ -401,13 +393,10 @@ def test_big_full_shard_properties(tmp_path):
     assert rel_err(oa[1] + ob[1], out[1]) < 1e-9 and rel_err(oa[2], out[2]) < 1e-12
     for k in grads:
         assert rel_err(ga[k] + gb[k], grads[k]) < 1e-8, (k, rel_err(ga[k] + gb[k], grads[k]))
-    # forced chunking in a child process
-    f = os.path.join(str(tmp_path), "forced.pt")
-    env = dict(os.environ, TGP_BIG_CHUNK="8192")
-    r = subprocess.run([sys.executable, "-c", _SHARD_SCRIPT % (ROOT, os.path.join(ROOT, "tests")), f], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=900)
-    assert "SHARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-    forced = torch.load(f)
+    # forced chunking: 31 chunks of 8 192 rows instead of 16 of 15 744 (tgp_model.plan)
+    from tgp.pytorch_amd import lib
+    fo, fg = _shard_step(N, plan=lib.plan_chunk_rows(8192))
+    forced = {"out": fo, "grads": fg}
     assert rel_err(forced["out"][:3], out[:3]) < 1e-10
     for k in grads:
         assert rel_err(forced["grads"][k], grads[k]) < 1e-8, (k, rel_err(forced["grads"][k], grads[k]))

@@ -90,3 +90,44 @@ def test_update_inside_the_backward_launch_equals_the_separate_update(N, D, M, f
         err = float((x - y).abs().max() / (y.abs().max() + 1e-300))
         assert err < 1e-13, (what, err)
     assert a.status.cpu().tolist()[4:] == [0, 0, 0, 0]
+
+
+def test_a_hand_off_timeout_is_sticky_and_skips_the_update():
+    """a wait of the backward launch that runs to its bound must not be lost when the next step's prepare launch rewrites
+    status[0], and must not step the optimiser on gradients built from stale operands.  The PP count of status[6] is poisoned
+    (sign bit: the count can never reach its target), one fused-update step is launched, then two healthy ones:
+    status[3] keeps the event, the first step changed nothing outside Lam and returned NaN scalars, the Adam step counter did
+    not advance, check_status() raises HandoffTimeoutError although status[0] is 0 again."""
+    from tgp.pytorch_amd import ops
+    eng = _engine(2153, 4, 100, "tanh3x2", seed=7)
+    assert eng.fused_adam
+    eng.step_adam()
+    torch.cuda.synchronize()
+    assert eng.status.cpu().tolist()[3] == 0
+    before, step0 = eng.fp.data.clone(), int(eng.step_dev[0])
+    lam_lo = eng.fp.offsets["Lam"]
+    lam_hi = lam_lo + eng.fp.sizes["Lam"]
+    eng.status[6] = -2 ** 31                       # bits 24-31 are the PP count: never >= 2 MT with the sign bit set
+    t = time.time()
+    eng.step_adam()
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    st = eng.status.cpu().tolist()
+    assert st[0] == ops.STATUS_SYNC_TIMEOUT and st[3] >= 1, st
+    assert st[4:] == [0, 0, 0, 0], st             # the final role still zeroes the words: the next launch starts clean
+    assert dt < 5.0, "a bounded wait took %.1f s" % dt
+    assert int(eng.step_dev[0]) == step0, "the optimiser stepped on a timed-out launch"
+    after = eng.fp.data
+    assert torch.equal(after[:lam_lo], before[:lam_lo]) and torch.equal(after[lam_hi:], before[lam_hi:])
+    assert bool(torch.isnan(eng.fp.out[:3]).all())
+    sticky = st[3]
+    for _ in range(2):
+        eng.step_adam()
+    torch.cuda.synchronize()
+    st = eng.status.cpu().tolist()
+    assert st[0] == 0 and st[3] == sticky, st     # status[0] is rewritten by every prepare launch; status[3] is not
+    assert int(eng.step_dev[0]) == step0 + 2 and bool(torch.isfinite(eng.fp.out[:3]).all())
+    with pytest.raises(ops.HandoffTimeoutError):
+        eng.check_status()
+    eng.status[3] = 0                             # handled: the caller clears the sticky word
+    eng.check_status()

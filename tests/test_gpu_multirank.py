@@ -151,3 +151,18 @@ def test_abi_bootstrap_with_two_ranks_on_one_gpu_errors_out(tmp_path):
     assert len(ended) == 2, r.stdout[-2000:] + r.stderr[-3000:]
     for l in ended:
         assert (": error:" in l) or (": timeout:" in l) or (": unavailable:" in l), l     # never "built", never a hang
+
+
+def test_bench_allreduce_only_one_rank():
+    """`bench.py --allreduce-only`: tgp_allreduce_f64 in a captured graph at the two exchange sizes.  One rank here
+    (a 1-rank RCCL communicator: the launch overhead of the collective); on a multi-GPU node the same command replaces the
+    ESTIMATE behind config.expected with a measurement."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--allreduce-only"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 1 and [s["doubles"] for s in res["sizes"]] == [10540, 1009064]
+    assert all(0.0 < s["us_per_allreduce"] < 5000.0 for s in res["sizes"]), res

@@ -72,7 +72,13 @@ def test_elbo_step_matches_reference_fixture(name):
                                            (200, 13, 128, "sal2", 16),
                                            # a flow stack that does not fit a CU's LDS beside the fused row kernel's tiles
                                            # (35 slots, 120 parameters at MT = 8): the step runs on the general-M path
-                                           (767, 5, 127, "tanh5x6", 8)])
+                                           (767, 5, 127, "tanh5x6", 8),
+                                           # the selection window of k_rows<.., RW = 10> (7 936 < N <= 10 240 at 10 S <= 320) and its
+                                           # edges: first size above k_rows4's range; the window's last size and the
+                                           # first beyond it (-> 16 rows per wave); per-row SAL at MT = 8, D = 13; one tile, S = 8;
+                                           # S = 33 (10 S > 320 -> 16 rows per wave)
+                                           (7937, 4, 100, "tanh3x2", 32), (10240, 8, 64, "sal2", 32), (10241, 8, 64, "sal2", 32),
+                                           (9000, 13, 128, "idsal3", 20), (8000, 3, 16, "tanh1x1", 8), (8611, 4, 100, "sal2", 33)])
 def test_elbo_step_matches_oracle(N, D, M, flow, S):
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(N, D, M, seed=3, flow=flow, S=S)

@@ -1,9 +1,9 @@
 """The 4-rows-per-wave row kernel (csrc/tgp_rows4.hpp, v_mfma_f64_4x4x4_4b) against the 16-rows-per-wave one on the same
 inputs: which of the two a training launch gets is decided inside the library (row blocks + passenger blocks at most one per
-CU -> k_rows4), `TGP_ROWS4=0` (read once per process) forces k_rows -- so the reference side runs in a child process.  Also:
-bit reproducibility of k_rows4, and the oracle at a size where k_rows4 runs with 8-wave workgroups."""
+CU -> k_rows4); `tgp_model.plan` (lib.PLAN_ROWS_K: k_rows with its own rows-per-wave rule, PLAN_ROWS_K16: k_rows at 16 rows per
+wave) overrides that choice for ONE call, so both sides run in this process.  Also: bit reproducibility of k_rows4, the oracle
+at a size where k_rows4 runs with 8-wave workgroups, and k_rows<.., 10> against k_rows<.., 16> on the same inputs."""
 import os
-import subprocess
 import sys
 
 import pytest
@@ -22,7 +22,7 @@ CASES = [(455, 13, 5, "tanh3x2", 32), (1077, 4, 100, "tanh3x2", 32), (2153, 4, 1
          (2153, 4, 100, None, 32), (6000, 8, 64, None, 32)]      # closed-form likelihood (SVGP)
 
 
-def _run(case):
+def _run(case, plan=0):
     from tgp.pytorch_amd import ops, synthetic
     N, D, M, flow, S = case
     dev = torch.device("cuda:0")
@@ -32,7 +32,7 @@ def _run(case):
     fs = ops.FlowSpec(prob["program"], p["theta"].numel(), 0 if rowp is None else rowp.shape[1], dev) if flow else None
     out, g, status, (mu, v) = ops.elbo_step(prob["X"].to(dev), prob["Y"].to(dev), p["Z"], p["raw_lengthscale"],
                                             p["raw_outputscale"], p["m"], p["Lam"], p["log_var_noise"], prob["N_total"],
-                                            flow=fs, theta=p.get("theta"), rowp=rowp, S=S, want_moments=True)
+                                            flow=fs, theta=p.get("theta"), rowp=rowp, S=S, want_moments=True, plan=plan)
     torch.cuda.synchronize()
     assert int(status[0]) == 0 and int(status[1]) == 0
     res = {"out": out.cpu(), "mu": mu.cpu(), "v": v.cpu()}
@@ -44,19 +44,34 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-300))
 
 
-def test_rows4_matches_rows16_and_is_reproducible(tmp_path):
-    if os.environ.get("TGP_ROWS4") == "0":
-        pytest.skip("this process is pinned to k_rows")
-    ref_file = str(tmp_path / "rows16.pt")
-    env = dict(os.environ, TGP_ROWS4="0")
-    subprocess.check_call([sys.executable, os.path.abspath(__file__), ref_file], env=env, cwd=ROOT)
-    ref = torch.load(ref_file)
-    for case, r16 in zip(CASES, ref):
-        a, b = _run(case), _run(case)
-        for k in a:
-            assert torch.equal(a[k], b[k]), ("k_rows4 is not bit-reproducible", case, k)
-            tol = 1e-10 if k in ("out", "mu", "v") else 1e-8
-            assert _rel(a[k], r16[k]) < tol, (case, k, _rel(a[k], r16[k]))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_D%d_M%d_%s_S%d" % c)
+def test_rows4_matches_rows16_and_is_reproducible(case):
+    from tgp.pytorch_amd import lib
+    r16 = _run(case, plan=lib.PLAN_ROWS_K)          # k_rows (rows per wave by its own rule), same process, same inputs
+    a, b = _run(case), _run(case)                   # the library's choice at these sizes: k_rows4
+    for k in a:
+        assert torch.equal(a[k], b[k]), ("k_rows4 is not bit-reproducible", case, k)
+        tol = 1e-10 if k in ("out", "mu", "v") else 1e-8
+        assert _rel(a[k], r16[k]) < tol, (case, k, _rel(a[k], r16[k]))
+
+
+# k_rows<.., RW = 10> (selected for 7 936 < N <= 10 240 with a flow likelihood whose 10 S (row, node) pairs fill the lanes in one
+# trip) against k_rows<.., 16> forced by plan: the two tilings share every tile chain and differ in the quadrature's lane
+# assignment and in the statistics' contraction length (the selection window and its edges)
+RW_CASES = [(8611, 4, 100, "tanh3x2", 32), (7937, 4, 100, "tanh3x2", 32), (10240, 8, 64, "sal2", 32), (9000, 13, 128, "idsal3", 20),
+            (8000, 3, 16, "tanh1x1", 8), (8200, 16, 37, "sal2", 32)]
+
+
+@pytest.mark.parametrize("case", RW_CASES, ids=lambda c: "N%d_D%d_M%d_%s_S%d" % c)
+def test_rows10_matches_rows16_and_is_reproducible(case):
+    from tgp.pytorch_amd import lib
+    r16 = _run(case, plan=lib.PLAN_ROWS_K16)
+    a, b = _run(case), _run(case)
+    for k in a:
+        assert torch.equal(a[k], b[k]), ("k_rows<.., 10> is not bit-reproducible", case, k)
+        tol = 1e-10 if k in ("out", "mu", "v") else 1e-8
+        assert _rel(a[k], r16[k]) < tol, (case, k, _rel(a[k], r16[k]))
+    assert any(not torch.equal(a[k], r16[k]) for k in a), "plan=PLAN_ROWS_K16 ran the same kernel as the automatic choice"
 
 
 def test_rows4_against_the_oracle_at_a_two_gpu_shard_size():
@@ -78,8 +93,3 @@ def test_rows4_against_the_oracle_at_a_two_gpu_shard_size():
     for k_hip, k_or in (("Z", "Z"), ("raw_ls", "raw_lengthscale"), ("raw_os", "raw_outputscale"), ("m", "m"),
                         ("Lam", "Lam"), ("lvn", "log_var_noise"), ("theta", "theta")):
         assert _rel(g[k_hip].cpu(), og[k_or]) < 1e-7, (k_hip, _rel(g[k_hip].cpu(), og[k_or]))
-
-
-if __name__ == "__main__":       # child of the first test: the same cases through k_rows (TGP_ROWS4=0 in the environment)
-    assert os.environ.get("TGP_ROWS4") == "0"
-    torch.save([_run(c) for c in CASES], sys.argv[1])

@@ -3,7 +3,11 @@ import numpy as np
 import pytest
 import torch
 
+import os
+
 from oracle import tgp_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -234,3 +238,46 @@ def test_collective_decision_function():
     import pytest
     with pytest.raises(ValueError):
         c("rccl", 2, "nccl")
+
+
+def test_bench_rank_failure_is_a_clean_exit_3(tmp_path):
+    """a rank of bench.py that fails behind init_process_group (communicator bootstrap timeout, RCCL missing, a
+    hand-off timeout) reports, tears its process group down in a bounded way and leaves with code 3 through a fresh exit --
+    here with a live 1-rank gloo group and a TimeoutError raised where the engine would raise it."""
+    import subprocess
+    import sys
+    script = (
+        "import os, sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')\n"
+        "torch.distributed.init_process_group('gloo', rank=0, world_size=1)\n"
+        "def boom(*a, **k):\n"
+        "    raise TimeoutError('tgp_comm_init did not return within 1 s on rank 0')\n"
+        "bench.run_bench = boom\n"
+        "try:\n"
+        "    bench.run_bench(None, 1, 0, None, 'gloo')\n"
+        "except BaseException as e:\n"
+        "    bench.fail_all_ranks(e, 0, 1)\n"
+        "print('NOT REACHED')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "NOT REACHED" not in r.stdout and "TimeoutError" in r.stderr and "rank 0 of 1 failed" in r.stderr
+
+
+def test_rccl_comm_without_a_carrier_for_the_id_raises_instead_of_hanging():
+    """RcclComm(world_size > 1) with torch.distributed not initialised has no way to carry rank 0's id to the other
+    ranks; ranks != 0 used to call ncclCommInitRank with an all-zero id (a hang).  It raises RcclUnavailable now."""
+    from tgp.pytorch_amd.engine import RcclComm, RcclUnavailable
+    assert not torch.distributed.is_initialized()
+    with pytest.raises(RcclUnavailable):
+        RcclComm(world_size=2, rank=1)
+
+
+def test_bench_expected_line_carries_what_it_is_built_from():
+    import bench
+    w = bench.WORKLOADS["tgp_power_tanh3x2"]
+    e1 = bench.expected_line("tgp_power_tanh3x2", w, 1, "strong", 10540)
+    e8 = bench.expected_line("tgp_power_tanh3x2", w, 8, "strong", 10540)
+    assert e1["value"] > e8["value"] > 0 and "ESTIMATE" in e8["basis"]
+    assert bench.allreduce_estimate_us(1, 10540) == 0.0 and bench.allreduce_estimate_us(8, 10540) > bench.allreduce_estimate_us(2, 10540)

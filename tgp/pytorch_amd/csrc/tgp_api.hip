@@ -82,8 +82,13 @@ size_t tgp_workspace_bytes(int32_t N, int32_t D, int32_t M, int32_t S, int32_t n
 
 size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
                                   int32_t kernel) {
+  return tgp_workspace_bytes_plan(N, D, M, S, nblk, P, RP, kernel, 0);
+}
+
+size_t tgp_workspace_bytes_plan(int32_t N, int32_t D, int32_t M, int32_t S, int32_t nblk, int32_t P, int32_t RP,
+                                int32_t kernel, int32_t plan) {
   if (M > TGP_FUSED_MAX_M || kernel != TGP_KERNEL_SCALE_RBF)
-    return big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel) * sizeof(double);
+    return big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel, plan) * sizeof(double);
   Plan p;
   if (make_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW) != 0) return 0;
   size_t d = p.total + (size_t)(plan_alloc_blocks(N) - p.nblocks) * p.slab_len;   // slabs for whichever row kernel runs
@@ -91,10 +96,12 @@ size_t tgp_workspace_bytes_kernel(int32_t N, int32_t D, int32_t M, int32_t S, in
   if (lik > d) d = lik;
   // A training step whose flow stack does not fit a CU's LDS beside the row kernel's tiles (M > 112 with a 5 x 6 tanh flow)
   // runs on the general-M path (elbo_step_impl): room for that path too.  The program is not known here; an upper bound
-  // of its stack slots (SAL: 3 per block; step-tanh: 1 + K per block with 4 K parameters) decides.
-  const int slots_ub = (nblk + P / 4) > 3 * nblk ? nblk + P / 4 : 3 * nblk;
+  // of its stack slots decides: a block has at most 3 slots (SAL) or 1 + K (step-tanh, whose 4 K parameters are counted in P, or in
+  // RP when they are per-row), so 3 nblk + (P + RP) / 4 bounds every mix of blocks (max(nblk + P/4, 3 nblk) did not --
+  // SAL + step-tanh(K = 10) has 14 slots against a "bound" of 12)
+  const int slots_ub = 3 * nblk + (P + RP) / 4;
   if (nblk > 0 && !rows_train_lds_fits(p, slots_ub)) {
-    const size_t big = big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel);
+    const size_t big = big_workspace_doubles(N, D, M, S, nblk, P, RP, kernel, plan);
     if (big > d) d = big;
   }
   return d * sizeof(double);
@@ -169,10 +176,10 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik)) return rc;
   p.nslots = fp.nslots;
-  if (const int nw4 = choose_rows4(p, true)) {
+  if (const int nw4 = choose_rows4(p, true, model->plan)) {
     if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, nw4)) return rc;
     p.nslots = fp.nslots;
-  } else if (const int rw = rows_per_wave(p, fp, true); rw != 16) {
+  } else if (const int rw = rows_per_wave(p, fp, true, model->plan); rw != 16) {
     if (int rc = make_plan(p, model->N, model->D, model->M, model->S, nblk, P, RP, model->lik, 0, rw)) return rc;
     p.nslots = fp.nslots;
   }
@@ -217,7 +224,7 @@ int tgp_qf_moments_f64(const tgp_model* model, const double* X, double* mu, doub
   if (model->M > TGP_FUSED_MAX_M || model->kernel != TGP_KERNEL_SCALE_RBF) return launch_big_moments(md, X, mu, v, status, ws, workspace_bytes / sizeof(double), st);
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS)) return rc;
-  if (const int nw4 = choose_rows4(p, false))
+  if (const int nw4 = choose_rows4(p, false, model->plan))
     if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_GAUSS, nw4)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   FlowProg fp;
@@ -253,7 +260,7 @@ int tgp_qf_moments_bwd_f64(const tgp_model* model, const double* X, const double
   }
   Plan p;
   if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_ADJOINT)) return rc;
-  if (const int nw4 = choose_rows4(p, true))
+  if (const int nw4 = choose_rows4(p, true, model->plan))
     if (int rc = make_plan(p, model->N, model->D, model->M, 1, 0, 0, 0, TGP_LIK_ADJOINT, nw4)) return rc;
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
   if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;

@@ -15,7 +15,6 @@
 //   backward  : Lbar = -tril(w s^T + 2 H' G), Lambar = 2 tril(G Lq) - kl(...), Q = Phi(L^T Lbar) + Phi(.)^T,
 //               Kbar_MM = 1/2 J^T Q J, U = (Kbar_MM o K_MM) [Zs, Zs^2, 1], parameter gradients.
 // Replaces the same reference lines as tgp_mm.hip / tgp_rows.hpp (models/sparse_MF_SP.py:274-431,552-626).
-#include <cstdlib>
 #include "tgp_dev.hpp"
 #include "tgp_gemm.hpp"
 #include "tgp_launch.hpp"
@@ -50,24 +49,13 @@ struct BigPlan {
   size_t total;
 };
 
-static int big_chunk_max() {
-  static int v = 0;
-  if (v == 0) {
-    const char* e = getenv("TGP_BIG_CHUNK");  // test hook: force several chunks at small N
-    int x = e ? atoi(e) : BIG_NCMAX;
-    if (x < 128) x = 128;
-    v = (x + 127) / 128 * 128;
-  }
-  return v;
-}
-
-static bool big_overlap_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TGP_BIG_OVERLAP");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v != 0;
+// tgp_model.plan (include/tgp_hip.h): chunk size and chunk-pipeline overlap are properties of the CALL (they
+// were process-global environment switches read once)
+static int big_chunk_max(int plan) {
+  int x = TGP_PLAN_CHUNK_OF(plan);
+  if (x <= 0) x = BIG_NCMAX;
+  if (x < 128) x = 128;
+  return (x + 127) / 128 * 128;
 }
 
 // helper stream + events for the chunk pipeline (created once per host thread)
@@ -99,7 +87,7 @@ static BigPlan plan_parity(const BigPlan& p, int par) {
   return q;
 }
 
-static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int kernel) {
+static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P, int RP, int lik, int kernel, int plan = 0) {
   if (D < 1 || D > 16) return -2;
   if (M < 1 || M > TGP_BIG_MAX_M) return TGP_E_UNSUPPORTED;
   // (M <= 128 with the RBF kernel normally takes the fused path; tgp_api.hip sends it here when the flow stack of a training
@@ -108,7 +96,7 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.N = N; p.D = D; p.M = M; p.S = S; p.nblk = nblk; p.P = P; p.RP = RP; p.lik = lik;
   p.MP = (M + 127) / 128 * 128;
   p.DP = D <= 4 ? 4 : (D <= 8 ? 8 : 16);
-  const int ncmax = big_chunk_max();
+  const int ncmax = big_chunk_max(plan);
   p.nchunks = (N + ncmax - 1) / ncmax;
   if (p.nchunks < 1) p.nchunks = 1;
   p.NC = (int)rup((size_t)(N + p.nchunks - 1) / p.nchunks, 128);
@@ -144,7 +132,7 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.Xaug = o; o += (size_t)p.NC * BIG_XW;
   p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
   p.cstride = 0;
-  if (p.nchunks >= 2 && big_overlap_enabled()) {
+  if (p.nchunks >= 2 && !(plan & TGP_PLAN_NO_CHUNK_OVERLAP)) {
     p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
     o += p.cstride;
   }
@@ -170,9 +158,9 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   return 0;
 }
 
-size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel) {
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel, int plan) {
   BigPlan p;
-  if (make_big_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW, kernel) != 0) return 0;
+  if (make_big_plan(p, N, D, M, S, nblk, P, RP, TGP_LIK_FLOW, kernel, plan) != 0) return 0;
   return p.total;
 }
 
@@ -1668,7 +1656,7 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
 int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
                        size_t ws_doubles, hipStream_t st) {
   BigPlan p;
-  if (int rc = make_big_plan(p, md.N, md.D, md.M, 1, 0, 0, 0, TGP_LIK_GAUSS, md.kernel)) return rc;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, 1, 0, 0, 0, TGP_LIK_GAUSS, md.kernel, md.plan)) return rc;
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
   if (int rc = big_prepare(p, md, ws, status, false, st)) return rc;
   for (int ci = 0; ci < p.nchunks; ++ci) {
@@ -1683,7 +1671,7 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
                     uint32_t phases, hipStream_t st) {
   BigPlan p;
-  if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik, md.kernel)) return rc;
+  if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik, md.kernel, md.plan)) return rc;
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
   const int MP = p.MP, NC = p.NC;
   const size_t mm = (size_t)MP * MP;

@@ -51,16 +51,16 @@ int launch_cholesky(const double* A, int M, double* L, double* Linv, int32_t* st
 
 // tgp_rows.hip
 // which row kernel a plan gets: 0 = k_rows (16 rows per wave), else the waves per workgroup of k_rows4 (4 rows per wave)
-int choose_rows4(const Plan& p, bool train);
+int choose_rows4(const Plan& p, bool train, int sel = 0);
 // data rows per wave of k_rows for this plan (16, or 10: training with the flow likelihood at Power-like sizes)
-int rows_per_wave(const Plan& p, const FlowProg& fp, bool train);
+int rows_per_wave(const Plan& p, const FlowProg& fp, bool train, int sel = 0);
 // does the training launch of the row kernel fit a CU's LDS with `nslots` flow-stack slots (its leanest form: one node in flight)?
 bool rows_train_lds_fits(const Plan& p, int nslots);
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
                 const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
 // tgp_big.hip (general-M path, 128 < M <= TGP_BIG_MAX_M)
-size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel);
+size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel, int plan = 0);
 int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
                     uint32_t phases, hipStream_t st);

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep_a(Plan p, tgp_model md, F
 #endif
   if (tid == 0 && cb == 0) {   // (block 1 arrives at the same three words)
     status[0] = s_sync != 0 ? TGP_STATUS_SYNC_TIMEOUT : s_info;
+    if (s_sync != 0) __hip_atomic_fetch_add(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: see report_sync_timeout
     status[1] = s_nan;
     status[2] = s_info == 0 ? attempt : 0;
   }
@@ -504,13 +505,29 @@ __device__ __forceinline__ void bwd_leave(int32_t* sb) {
 // Bounded wait of a WORKGROUP for a count of this launch: wave 0 polls, the others wait at the barrier (every polling wave is
 // one more uncached request stream to the same line, and the producers' traffic shares that channel).  A wait that runs to
 // its bound is reported in status[0].
+// A timeout is STICKY: status[3] counts the expired waits since the caller last zeroed it and no launch of the
+// library ever clears it -- status[0] is rewritten by the next step's prepare launch, so inside a replayed graph of U steps only
+// a timeout of the last step would be seen there.  Both words are written as agent-scope atomics: the final role reads
+// status[0] past its L1 before the update (bwd_timed_out).
+__device__ __forceinline__ void report_sync_timeout(int32_t* __restrict__ status) {
+  __hip_atomic_store(status, (int32_t)TGP_STATUS_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <class P>
 __device__ __forceinline__ void bwd_wait(const int32_t* w, P pred, int32_t* __restrict__ status) {
   if (threadIdx.x < 64) {
     const int v = sync_wait(w, pred);
-    if (v == (int)0x80000000 && threadIdx.x == 0) status[0] = TGP_STATUS_SYNC_TIMEOUT;
+    if (v == (int)0x80000000 && threadIdx.x == 0) {
+      report_sync_timeout(status);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the report has landed before this workgroup's other waves look for it
+    }
   }
   __syncthreads();
+}
+// true when a wait of THIS step has expired: the prepare launch's (it leaves the value in status[0]) or one of this launch's
+// whose role has counted itself since (a role drains its stores, the report among them, before it counts)
+__device__ __forceinline__ bool bwd_timed_out(const int32_t* __restrict__ status) {
+  return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)TGP_STATUS_SYNC_TIMEOUT;
 }
 
 // G(:, c) -> LDS, s(c-block) -> LDS, Lbar block zeroed (both column roles), in two steps so that
@@ -565,7 +582,7 @@ __device__ __forceinline__ d4 tile_mm_regA(const double (&a)[PF], FB fb, int n, 
 // Lam block c: dELBO/dLam(c-rows, :) = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)) (strict upper = 0), and Adam on those rows
 //   X(j, c) = sum_{k >= j} Lq[k, j]^T G[k, c]  ==  (G Lq)(c, j)^T ; rows of dLam = block c, cols = block j
 __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md, const tgp_grads& g, double* __restrict__ ws,
-                                             const AdamDev& ad, double* sm, int c) {
+                                             const AdamDev& ad, double* sm, int c, const int32_t* __restrict__ status) {
   static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one tile per wave");
   const int MP = p.MP, MT = p.MT, M = p.M;
   double* Gs = sm;                     // MP x 16
@@ -586,7 +603,7 @@ __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md,
   double lq[PF];
 #pragma unroll
   for (int s_ = 0; s_ < PF; ++s_) lq[s_] = s_ < n ? Lq[(size_t)(j0 + 4 * s_ + q) * MP + j0 + r] : 0.0;
-  const bool upd = ad.p != nullptr;
+  const bool upd = ad.p != nullptr && !bwd_timed_out(status);   // (the prepare launch's report; this role waits for nothing itself)
   const double step = upd ? (double)(ad.step_dev[0] + 1) : 1.0;
   double lamv[4], am[4], av[4];
   long ei[4];
@@ -833,6 +850,9 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
     zjf = Zs[j * DP + dd];
   }
   bwd_wait(sb + SB_PROG, [&](int x) { return (x >> 24) >= 2 * MT; }, status);
+  // a hand-off of this step expired (this wait, a row role's, the prepare launch's): the gradients below are built from stale
+  // operands -- no update, no step, NaN scalars; status[3] keeps the event for the host
+  const bool timed_out = bwd_timed_out(status);
   BW_STAMP(true, 12);
   double* csL = gl + (mirror ? n_rest : 0);      // M: the plain column sums cs_j, formed by the d = D items for the others
   for (int base = 0; base < nitems; base += NT) {
@@ -879,14 +899,14 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
       const double s2b = c_svb + s / s2;
       put(g.raw_os, 0, s2b * c_sig);
       put(g.log_var_noise, 0, c_etab);
-      const double ell = c_ell, kl = c_kl;
-      out[0] = ell - kl;
-      out[1] = ell;
-      out[2] = kl;
+      const double ell = c_ell, kl = c_kl, nan_ = __builtin_nan("");
+      out[0] = timed_out ? nan_ : ell - kl;
+      out[1] = timed_out ? nan_ : ell;
+      out[2] = timed_out ? nan_ : kl;
       out[3] = 0.0;
     }
   }
-  if (ad.p != nullptr) {
+  if (ad.p != nullptr && !timed_out) {
     if (mirror) __syncthreads();
     else handoff_barrier();  // this workgroup's gradient stores have landed
     const double bc1 = 1.0 - exp_fast(a_step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(a_step * ad.ln_b2));
@@ -912,7 +932,7 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   __syncthreads();   // EVERY wave of this workgroup has seen the count before it is zeroed (a wave still polling would never see it again)
   if (tid == 0) {
     sync_st(sb + SB_PROG, 0); sync_st(sb + SB_LEFT, 0);
-    if (ad.p != nullptr) atomicAdd(&ad.step_dev[0], 1);
+    if (ad.p != nullptr && !timed_out) atomicAdd(&ad.step_dev[0], 1);
   }
   BW_STAMP(true, 15);
 }
@@ -927,7 +947,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_g
     bwd_q_role(p, ws, sm, b, sb);
     bwd_leave(sb);
   } else if (b < 2 * MT) {
-    bwd_lam_role(p, md, g, ws, ad, sm, b - MT);
+    bwd_lam_role(p, md, g, ws, ad, sm, b - MT, status);
     bwd_leave(sb);
   } else if (b < 4 * MT) {
     bwd_row_role(p, ws, sm, (b - 2 * MT) >> 1, (b - 2 * MT) & 1, sb, status);

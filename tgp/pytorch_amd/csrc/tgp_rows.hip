@@ -1,8 +1,6 @@
 // tgp_rows.hip -- dispatch of the fused row kernel over its compile-time tilings (MT = ceil(M/16), DP)
 #include "tgp_rows.hpp"
 #include "tgp_launch.hpp"
-#include <cstdio>
-#include <cstdlib>
 
 namespace tgp {
 
@@ -13,28 +11,26 @@ size_t rows4_lds_bytes(const Plan& p, bool train, int nw);   // tgp_rows_inst.hi
 
 // Which row kernel: the 4-rows-per-wave kernel (tgp_rows4.hpp) where it measured faster -- a training launch (any
 // likelihood) whose row blocks and passenger blocks number at most one per CU with one to spare (rows4_waves, tgp_dev.hpp: up to 32 (255 - MT)
-// rows) -- and where its LDS plan fits a CU.  TGP_ROWS4=0 forces the
-// 16-row kernel, TGP_ROWS4=<4|8> a workgroup size (A/B measurements, tools/probes/rows_kernel_time.py).
-int choose_rows4(const Plan& p, bool train) {
-  static const int env = [] { const char* e = getenv("TGP_ROWS4"); return e ? atoi(e) : -1; }();
-  if (env == 0 || !train) return 0;
+// rows) -- and where its LDS plan fits a CU.  `sel` = tgp_model.plan & TGP_PLAN_ROWS_MASK: the caller's override for THIS call
+// (A/B measurements, tests of a specific kernel); the selection is a property of the call, not of the process.
+int choose_rows4(const Plan& p, bool train, int sel) {
+  sel &= TGP_PLAN_ROWS_MASK;
+  if (sel == TGP_PLAN_ROWS_K16 || sel == TGP_PLAN_ROWS_K || !train) return 0;
   int nw = rows4_waves(p.N, p.MT);
-  if (env == 4 || env == 8) nw = env;
+  if (sel == TGP_PLAN_ROWS4_NW4) nw = 4;
+  if (sel == TGP_PLAN_ROWS4_NW8) nw = 8;
   if (nw == 0) return 0;
   if ((p.N + 4 * nw - 1) / (4 * nw) > plan_alloc_blocks(p.N)) return 0;   // (a forced size the workspace has no slabs for)
   const size_t need = rows4_lds_bytes(p, train, nw);
-  static const bool verbose = getenv("TGP_ROWS4_VERBOSE") != nullptr;
-  if (verbose) fprintf(stderr, "[tgp] choose_rows4: N %d MT %d nslots %d -> nw %d, LDS %zu B\n", p.N, p.MT, p.nslots, nw, need);
   if (need > 160 * 1024 - 2048) return 0;
   return nw;
 }
 
 // Rows per wave of k_rows: TGP_RW_SMALL (10) for a training launch with the flow likelihood and whose
 // (row, node) pairs fill the lanes in one trip (10 S <= 64 x 5) at the sizes rows_rw() names, if the LDS plan fits; else 16.
-// TGP_ROWS_RW=16 forces 16 (A/B measurements).
-int rows_per_wave(const Plan& p, const FlowProg& fp, bool train) {
-  static const int env = [] { const char* e = getenv("TGP_ROWS_RW"); return e ? atoi(e) : 0; }();
-  if (!train || env == 16 || p.lik != TGP_LIK_FLOW || p.nblk < 1) return 16;
+// sel == TGP_PLAN_ROWS_K16 forces 16.
+int rows_per_wave(const Plan& p, const FlowProg& fp, bool train, int sel) {
+  if (!train || (sel & TGP_PLAN_ROWS_MASK) == TGP_PLAN_ROWS_K16 || p.lik != TGP_LIK_FLOW || p.nblk < 1) return 16;
   for (int b = 0; b < fp.nblk; ++b)      // per-row parameters: SAL blocks only (their per-pair partials use the block's own stack slots)
     if ((fp.blk[4 * b + 3] & TGP_FLAG_PER_ROW) && fp.blk[4 * b] != TGP_FLOW_SAL) return 16;
   if (rows_rw(p.N) != TGP_RW_SMALL || TGP_RW_SMALL * p.S > 64 * TGP_RW_NODES) return 16;

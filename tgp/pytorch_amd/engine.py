@@ -4,7 +4,7 @@ ELBO -> (-ELBO).backward() -> Adam.step()) with everything resident on the GPU.
 * every trainable tensor is a view into ONE flat float64 buffer (parameters, gradients, Adam moments),
   so the optimiser is a single launch and the multi-GPU exchange is a single all-reduce;
 * the C-ABI argument structs are built once (pointers never change), so one step is
-  `tgp_elbo_step_adam_f64` = 6 kernel launches (M <= 128) with no host synchronisation, plus
+  `tgp_elbo_step_adam_f64` = 4 kernel launches (M <= 128) with no host synchronisation, plus
   the MLP forward/backward launches for input-dependent flows;
 * `capture()` records that sequence into a HIP graph (torch.cuda.CUDAGraph is only the stream/graph
   plumbing) and `replay()` re-launches it;
@@ -48,7 +48,8 @@ class RcclUnavailable(RuntimeError):
     them take the same fallback branch)."""
 
 
-_COMM_GENERATION = [0]     # communicators built by this process (every rank builds them in the same order)
+COMM_TIMEOUT_S = 120.0     # default bound of the communicator bootstrap (RcclComm(timeout_s=...), ElboEngine(comm_timeout_s=...))
+_COMM_GENERATION = {}      # communicators built per group (key = the group's global ranks), counted by the group's rank 0
 
 
 def _store_rendezvous(tag, world_size, timeout_s):
@@ -78,20 +79,28 @@ class RcclComm:
     with a timeout, and the init call itself runs under a watchdog: a rank that cannot complete it raises TimeoutError
     (tgp_last_error() in the message) instead of hanging -- the caller exits non-zero, nothing re-execs."""
 
-    def __init__(self, world_size=1, rank=0, group=None, timeout_s=None):
+    def __init__(self, world_size=1, rank=0, group=None, timeout_s=None, uid=None):
         import ctypes as C
         import threading
-        timeout_s = float(os.environ.get("TGP_COMM_TIMEOUT_S", "120")) if timeout_s is None else float(timeout_s)
+        timeout_s = COMM_TIMEOUT_S if timeout_s is None else float(timeout_s)
         self.comm = None
         self.lib = L.load()
         dist = torch.distributed
-        multi = world_size > 1 and dist.is_initialized()
+        multi = world_size > 1 and dist.is_initialized() and uid is None
+        if world_size > 1 and not multi and uid is None:
+            # (ADVICE r5) a hand-made world: nothing here can carry rank 0's id to the others, and ncclCommInitRank with an
+            # all-zero id never returns -- say so instead of hanging
+            raise RcclUnavailable("RcclComm(world_size=%d) needs torch.distributed initialised (the id travels through its "
+                                  "object broadcast) or the 128-byte id of rank 0 passed as `uid`" % world_size)
+        given = uid
         uid = (C.c_char * 128)()
+        if given is not None:
+            uid.raw = bytes(given)[:128].ljust(128, b"\0")
         err = None
         try:
             path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")   # the RCCL this process already holds
             L.check(self.lib.tgp_comm_load(path.encode() if os.path.exists(path) else None), "tgp_comm_load")
-            if rank == 0:
+            if rank == 0 and given is None:
                 L.check(self.lib.tgp_comm_unique_id(C.cast(uid, C.c_void_p)), "tgp_comm_unique_id")
         except Exception as e:                      # (kept: all ranks must reach the agreement below)
             err = e
@@ -103,12 +112,16 @@ class RcclComm:
                 raise RcclUnavailable("tgp_comm bootstrap failed on %s: %s" % ("this rank" if err is not None else "another rank",
                                                                               err if err is not None else "see its log"))
             src = dist.get_global_rank(group, 0) if group is not None else 0
-            box = [bytes(uid.raw)]
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            key = "-".join(str(r) for r in ranks)
+            # the rendezvous tag's generation is rank 0's count FOR THIS GROUP and travels with the id (a process-global
+            # counter differs between ranks that are members of different sub-groups, and equal tags are what the ranks meet at)
+            if rank == 0:
+                _COMM_GENERATION[key] = _COMM_GENERATION.get(key, 0) + 1
+            box = [bytes(uid.raw), _COMM_GENERATION.get(key, 0)]
             dist.broadcast_object_list(box, src=src, group=group)
             uid.raw = box[0]
-            _COMM_GENERATION[0] += 1
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            tag = "tgp_comm_init/%d/%s" % (_COMM_GENERATION[0], "-".join(str(r) for r in ranks))
+            tag = "tgp_comm_init/%d/%s" % (int(box[1]), key)
             _store_rendezvous(tag, len(ranks), timeout_s)
         elif err is not None:
             raise RcclUnavailable(str(err))
@@ -124,7 +137,7 @@ class RcclComm:
             except Exception as e:
                 res["exc"] = e
 
-        if multi:
+        if world_size > 1:                           # any multi-rank init can block on a missing peer: always under the watchdog
             th = threading.Thread(target=_init, daemon=True)
             th.start()
             th.join(timeout_s)
@@ -223,7 +236,7 @@ class ElboEngine:
     def __init__(self, X, Y, params, N_total, flow_blocks=None, S=None, rowp=None, lr=0.01, betas=(0.9, 0.999),
                  eps=1e-8, device="cuda:0", world_size=1, rank=0, mb_global=None, process_group=None,
                  kernel="scale_rbf", mlp=None, mlp_weights=None, nn_weight_decay=1e-5, mlp_training=True,
-                 jitter_ladder=1e-8, share=None, collective=None):
+                 jitter_ladder=1e-8, share=None, collective=None, plan=0, comm_timeout_s=None):
         """`mlp` (ops.MlpSpec) + `mlp_weights` (packed, nnets * weights_per_net): input-dependent flow (ID_TGP) whose
         per-row parameters come from the HIP MLP kernels inside the step; `nn_weight_decay` is the reference's Adam
         group for the 'NNets' parameters (main.py:276-288).  `share` = another ElboEngine of the same model whose flat
@@ -256,7 +269,7 @@ class ElboEngine:
                     cw = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else self.world_size
                     cr = torch.distributed.get_rank(process_group) if torch.distributed.is_initialized() else self.rank
                     try:
-                        self.comm = RcclComm(cw, cr, process_group)
+                        self.comm = RcclComm(cw, cr, process_group, timeout_s=comm_timeout_s)
                         self._own_comm = True
                     except RcclUnavailable as e:
                         # every rank raised together (RcclComm's agreement step): with the automatic choice all of them
@@ -310,7 +323,7 @@ class ElboEngine:
         fp = self.fp
         self.md, self._keep = ops._model_struct(self.X, fp.view("Z"), fp.view("raw_ls"), fp.view("raw_os"), fp.view("m"),
                                                 fp.view("Lam"), fp.view("lvn"), scale, 0.0, 1.0 / self.world_size,
-                                                self.flow, fp.view("theta") if P else None, self.S, kernel)
+                                                self.flow, fp.view("theta") if P else None, self.S, kernel, plan)
         # psd_safe_cholesky's retry ladder (dsp/utils.py:256-269) runs on the device inside the captured step (fused path);
         # `jitter_ladder` is its base value (the reference: 1e-8 in float64, or cg.global_jitter), 0 disables it
         self.md.jitter_ladder = float(jitter_ladder or 0.0)
@@ -323,7 +336,7 @@ class ElboEngine:
         if RP:
             self.gs.rowp = L.ptr(self.g_rowp)
         self.ws = ops.workspace(self.N, self.D, self.M, self.md.S, self.md.nblk, self.md.P, self.md.RP, self.device,
-                                self.md.kernel)
+                                self.md.kernel, plan)
         self.mlp_ws = None
         if self.mlp is not None:
             d = self.mlp.struct(self.N, True)
@@ -650,7 +663,7 @@ class ElboEngine:
     def check_status(self):
         """Lazy Cholesky check (one sync): raises like the reference's psd_safe_cholesky would."""
         st = self.status.cpu()
-        if int(st[0]) == ops.STATUS_SYNC_TIMEOUT:
+        if int(st[0]) == ops.STATUS_SYNC_TIMEOUT or int(st[3]):    # st[3]: sticky count, survives the later steps of a replayed graph
             ops.raise_for_status(st)
         if int(st[1]):
             raise ops.NanError("cholesky: K_MM contains NaN")

@@ -20,11 +20,19 @@ _dp = C.c_void_p
 
 KERNEL_SCALE_RBF, KERNEL_SCALE_MATERN32 = 0, 1
 KERNELS = {"scale_rbf": KERNEL_SCALE_RBF, "scale_matern32": KERNEL_SCALE_MATERN32}
+# tgp_model.plan (include/tgp_hip.h TGP_PLAN_*): kernel-selection overrides of ONE call; 0 = the library's choice
+PLAN_ROWS_AUTO, PLAN_ROWS_K16, PLAN_ROWS_K, PLAN_ROWS4_NW4, PLAN_ROWS4_NW8 = 0, 1, 2, 3, 4
+PLAN_NO_CHUNK_OVERLAP = 16
+
+
+def plan_chunk_rows(n):
+    """TGP_PLAN_CHUNK_ROWS(n): row chunks of at most n rows on the general-M path."""
+    return (((int(n) + 127) // 128) & 0xffff) << 8
 
 
 class TgpModel(C.Structure):
     _fields_ = [("N", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("S", C.c_int32), ("nblk", C.c_int32),
-                ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("kernel", C.c_int32), ("reserved0", C.c_int32),
+                ("P", C.c_int32), ("RP", C.c_int32), ("lik", C.c_int32), ("kernel", C.c_int32), ("plan", C.c_int32),
                 ("scale", C.c_double),
                 ("jitter", C.c_double), ("kl_scale", C.c_double), ("jitter_ladder", C.c_double), ("Z", _dp), ("raw_ls", _dp), ("raw_os", _dp),
                 ("m", _dp), ("Lam", _dp), ("log_var_noise", _dp), ("theta", _dp), ("program", _dp), ("xs", _dp),
@@ -60,6 +68,7 @@ _SIGS = {
     "tgp_source_hash": (C.c_char_p, []),
     "tgp_workspace_bytes": (C.c_size_t, [C.c_int32] * 7),
     "tgp_workspace_bytes_kernel": (C.c_size_t, [C.c_int32] * 8),
+    "tgp_workspace_bytes_plan": (C.c_size_t, [C.c_int32] * 9),
     "tgp_kernel_matrix_f64": (C.c_int, [C.c_int32, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp]),
     "tgp_elbo_step_f64": (C.c_int, [C.POINTER(TgpModel), _dp, _dp, _dp, _dp, C.POINTER(TgpGrads), _dp, _dp, _dp, _dp,
                                     C.c_size_t, _dp]),

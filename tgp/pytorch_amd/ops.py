@@ -65,11 +65,11 @@ def kernel_id(kernel):
     return int(kernel)
 
 
-def workspace(N, D, M, S, nblk, P, RP, device, kernel=0):
-    key = (N, D, M, S, nblk, P, RP, str(device), torch.cuda.current_stream().cuda_stream, kernel)
+def workspace(N, D, M, S, nblk, P, RP, device, kernel=0, plan=0):
+    key = (N, D, M, S, nblk, P, RP, str(device), torch.cuda.current_stream().cuda_stream, kernel, int(plan))
     buf = _ws_cache.get(key)
     if buf is None:
-        nbytes = L.load().tgp_workspace_bytes_kernel(N, D, M, max(S, 1), nblk, P, RP, kernel)
+        nbytes = L.load().tgp_workspace_bytes_plan(N, D, M, max(S, 1), nblk, P, RP, kernel, int(plan))
         if nbytes == 0:
             raise L.TgpError("unsupported problem shape N=%d D=%d M=%d (this build: D<=16, M<=4096)" % (N, D, M))
         buf = torch.empty(nbytes // 8 + 16, dtype=torch.float64, device=device)
@@ -104,9 +104,10 @@ class FlowSpec:
         return FlowSpec(self.blocks, self.P, self.RP, device)
 
 
-def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel=0):
+def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel=0, plan=0):
     md = L.TgpModel()
     md.kernel = kernel_id(kernel)
+    md.plan = int(plan)          # lib.PLAN_*: which of the equivalent kernels this call runs; 0 = the library's choice
     md.N, md.D = X.shape[0], X.shape[1]
     md.M = m.numel()
     md.scale, md.jitter, md.kl_scale = float(scale), float(jitter), float(kl_scale)
@@ -125,7 +126,7 @@ def _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, fl
 
 
 def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=None, rowp=None, S=None, jitter=0.0,
-              kl_scale=1.0, mb_global=None, want_moments=False, kernel="scale_rbf"):
+              kl_scale=1.0, mb_global=None, want_moments=False, kernel="scale_rbf", plan=0):
     """One fused ELBO evaluation + all gradients on the GPU.  Returns (out[4], grads dict, status[8], (mu, v)); status[0..2] are the
     Cholesky words of include/tgp_hip.h, status[4..7] the in-launch hand-off words (zero before and after every call).
 
@@ -140,8 +141,8 @@ def elbo_step(X, Y, Z, raw_ls, raw_os, m, Lam, lvn, N_total, flow=None, theta=No
     N, D = X.shape
     M = m.numel()
     scale = float(N_total) / float(mb_global if mb_global is not None else N)
-    md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel)
-    ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev, md.kernel)
+    md, keep = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, scale, jitter, kl_scale, flow, theta, S, kernel, plan)
+    ws = workspace(N, D, M, md.S, md.nblk, md.P, md.RP, dev, md.kernel, plan)
     out = torch.empty(4, dtype=torch.float64, device=dev)
     status = torch.zeros(8, dtype=torch.int32, device=dev)
     g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
@@ -176,9 +177,14 @@ def raise_for_status(status, retrying=False):
     """Translate the device status words into the reference's exceptions; returns True if a retry with more
     jitter is needed."""
     info, nan = int(status[0]), int(status[1])
-    if info == STATUS_SYNC_TIMEOUT:
-        raise HandoffTimeoutError("a hand-off wait inside the prepare / backward launch expired (status[0] = %d): status[4..7] "
-                                  "must be zero before the first call and untouched while a call is in flight" % info)
+    sticky = int(status[3]) if len(status) > 3 else 0
+    if info == STATUS_SYNC_TIMEOUT or sticky:
+        # status[3] counts the expired waits since the caller last zeroed it: status[0] is rewritten by every prepare launch, so a
+        # timeout inside a replayed multi-step graph is only visible there
+        raise HandoffTimeoutError("a hand-off wait inside the prepare / backward launch expired (status[0] = %d, %d expired wait(s) "
+                                  "counted in status[3]): status[4..7] must be zero before the first call and untouched while a "
+                                  "call is in flight; the step's results are invalid and the fused update was skipped where the "
+                                  "launch could tell (Lam rows may have moved): restore the parameters" % (info, sticky))
     if nan:
         raise NanError("cholesky: K_MM contains NaN")
     return info != 0
@@ -236,7 +242,7 @@ class ElboFunction(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------
 # stand-alone operators
 # ---------------------------------------------------------------------------------------------------
-def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="scale_rbf", info=None):
+def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="scale_rbf", info=None, plan=0):
     """q(f) marginals (models/sparse_MF_SP.py:274-396): returns mu, v of shape (N,).  `info` (a dict) receives the
     jitter the factorisation ended with (info["jitter"]: the ladder of psd_safe_cholesky may have raised it)."""
     lib = L.load()
@@ -244,8 +250,8 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="sca
     Z, raw_ls, raw_os, m, Lam = (_c(t, "param") for t in (Z, raw_ls, raw_os, m, Lam))
     dev = X.device
     lvn = torch.zeros(1, dtype=torch.float64, device=dev)
-    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 1.0, None, None, None, kernel)
-    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel)
+    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 1.0, None, None, None, kernel, plan)
+    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel, plan)
     mu = torch.empty(X.shape[0], dtype=torch.float64, device=dev)
     v = torch.empty_like(mu)
     status = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -268,7 +274,7 @@ def qf_moments(X, Z, raw_ls, raw_os, m, Lam, jitter=0.0, check=True, kernel="sca
     return mu, v
 
 
-def qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, mu_bar, v_bar, jitter=0.0, kernel="scale_rbf"):
+def qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, mu_bar, v_bar, jitter=0.0, kernel="scale_rbf", plan=0):
     """Adjoint of qf_moments (tgp_qf_moments_bwd_f64): d(sum mu_bar*mu + v_bar*v)/d{Z, raw_ls, raw_os, m, Lam} as a dict."""
     lib = L.load()
     X = _c(X, "X")
@@ -278,8 +284,8 @@ def qf_moments_bwd(X, Z, raw_ls, raw_os, m, Lam, mu_bar, v_bar, jitter=0.0, kern
         raise ValueError("mu_bar / v_bar must have one entry per row of X")
     dev = X.device
     lvn = torch.zeros(1, dtype=torch.float64, device=dev)
-    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 0.0, None, None, None, kernel)
-    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel)
+    md, _ = _model_struct(X, Z, raw_ls, raw_os, m, Lam, lvn, 1.0, jitter, 0.0, None, None, None, kernel, plan)
+    ws = workspace(X.shape[0], X.shape[1], m.numel(), 1, 0, 0, 0, dev, md.kernel, plan)
     g = {"Z": torch.empty_like(Z), "raw_ls": torch.empty_like(raw_ls), "raw_os": torch.empty_like(raw_os),
          "m": torch.empty_like(m), "Lam": torch.empty_like(Lam)}
     glvn = torch.empty_like(lvn)
