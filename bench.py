@@ -303,6 +303,8 @@ def main():
                     "multi-GPU lease (with one rank: a 1-rank RCCL group, the launch overhead only)")
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="bound (s) of the communicator bootstrap; a rank that cannot "
                     "complete it ends the whole job with exit code 3")
+    ap.add_argument("--plan", type=int, default=0, help="tgp_model.plan of the engine's calls (include/tgp_hip.h TGP_PLAN_*): A/B of "
+                    "equivalent kernels, e.g. 32 = the general-M path's row statistics by kernels of their own; 0 = the library's choice")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
                     "--pmc pass, keyed by the source hash of the library it was measured on (default: "
                     "profiles/rows_traffic.json); a summary of other sources is rejected and roofline.traffic is null")
@@ -435,7 +437,7 @@ def run_bench(args, world, rank, dev, backend):
                      S=w["S"], device=dev, world_size=world, rank=rank, mb_global=n_global,
                      mlp=mlp[0] if mlp else None, mlp_weights=mlp[1] if mlp else None,
                      collective=(None if args.collective == "auto" else args.collective) if world > 1 else "torch",
-                     comm_timeout_s=args.comm_timeout)
+                     comm_timeout_s=args.comm_timeout, plan=args.plan)
     log("collective: %s" % json.dumps(eng.collective_info))
 
     def barrier():

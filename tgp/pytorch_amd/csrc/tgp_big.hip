@@ -6,12 +6,13 @@
 //
 //   prepare   : K_MM, blocked right-looking Cholesky (128-wide: in-LDS potrf+trtri of the diagonal block, panel and
 //               trailing update as GEMMs), block-row inverse J = L^-1, S = Lq Lq^T, H' = J^T (S - I), w = J^T m, KL
-//   row chunks: rows are processed NC (<= 16384) at a time; the chunk matrices are the TRANSPOSES of the DESIGN.md
-//               operands, laid out [NC][MP] (one data row = 8 KB contiguous), so that the triangular GEMMs stream
-//               contiguous 1 MB row blocks and the two reductions over rows (G, T) read k-major, fully coalesced:
-//               K' = K_NM -> A' = K' J^T -> B' = A' Lq -> (mu, v) -> likelihood (k_ell_gauss / k_ell_flow) ->
-//               Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T (GEMM epilogue) -> Kbar' = Abar' J ->
-//               T += (Kbar' o K')^T [xs, xs^2, 1] (split-K)   G += A'^T diag(vbar) A' (split-K SYRK)   s += A'^T mubar
+//   row chunks: rows are processed NC (<= 16384) at a time; the chunk matrices are the DESIGN.md operands themselves, laid out
+//               [MP][NC] ("m-major", round 6: the small M x M factor is op(A) of every product, the chunk matrix op(B), stored
+//               [k][n] -- the operand layout the GEMM runs fastest on; rounds 1-5 kept the transposes [NC][MP]):
+//               K = K_MN -> A = J K -> B = Lq^T A -> (mu, v): column sums formed in the epilogues of those two products ->
+//               likelihood (k_ell_gauss / k_ell_flow) -> Abar = (2 Lq B - 2 A) diag(vbar) + m mubar^T (GEMM epilogue, which also
+//               forms s += A mubar) -> Kbar = J^T Abar -> T += (Kbar o K) [xs, xs^2, 1] (split-K) -> G += A diag(vbar) A^T
+//               (split-K SYRK)
 //   backward  : Lbar = -tril(w s^T + 2 H' G), Lambar = 2 tril(G Lq) - kl(...), Q = Phi(L^T Lbar) + Phi(.)^T,
 //               Kbar_MM = 1/2 J^T Q J, U = (Kbar_MM o K_MM) [Zs, Zs^2, 1], parameter gradients.
 // Replaces the same reference lines as tgp_mm.hip / tgp_rows.hpp (models/sparse_MF_SP.py:274-431,552-626).
@@ -43,6 +44,9 @@ struct BigPlan {
   size_t Kc, A, B, Ab;
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
+  size_t cstat, sp;  // epilogue statistics: 3 x (MP/64) x NC column partials (sum A^2, sum m A, sum B^2); (NC/64) x MP row partials of A mubar
+  size_t JT, LqT;    // J^T and Lq^T, row-major (the products pick the stored orientation their tiling runs fastest on)
+  int fuse;          // row statistics in the GEMM epilogues (0: kernels of their own, TGP_PLAN_NO_EPI_STATS or 64 x 64 tiles)
   size_t cstride;  // second set of chunk buffers {Xaug, K', A', B', Abar'} (0 = none): forward of chunk c+1 overlaps backward of chunk c
   size_t Sk;  // split-K slabs of the M x M products
   size_t Kmmg, TpartK, TK, UK;  // MATERN32 only: derivative-weight K_MM, statistics of (Kbar o K) next to those of (Kbar o K_g)
@@ -136,6 +140,10 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
     p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
     o += p.cstride;
   }
+  p.cstat = o; o += (size_t)3 * (p.MP / 64) * p.NC;
+  p.sp = o; o += (size_t)(p.NC / 64) * p.MP;
+  p.JT = o; o += mm; p.LqT = o; o += mm;
+  p.fuse = (plan & TGP_PLAN_NO_EPI_STATS) ? 0 : 1;
   p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
   p.Gpart = o; o += (size_t)p.ksg * mm;
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
@@ -167,7 +175,7 @@ size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP
 // ---------------------------------------------------------------------------------------------------
 // GEMM launcher
 // ---------------------------------------------------------------------------------------------------
-template <bool TA, bool TB, bool MOD, bool EPI>
+template <bool TA, bool TB, bool MOD, int EPI>
 static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   static bool attr_done = false;
   const void* f = reinterpret_cast<const void*>(k_gemm<TA, TB, MOD, EPI>);
@@ -185,7 +193,7 @@ static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
-template <bool MOD, bool EPI>
+template <bool MOD, int EPI>
 static int launch_gemm_l(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
   if (ta && tb) return launch_gemm_t<true, true, MOD, EPI>(g, st);
   if (ta) return launch_gemm_t<true, false, MOD, EPI>(g, st);
@@ -227,40 +235,62 @@ static int gemm_normalise(GemmArgs& g) {
 }
 static bool gemm_has_mod(const GemmArgs& g) { return g.a_mul != nullptr || g.k_scale != nullptr; }
 static bool gemm_has_epi(const GemmArgs& g) {
-  return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
+  // (rowv without colv is the weight vector of the EPI 2 column statistics, not a rank-1 term)
+  return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || (g.rowv && g.colv);
 }
 
 static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st);
 
+// Products without operand modifiers and with op(A) stored [m][k], one of whose operands may be triangular, whose 128 x 128
+// tiling leaves the chip mostly idle: 64 x 64 tiles (k_gemm64).  `g` normalised.
+// Times in units of one 128^3 k-block on a CU: the big tiling's longest workgroup / balance, against the small tiling's
+// (a 64^3 block is 1/8 of it, two resident workgroups share a CU).
+static bool gemm_small_tiles(bool ta, const GemmArgs& g) {
+  const int tB = g.tri & (TRI_B_LOWER | TRI_B_UPPER), tA = g.tri & (TRI_A_LOWER | TRI_A_UPPER);
+  if (ta || gemm_has_mod(g) || g.ksplit != 1 || (g.tri & TRI_C_LOWER) || (tA && tB) || g.k % 64 != 0) return false;
+  const long nrow = g.m / GT, nj = g.n / GT, kb = g.k / GT;
+  const long total = tB ? nrow * nj * (nj + 1) / 2 : (tA ? nj * nrow * (nrow + 1) / 2 : nrow * nj * kb);
+  const long longest = tB ? nj : (tA ? nrow : kb);
+  long big = g.pair ? ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1) : (total + 255) / 256;
+  if (!g.pair && big < longest) big = longest;
+  // small tiling, in eighths of a block time: total / 256 CUs, or the longest tile at half rate
+  const long nj2 = g.n / 64, rows2 = g.m / 64, kb2 = g.k / 64;
+  const long total2 = tB ? rows2 * nj2 * (nj2 + 1) / 2 : (tA ? nj2 * rows2 * (rows2 + 1) / 2 : rows2 * nj2 * kb2);
+  long small8 = (total2 + 255) / 256;
+  const long longest2 = 2 * (tB ? nj2 : (tA ? rows2 : kb2));
+  if (small8 < longest2) small8 = longest2;
+  return small8 * 10 < big * 8 * 7;   // predicted at least 30 % faster
+}
+
+// true when launch_gemm would run this product on k_gemm (128 x 128 tiles), whose epilogue can form the row / column
+// statistics (stat0 / stat1); k_gemm64 cannot
+bool gemm_runs_big_tiles(bool ta, bool tb, const GemmArgs& g_in) {
+  GemmArgs g = g_in;
+  if (gemm_normalise(g)) return false;
+  return !gemm_small_tiles(ta, g);
+}
+
 int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   if (gemm_normalise(g)) return -1;
-  {
-    // products without operand modifiers, with a (possibly triangular) op(B), whose 128 x 128 tiling leaves the chip mostly
-    // idle: 64 x 64 tiles.
-    // Times in units of one 128^3 k-block on a CU: the big tiling's longest workgroup / balance, against the small
-    // tiling's (a 64^3 block is 1/8 of it, two resident workgroups share a CU).
-    const bool plain = !ta && !gemm_has_mod(g) && g.ksplit == 1 && !(g.tri & ~(TRI_B_LOWER | TRI_B_UPPER)) && g.k % 64 == 0;
-    if (plain) {
-      const long nrow = g.m / GT, nj = g.n / GT, kb = g.k / GT;
-      const bool tri = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) != 0;
-      const long per_row = tri ? nj * (nj + 1) / 2 : nj * kb;
-      const long longest = tri ? nj : kb;
-      long big = g.pair ? ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1) : (nrow * per_row + 255) / 256;
-      if (!g.pair && big < longest) big = longest;
-      // small tiling, in eighths of a block time: total / 256 CUs, or the longest tile at half rate
-      const long nj2 = 2 * nj, rows2 = (g.m + 63) / 64;
-      const long per_row2 = tri ? nj2 * (nj2 + 1) / 2 : nj2 * 2 * kb;
-      long small8 = (rows2 * per_row2 + 255) / 256;
-      const long longest2 = 2 * (tri ? nj2 : 2 * kb);
-      if (small8 < longest2) small8 = longest2;
-      if (small8 * 10 < big * 8 * 7) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
-    }
+  const bool stats = g.stat0 != nullptr || g.stat1 != nullptr;
+  if (gemm_small_tiles(ta, g)) {
+    if (stats) return -1;   // (callers ask gemm_runs_big_tiles first)
+    return launch_gemm64(tb, g, st);
   }
-  const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
-  const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
-  if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
-  return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
+  const bool mod = gemm_has_mod(g), epi = gemm_has_epi(g);
+  if (stats) {
+    // the two statistic epilogues of the m-major chunk pipeline: plain product + column statistics (2), epilogue + row dots (3)
+    if (mod || tb || g.ksplit != 1) return -1;
+    if (epi) {
+      if (g.stat1 == nullptr || g.add == nullptr || g.colv == nullptr) return -1;
+      return ta ? launch_gemm_t<true, false, false, 3>(g, st) : launch_gemm_t<false, false, false, 3>(g, st);
+    }
+    if (g.stat0 == nullptr || (g.stat1 != nullptr && g.rowv == nullptr)) return -1;
+    return ta ? launch_gemm_t<true, false, false, 2>(g, st) : launch_gemm_t<false, false, false, 2>(g, st);
+  }
+  if (mod) return epi ? launch_gemm_l<true, 1>(ta, tb, g, st) : launch_gemm_l<true, 0>(ta, tb, g, st);
+  return epi ? launch_gemm_l<false, 1>(ta, tb, g, st) : launch_gemm_l<false, 0>(ta, tb, g, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -447,6 +477,8 @@ __device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, doubl
   int kb = 0, ke = g.k;
   if (g.tri & TRI_B_LOWER) kb = max(kb, j0);
   if (g.tri & TRI_B_UPPER) ke = min(ke, j0 + 64);
+  if (g.tri & TRI_A_LOWER) ke = min(ke, i0 + 64);
+  if (g.tri & TRI_A_UPPER) kb = max(kb, i0);
   d2 ra[8], rb[8];
   auto load_stage = [&](int k0) {
 #pragma unroll
@@ -545,12 +577,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm64(G64Args g, int gx, int gy8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char g64_smem[];
   double* As = reinterpret_cast<double*>(g64_smem);
   double* Bs = As + 64 * FAC_LD;
-  // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
-  const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
-  const int w = sq / nrx, by = xc + 8 * (sq % nrx);
-  int bx = w;
-  if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
-  if (by * 64 >= g.m) return;
+  int bx, by;
+  if (g.tri & (TRI_A_LOWER | TRI_A_UPPER)) {
+    // triangular op(A) (the m-major chunk products at small NC): heaviest tile rows first, natural XCD spread
+    const int L = blockIdx.x, wr = L / gx, gy = g.m / 64;
+    bx = L % gx;
+    by = (g.tri & TRI_A_UPPER) ? wr : gy - 1 - wr;
+    if (wr >= gy) return;
+  } else {
+    // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
+    const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
+    const int w = sq / nrx;
+    by = xc + 8 * (sq % nrx);
+    bx = w;
+    if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
+    if (by * 64 >= g.m) return;
+  }
   if (g.tb) g64_tile<true, EPI>(g, by * 64, bx * 64, As, Bs);
   else g64_tile<false, EPI>(g, by * 64, bx * 64, As, Bs);
 }
@@ -705,6 +747,21 @@ __global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double
   ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
   ws[p.J + e] = 0.0;
   ws[p.Lq + e] = lq;
+  // Lq^T beside it (the chunk products take whichever stored orientation their tiling runs fastest on): element (row, col) of
+  // the transpose read from Lam directly -- the strided access is a load, the stores stay coalesced
+  ws[p.LqT + e] = (row < M && col < M && row <= col) ? md.Lam[(size_t)col * M + row] : 0.0;
+}
+
+// dst = src^T (MP x MP, 32 x 32 tiles through LDS): J^T after the factorisation
+__global__ __launch_bounds__(256) void k_big_transpose(const double* __restrict__ src, double* __restrict__ dst, int MP) {
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) t[ty + 8 * u][tx] = src[(size_t)(i0 + ty + 8 * u) * MP + j0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) dst[(size_t)(j0 + ty + 8 * u) * MP + i0 + tx] = t[tx][ty + 8 * u];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1055,7 +1112,7 @@ __global__ __launch_bounds__(WVEC_THREADS) void k_big_wvec(BigPlan p, double* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// row-chunk kernels (matrices [MP][NC], column n = data row c0 + n)
+// row-chunk kernels (chunk matrices [MP][NC], column n = data row c0 + n)
 // ---------------------------------------------------------------------------------------------------
 // Xaug[n][:] = [xs, xs^2, 1, 0...] (zero rows for the padding)
 __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
@@ -1077,90 +1134,137 @@ __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __res
   ws[p.Xaug + e] = x;
 }
 
-// K'[n][m] = k(xs_n, zs_m) (gweight: its derivative weight k_g instead); block = 32 data rows x 128 inducing columns
+// K[m][n] = k(zs_m, xs_n) (gweight: its derivative weight k_g instead); block = 32 inducing rows x 128 data columns, a thread
+// keeps its data row's scaled coordinates in registers and walks 16 inducing rows (stores coalesced along n)
 __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws,
                                                   int gweight) {
-  __shared__ double xl[32 * 16];
-  const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7, DP = p.DP;
-  const int m = blockIdx.x * 128 + c, n0 = blockIdx.y * 32;
-  for (int i = tid; i < 32 * DP; i += 256) {
-    const int nl = i / DP, d = i % DP;
-    int n = n0 + nl;
-    n = n < nrows ? n : nrows - 1;  // padding rows repeat the last row: finite values, zero adjoints
-    xl[i] = d < p.D ? X[(size_t)n * p.D + d] * ws[p.ils + d] : 0.0;
-  }
-  double zs[16];
+  __shared__ double zl[32 * 16];
+  const int tid = threadIdx.x, c = tid & 127, mg = tid >> 7, DP = p.DP;
+  const int n = blockIdx.x * 128 + c, m0 = blockIdx.y * 32;
+  for (int i = tid; i < 32 * DP; i += 256) zl[i] = ws[p.Zs + (size_t)m0 * DP + i];
+  const int nn = n < nrows ? n : nrows - 1;  // padding columns repeat the last row: finite values, zero adjoints
+  double xs[16];
 #pragma unroll
-  for (int d = 0; d < 16; ++d) zs[d] = d < DP ? ws[p.Zs + (size_t)m * DP + d] : 0.0;
+  for (int d = 0; d < 16; ++d) xs[d] = d < p.D ? X[(size_t)nn * p.D + d] * ws[p.ils + d] : 0.0;
   __syncthreads();
   const double s2 = ws[p.hdr + H_S2];
   double* __restrict__ Kc = ws + p.Kc;
   for (int u = 0; u < 16; ++u) {
-    const int nl = rg * 16 + u;
+    const int ml = mg * 16 + u, m = m0 + ml;
     double d2 = 0.0;
     for (int d = 0; d < DP; ++d) {
-      const double t = xl[nl * DP + d] - zs[d];
+      const double t = xs[d] - zl[ml * DP + d];
       d2 += t * t;
     }
-    Kc[(size_t)(n0 + nl) * p.MP + m] = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
+    Kc[(size_t)m * p.NC + n] = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
   }
 }
 
-// mu_n = sum_m m_m A'_nm ; v_n = s2 - sum_m A'_nm^2 + sum_m B'_nm^2   (sparse_MF_SP.py:354-355,376-382); wave per row
+// mu_n = sum_m m_m A_mn ; v_n = s2 - sum_m A_mn^2 + sum_m B_mn^2   (sparse_MF_SP.py:354-355,376-382)
+// (a) from the column partials the two products left in their epilogues (EPI 2: one row of partials per 64 rows of A, B)
+__global__ __launch_bounds__(256) void k_big_moments_p(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
+                                                        double* __restrict__ v, int nrows) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= nrows) return;
+  const int np = p.MP / 64;
+  const double* __restrict__ pa = ws + p.cstat + n;
+  const double* __restrict__ pm = pa + (size_t)np * p.NC;
+  const double* __restrict__ pb = pm + (size_t)np * p.NC;
+  double sa = 0.0, sm = 0.0, sb = 0.0;
+  for (int k = 0; k < np; ++k) {
+    sa += pa[(size_t)k * p.NC];
+    sm += pm[(size_t)k * p.NC];
+    sb += pb[(size_t)k * p.NC];
+  }
+  mu[n] = sm;
+  v[n] = ws[p.hdr + H_S2] - sa + sb;
+}
+// (b) from the matrices (TGP_PLAN_NO_EPI_STATS, or products that ran on 64 x 64 tiles): block = 16 columns x 16 row phases
+// (128-byte row segments; NC / 16 blocks -- a small chunk is what takes this path, and 64-column blocks left it 20 workgroups)
 __global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
                                                       double* __restrict__ v, int nrows) {
-  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= nrows) return;
-  const double* __restrict__ A = ws + p.A + (size_t)n * p.MP;
-  const double* __restrict__ B = ws + p.B + (size_t)n * p.MP;
+  __shared__ double red[3][16][17];
+  const int tid = threadIdx.x, c = tid & 15, g = tid >> 4, n = blockIdx.x * 16 + c;
+  const double* __restrict__ A = ws + p.A + n;
+  const double* __restrict__ B = ws + p.B + n;
   const double* __restrict__ mp = ws + p.mpad;
   double sm = 0.0, sa = 0.0, sb = 0.0;
-  for (int m = 2 * lane; m < p.MP; m += 128) {
-    const d2 a = *reinterpret_cast<const d2*>(A + m), b = *reinterpret_cast<const d2*>(B + m);
-    const d2 mm_ = *reinterpret_cast<const d2*>(mp + m);
-    sm = fma(mm_[0], a[0], sm); sm = fma(mm_[1], a[1], sm);
-    sa = fma(a[0], a[0], sa); sa = fma(a[1], a[1], sa);
-    sb = fma(b[0], b[0], sb); sb = fma(b[1], b[1], sb);
+  for (int m = g; m < p.MP; m += 64) {       // MP is a multiple of 128: four rows per trip, all in range
+    double a[4], b[4], w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = A[(size_t)(m + 16 * u) * p.NC]; b[u] = B[(size_t)(m + 16 * u) * p.NC]; w[u] = mp[m + 16 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sm = fma(w[u], a[u], sm); sa = fma(a[u], a[u], sa); sb = fma(b[u], b[u], sb); }
   }
-  sm = wave_sum(sm); sa = wave_sum(sa); sb = wave_sum(sb);
-  if (lane == 0) {
-    mu[n] = sm;
-    v[n] = ws[p.hdr + H_S2] - sa + sb;
+  red[0][g][c] = sm; red[1][g][c] = sa; red[2][g][c] = sb;
+  __syncthreads();
+  if (g == 0 && n < nrows) {
+    double t[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double x = 0.0;
+#pragma unroll
+      for (int gg = 0; gg < 16; ++gg) x += red[k][gg][c];
+      t[k] = x;
+    }
+    mu[n] = t[0];
+    v[n] = ws[p.hdr + H_S2] - t[1] + t[2];
   }
 }
 
-// s_m partial (+)= sum_{n in row slab} A'[n][m] mubar_n : grid (MP/64, BIG_SSL), block = 64 columns x 4 row phases;
-// block (0, BIG_SSL) accumulates sum_n vbar_n
-__global__ __launch_bounds__(256) void k_big_coldot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
-  __shared__ double red[4][64];
-  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+// s_m partial (+)= sum over a column slab of A[m][n] mubar_n, BIG_SSL slabs per chunk; block (0, BIG_SSL) accumulates sum_n vbar_n
+// (a) from the row partials the Abar product left in its epilogue (EPI 3: one row of partials per 64 columns): thread per m
+__global__ __launch_bounds__(256) void k_big_sred(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
   if ((int)blockIdx.y == BIG_SSL) {
     if (blockIdx.x != 0) return;
     const double* __restrict__ vb = ws + p.vb + c0;
     double s = 0.0;
     for (int n = tid; n < p.NC; n += 256) s += vb[n];
     s = wave_sum(s);
-    if (c == 0) red[g][0] = s;
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
+    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
     return;
   }
-  const int m = blockIdx.x * 64 + c;
-  const int per = (p.NC + BIG_SSL - 1) / BIG_SSL, n0 = blockIdx.y * per, n1 = min(p.NC, n0 + per);
-  const double* __restrict__ A = ws + p.A;
+  const int m = blockIdx.x * 256 + tid, P = p.NC / 64;
+  const int per = (P + BIG_SSL - 1) / BIG_SSL, k0 = blockIdx.y * per, k1 = min(P, k0 + per);
+  double s = 0.0;
+  for (int k = k0; k < k1; ++k) s += ws[p.sp + (size_t)k * p.MP + m];
+  double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
+  *o = (accumulate ? *o : 0.0) + s;
+}
+// (b) from the matrix: a wave per (row m, slab), lanes along n
+__global__ __launch_bounds__(256) void k_big_coldot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  if ((int)blockIdx.y == BIG_SSL) {
+    if (blockIdx.x != 0) return;
+    const double* __restrict__ vb = ws + p.vb + c0;
+    double s = 0.0;
+    for (int n = tid; n < p.NC; n += 256) s += vb[n];
+    s = wave_sum(s);
+    if (lane == 0) red[g] = s;
+    __syncthreads();
+    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
+    return;
+  }
+  const int m = blockIdx.x * 4 + g;
+  const int per = ((p.NC + BIG_SSL - 1) / BIG_SSL + 63) & ~63, n0 = blockIdx.y * per, n1 = min(p.NC, n0 + per);
+  const double* __restrict__ A = ws + p.A + (size_t)m * p.NC;
   const double* __restrict__ mub = ws + p.mub + c0;
   double s0 = 0.0, s1 = 0.0;
-  int n = n0 + g;
-  for (; n + 4 < n1; n += 8) {
-    s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
-    s1 = fma(A[(size_t)(n + 4) * p.MP + m], mub[n + 4], s1);
+  int n = n0 + lane;
+  for (; n + 64 < n1; n += 128) {
+    s0 = fma(A[n], mub[n], s0);
+    s1 = fma(A[n + 64], mub[n + 64], s1);
   }
-  for (; n < n1; n += 4) s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
-  red[g][c] = s0 + s1;
-  __syncthreads();
-  if (g == 0) {
+  for (; n < n1; n += 64) s0 = fma(A[n], mub[n], s0);
+  const double s = wave_sum(s0 + s1);
+  if (lane == 0) {
     double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
-    *o = (accumulate ? *o : 0.0) + ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    *o = (accumulate ? *o : 0.0) + s;
   }
 }
 
@@ -1591,6 +1695,8 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
     hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
     LAUNCH_CHECK();
   }
+  hipLaunchKernelGGL(k_big_transpose, dim3(MP / 32, MP / 32), dim3(256), 0, st, ws + p.J, ws + p.JT, MP);   // (after the ladder: a retry rewrites J)
+  LAUNCH_CHECK();
   if (hipError_t e = hipStreamWaitEvent(sx, fk.ev[0], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   if (train) {
     hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, sx, p, md, ws);
@@ -1630,25 +1736,53 @@ static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, doubl
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
+  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
   LAUNCH_CHECK();
   return 0;
+}
+
+// The four triangular products of a chunk, C [MP][NC] = op(F) X with F one of the M x M factors (lower L-shaped: J, Lq; or their
+// transposes) and X a chunk matrix.  Both stored orientations of F exist (J / J^T, Lq / Lq^T): the 128 x 128 tiling reads
+// op(A) fastest k-major (TA: 58.8 against 55.9 TF/s at 15 744 rows, profiles/r06_gemm_mmajor_probe.txt), the 64 x 64 tiling of
+// small chunks wants it stored [m][k].  `F` = the factor stored row-major, `FT` = its transpose stored row-major; `upper`:
+// op(A) = F^T (upper triangular) instead of F.
+static GemmArgs chunk_product(const BigPlan& p, double* ws, size_t F, size_t FT, bool upper, const double* X, double* C, double alpha,
+                              bool* ta_out) {
+  const int MP = p.MP, NC = p.NC;
+  const int tri = upper ? TRI_A_UPPER : TRI_A_LOWER;
+  // stored [m][k]: op(A) = F -> F itself; op(A) = F^T -> FT.   stored [k][m] (TA): op(A) = F -> FT; op(A) = F^T -> F.
+  GemmArgs plain = gemm_args(ws + (upper ? FT : F), MP, X, NC, C, NC, MP, NC, MP, alpha, 0.0, tri);
+  plain.xcd = 6;
+  if (!gemm_runs_big_tiles(false, false, plain)) {
+    *ta_out = false;
+    return plain;
+  }
+  GemmArgs g = gemm_args(ws + (upper ? F : FT), MP, X, NC, C, NC, MP, NC, MP, alpha, 0.0, tri);
+  g.xcd = 6;
+  *ta_out = true;
+  return g;
 }
 
 // forward part of one chunk: Kc (unless `have_k`: made during the factorisation), A, B, moments
 static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, double* ws, double* mu, double* v, bool train,
                              hipStream_t st, bool have_k = false) {
-  const int MP = p.MP, NC = p.NC;
+  const int MP = p.MP, NC = p.NC, np = MP / 64;
   if (!have_k)
     if (int rc = big_chunk_kernel(p, Xc, nrows, ws, train, st)) return rc;
-  // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD
-  GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
-  a1.xcd = 1;
-  GEMM(false, true, a1);
-  GemmArgs a2 = gemm_args(ws + p.A, MP, ws + p.Lq, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
-  a2.xcd = 1;
-  GEMM(false, false, a2);
-  hipLaunchKernelGGL(k_big_moments, dim3((nrows + 3) / 4), dim3(256), 0, st, p, ws, mu, v, nrows);
+  // A = J K (J lower), B = Lq^T A (Lq^T upper); the column sums the moments need are formed in the epilogues (EPI 2) where
+  // the products run on 128 x 128 tiles
+  bool ta1, ta2;
+  GemmArgs a1 = chunk_product(p, ws, p.J, p.JT, false, ws + p.Kc, ws + p.A, 1.0, &ta1);
+  GemmArgs a2 = chunk_product(p, ws, p.Lq, p.LqT, true, ws + p.A, ws + p.B, 1.0, &ta2);
+  const bool fuse = p.fuse && ta1 && ta2;   // (ta = the 128 x 128 tiling was chosen)
+  if (fuse) {
+    a1.stat0 = ws + p.cstat; a1.stat1 = ws + p.cstat + (size_t)np * NC; a1.rowv = ws + p.mpad; a1.ldstat = NC;
+    a2.stat0 = ws + p.cstat + (size_t)2 * np * NC; a2.ldstat = NC;
+  }
+  GEMM(ta1, false, a1);
+  GEMM(ta2, false, a2);
+  if (fuse) hipLaunchKernelGGL(k_big_moments_p, dim3((nrows + 255) / 256), dim3(256), 0, st, p, ws, mu, v, nrows);
+  else hipLaunchKernelGGL(k_big_moments, dim3(NC / 16), dim3(256), 0, st, p, ws, mu, v, nrows);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1728,33 +1862,35 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       // (the G SYRK and s = A'^T mubar need only A', vbar, mubar and could run beside the chain Abar' -> Kbar' -> T on the
       //  fork stream: measured, the two branches take exactly the sum of their solo times -- the launches are bound by
       //  matrix throughput, not by idle CUs -- so they stay in line)
-      // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T
-      GemmArgs a3 = gemm_args(ws + pc.B, MP, ws + p.Lq, MP, ws + pc.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
-      a3.add = ws + pc.A; a3.ldadd = MP; a3.gamma = -2.0;
-      a3.row_scale = ws + p.vb + c0; a3.rowv = ws + p.mub + c0; a3.colv = ws + p.mpad;
-      a3.xcd = 1;
-      GEMM(false, true, a3);
-      // Kbar' = Abar' J  (into the B' buffer)
-      GemmArgs a4 = gemm_args(ws + pc.Ab, MP, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
-      a4.xcd = 1;
-      GEMM(false, false, a4);
-      // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
-      // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
-      GemmArgs at = gemm_args(ws + pc.B, MP, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+      // Abar = (2 Lq B - 2 A) diag(vbar) + m mubar^T ; the same epilogue forms the row partials of s = A mubar (EPI 3)
+      bool ta3, ta4;
+      GemmArgs a3 = chunk_product(pc, ws, p.Lq, p.LqT, false, ws + pc.B, ws + pc.Ab, 2.0, &ta3);
+      a3.add = ws + pc.A; a3.ldadd = NC; a3.gamma = -2.0;
+      a3.col_scale = ws + p.vb + c0; a3.rowv = ws + p.mpad; a3.colv = ws + p.mub + c0;
+      const bool fuse_s = p.fuse && ta3;
+      if (fuse_s) { a3.stat1 = ws + p.sp; a3.ldstat = MP; }
+      GEMM(ta3, false, a3);
+      // Kbar = J^T Abar  (into the B buffer)
+      GemmArgs a4 = chunk_product(pc, ws, p.J, p.JT, true, ws + pc.Ab, ws + pc.B, 1.0, &ta4);
+      GEMM(ta4, false, a4);
+      // T slabs (+)= (Kbar o K_g) Xaug.  RBF: K_g = K.  MATERN32: first the statistics with K itself (only their
+      // ones column is used: d/d outputscale), then K is overwritten by its derivative weight K_g
+      GemmArgs at = gemm_args(ws + pc.B, NC, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
       at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
       if (p.kernel != TGP_KERNEL_SCALE_RBF) {
         GemmArgs atk = at;
         atk.C = ws + p.TpartK;
-        GEMM(true, false, atk);
-        hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
+        GEMM(false, false, atk);
+        hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
         LAUNCH_CHECK();
       }
-      GEMM(true, false, at);
-      // G slabs (+)= A'^T diag(vbar) A', lower block triangle
-      GemmArgs ag = gemm_args(ws + pc.A, MP, ws + pc.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
+      GEMM(false, false, at);
+      // G slabs (+)= A diag(vbar) A^T, lower block triangle
+      GemmArgs ag = gemm_args(ws + pc.A, NC, ws + pc.A, NC, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
       ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;
-      GEMM(true, false, ag);
-      hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
+      GEMM(false, true, ag);
+      if (fuse_s) hipLaunchKernelGGL(k_big_sred, dim3(MP / 256, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
+      else hipLaunchKernelGGL(k_big_coldot, dim3(MP / 4, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
       LAUNCH_CHECK();
       if (aux) HIPCK(hipEventRecord(aux->eB[par], st));
     }

@@ -47,6 +47,12 @@ struct GemmArgs {
   const double* row_scale;
   const double* rowv;
   const double* colv;
+  // statistics of the output formed in the epilogue (EPI 2 / 3; nullptr = off), partial sums per 64-row / 64-column wave tile:
+  //   EPI 2: stat0[(i / 64) * ldstat + j] = sum over the 64 rows i.. of C[i][j]^2 ; stat1[...] = sum of rowv[i] C[i][j]
+  //   EPI 3: stat1[(j / 64) * ldstat + i] = sum over the 64 columns j.. of add[i][j] colv[j]
+  double* stat0;
+  double* stat1;
+  int ldstat;
   int ksplit;          // >= 1
   size_t cz;           // doubles between slab outputs
   int pair;            // set by the launcher: triangular op(B), column tiles j and n/128-1-j handled by one workgroup
@@ -54,6 +60,8 @@ struct GemmArgs {
                        // re-read the same op(A) rows), 2 all tiles of a k SLAB share an XCD (split-K operands),
                        // 3 (set by the launcher for TRI_C_LOWER + split-K) compact lower-triangle enumeration,
                        // 4 (set by the launcher for an unpaired triangular op(B)) per-XCD heavy-column-first order
+                       // 6 weight-ranked order for a triangular op(A) whose tiles are all computed (the m-major chunk
+                       //   products: small op(A), big op(B)): heaviest tile rows first, the second 256 ids in reverse
 };
 
 inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int n, int k,
@@ -63,6 +71,7 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
   g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.a_mul = nullptr; g.k_scale = nullptr; g.add = nullptr; g.ldadd = 0; g.gamma = 0.0;
   g.col_scale = nullptr; g.row_scale = nullptr; g.rowv = nullptr; g.colv = nullptr; g.ksplit = 1; g.cz = 0; g.xcd = 0; g.pair = 0;
+  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0;
   return g;
 }
 
@@ -144,12 +153,14 @@ __device__ __forceinline__ double gemm_frag(const double* __restrict__ L, int k,
   return KMAJ ? L[k * GLDK + x] : L[x * GLDX + k];
 }
 
-// MOD: a_mul / k_scale in use; EPI: the epilogue reads beta*C or gamma*add (separate instantiations: the plain
-// GEMM keeps its registers).
+// MOD: a_mul / k_scale in use; EPI: 0 = store only; 1 = the epilogue reads beta*C or gamma*add (separate instantiations: the
+// plain GEMM keeps its registers); 2 = store only + per-column statistics of the tile (stat0, stat1); 3 = 1 + per-row dot
+// products of the `add` tile with colv (stat1) -- the element-wise passes over the chunk matrices that used to be kernels of
+// their own (k_big_moments, k_big_coldot), formed while the tile is in registers (VERDICT r5 #1a).
 //
 // One 128 x 128 output tile.  Kept out of line on purpose: the kernel calls it once or twice (tile pairing) and the
 // register allocator, given the two calls inlined in a loop, spilled ~80 VGPRs of accumulator state.
-template <bool TA, bool TB, bool MOD, bool EPI>
+template <bool TA, bool TB, bool MOD, int EPI>
 __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, int j0, int bz, double* As, double* Bs) {
   // the kernel's only parameter, re-read from the kernarg segment with scalar loads instead of travelling through
   // the call in vector registers or scratch (the address arrives in VGPRs: make it provably uniform first)
@@ -228,7 +239,14 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
     // between two stores makes the second wait for the first to complete (one memory round trip per element).
     // EPI = 1: every optional read (row vectors once, column vectors and the beta*C / gamma*add matrix per
     // 16-column group) is issued ahead of the stores it feeds.  The launcher never sets beta and add together.
-    if (!EPI) {
+    if (EPI == 0 || EPI == 2) {
+      double rv2[4][4];
+      if (EPI == 2) {       // (requested ahead of the stores: loads and stores share vmcnt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) rv2[a][rr] = g.stat1 ? gemm_ld1(g.rowv + i0 + wi + 16 * a + q + 4 * rr) : 0.0;
+      }
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -236,46 +254,79 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
             gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r, g.alpha * acc[a][b][rr]);
+      if (EPI == 2) {
+        // column j of this wave's 64 x 64 tile: 16 rows in this lane's registers, then the four 16-lane groups (fixed order)
+        const size_t prow = (size_t)((i0 + wi) >> 6) * g.ldstat;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          double sq = 0.0, dt = 0.0;
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const double x = g.alpha * acc[a][b][rr];
+              sq = fma(x, x, sq);
+              dt = fma(rv2[a][rr], x, dt);
+            }
+          sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+          dt += __shfl_xor(dt, 16); dt += __shfl_xor(dt, 32);
+          if (q == 0) {
+            gemm_st1(g.stat0 + prow + j0 + wj + 16 * b + r, sq);
+            if (g.stat1) gemm_st1(g.stat1 + prow + j0 + wj + 16 * b + r, dt);
+          }
+        }
+      }
     } else {
+      // Tile-row group by tile-row group (a): what is live beside the 64 accumulators is one group's 16 elements of the extra
+      // matrix, its 4 + 4 row factors and the 4 + 4 column factors -- the column-group order of rounds 1-5 kept all 32 row
+      // factors (and, with the row dots of EPI 3, 16 running sums) live across the whole epilogue and spilled ~50 registers.
       const bool ha = g.add != nullptr;
       const double* __restrict__ E = ha ? g.add : C;
       const int lde = ha ? g.ldadd : g.ldc;
       const bool he = ha || g.beta != 0.0;
-      double rs[4][4], rv[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = i0 + wi + 16 * a + q + 4 * rr;
-          rs[a][rr] = g.row_scale ? gemm_ld1(g.row_scale + row) : 1.0;
-          rv[a][rr] = g.rowv ? gemm_ld1(g.rowv + row) : 0.0;
-        }
+      const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
+      double cs[4], cv[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int col = j0 + wj + 16 * b + r;
-        const double cs = g.col_scale ? gemm_ld1(g.col_scale + col) : 1.0;
-        const double cv = g.colv ? gemm_ld1(g.colv + col) : 0.0;
-        double ein[4][4];
+        cs[b] = g.col_scale ? gemm_ld1(g.col_scale + col) : 1.0;
+        cv[b] = g.colv ? gemm_ld1(g.colv + col) : 0.0;
+      }
+      const size_t pcol = EPI == 3 ? (size_t)((j0 + wj) >> 6) * g.ldstat : 0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a) {
+        double rs[4], rv[4], ein[4][4];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            ein[a][rr] = he ? gemm_ld1(E + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * lde + col) : 0.0;
-        const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = i0 + wi + 16 * a + q + 4 * rr;
+          rs[rr] = g.row_scale ? gemm_ld1(g.row_scale + row) : 1.0;
+          rv[rr] = g.rowv ? gemm_ld1(g.rowv + row) : 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 4; ++b) ein[b][rr] = he ? gemm_ld1(E + (size_t)row * lde + j0 + wj + 16 * b + r) : 0.0;
+        }
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            double x = g.alpha * acc[a][b][rr] + ca * ein[a][rr];
-            x = x * cs * rs[a][rr] + rv[a][rr] * cv + cb * ein[a][rr];
-            gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + col, x);
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = i0 + wi + 16 * a + q + 4 * rr;
+          double sd = 0.0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            double x = g.alpha * acc[a][b][rr] + ca * ein[b][rr];
+            x = x * cs[b] * rs[rr] + rv[rr] * cv[b] + cb * ein[b][rr];
+            gemm_st1(C + (size_t)row * g.ldc + j0 + wj + 16 * b + r, x);
+            if (EPI == 3) sd = fma(ein[b][rr], cv[b], sd);
           }
+          if (EPI == 3) {
+            // row `row` of this wave's tile: its 4 column groups are in sd, then the 16 lanes of the row's lane group
+            sd += __shfl_xor(sd, 1); sd += __shfl_xor(sd, 2); sd += __shfl_xor(sd, 4); sd += __shfl_xor(sd, 8);
+            if (r == 0) gemm_st1(g.stat1 + pcol + row, sd);
+          }
+        }
       }
     }
   }
 }
 
-template <bool TA, bool TB, bool MOD, bool EPI>
+template <bool TA, bool TB, bool MOD, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   double* As = reinterpret_cast<double*>(gemm_smem);  // 2 stage buffers
@@ -303,6 +354,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     by = xc + 8 * (sq % nrx);
     bx = (g.tri & TRI_B_LOWER) ? w : gx - 1 - w;
     if (by * GT >= g.m) return;   // the launcher rounds the tile rows up to a multiple of 8
+  } else if (g.xcd == 6) {
+    // Triangular op(A), every tile computed, k range growing with the tile row (TRI_A_LOWER) or shrinking (TRI_A_UPPER): ids in
+    // order of decreasing work.  On an idle chip ids i and i + 256 share a CU (two resident workgroups per CU, tools/probes/
+    // wg_placement.hip), so in plain decreasing order an 8-block tile meets a 5-block one (13 block times on that CU against
+    // an average of 11 at 10 000 rows); with ids 256..511 taken in REVERSE the heaviest tiles meet the lightest of that
+    // group (10-11).  Natural XCD spread: measured best for this shape (profiles/r06_gemm_mmajor_probe.txt).
+    const int gx = gridDim.x, gy = gridDim.y, W = gx * gy, L = bx + gx * by;
+    const int hi = W < 512 ? W : 512;
+    const int rk = (L >= 256 && L < hi) ? 256 + (hi - 1 - L) : L;
+    const int wr = rk / gx;                        // 0 = heaviest tile row
+    bx = rk % gx;
+    by = (g.tri & TRI_A_UPPER) ? wr : gy - 1 - wr;
   } else if (g.xcd == 3) {
     // compact split-K enumeration of the lower block triangle: gridDim.x = ntl * ksplit, slab-major, and the ids
     // that share an XCD (same id mod 8) take a contiguous run of (slab, tile) pairs -- equal load per XCD and the
@@ -336,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 // that does not depend on the current step rides in the same launches instead of costing launches -- or cross-queue
 // graph dependencies, ~10 us each under replay -- of its own.  The second GemmArgs sits behind the first in the kernel
 // argument segment (gemm_tile reads its arguments through scalar loads from that segment).
-template <bool TA1, bool TB1, bool MOD1, bool EPI1, bool TA2, bool TB2, bool MOD2, bool EPI2>
+template <bool TA1, bool TB1, bool MOD1, int EPI1, bool TA2, bool TB2, bool MOD2, int EPI2>
 __global__ __launch_bounds__(256, 2) void k_gemm_pair(GemmArgs a, GemmArgs b, int na, int gxa, int gya, int gxb, int gyb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   double* As = reinterpret_cast<double*>(gemm_smem);
