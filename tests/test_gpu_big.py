@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import rel_err
-from test_gpu_parity import compare, run_hip
+from test_gpu_parity import compare, run_hip, TOL_GRAD
 
 pytestmark = pytest.mark.gpu
 
@@ -67,9 +67,12 @@ def test_gemm_triangular_trimming():
                 assert float((blk - 7.0).abs().max()) == 0.0
 
 
-def _oracle_case(N, D, M, flow, S, seed=3, kernel="scale_rbf"):
+def _oracle_case(N, D, M, flow, S, seed=3, kernel="scale_rbf", lengthscale=None):
     from oracle import tgp_oracle as orc
     prob = orc.synthetic_problem(N, D, M, seed=seed, flow=flow, S=S)
+    if lengthscale is not None:       # softplus^-1 of the wanted lengthscale, every dimension
+        ls = torch.full((D,), float(lengthscale), dtype=torch.float64)
+        prob["params"]["raw_lengthscale"] = torch.log(torch.expm1(ls))
     (elbo, ell, kld), og = orc.elbo_and_grads(prob["X"], prob["Y"], prob["params"], prob["N_total"], prob["program"],
                                               prob["xs"], prob["ws"], prob["rowp"], kernel=kernel)
     g = dict(prob)
@@ -362,6 +365,28 @@ def _shard_step(N, lo=0, hi=None, mb_global=None, plan=0):
     torch.cuda.synchronize()
     assert int(st[0]) == 0 and int(st[1]) == 0
     return out.cpu(), {k: t.cpu() for k, t in g.items()}
+
+
+@pytest.mark.parametrize("N,D,flow,S", [(6100, 3, "sal2", 16), (6100, 13, None, 8)])
+def test_big_fused_statistics_epilogue_other_coordinate_widths(N, D, flow, S):
+    """The statistics T in the epilogue of the K_bar product (k_gemm EPI 4) contracts with 16 nct coordinate columns, nct =
+    ceil((2 DP + 1) / 16): D = 8 (the airline shape: nct = 2) is covered above; here D = 3 (nct = 1) and D = 13 (nct = 3), M = 1000
+    so that the chunk products run on 128 x 128 tiles, against the oracle -- and against the same step with the statistics
+    formed by kernels of their own (TGP_PLAN_NO_EPI_STATS)."""
+    from tgp.pytorch_amd import lib
+    # (1000 inducing points in 3 dimensions at the generator's lengthscale of 2 are numerically singular: 0.5 there)
+    g = _oracle_case(N, D, 1000, flow, S, seed=4, lengthscale=0.5 if D == 3 else None)
+    out, grads, status, _ = run_hip(g)
+    assert int(status[0]) == 0 and int(status[1]) == 0
+    o2, g2, st2, _ = run_hip(g, plan=lib.PLAN_NO_EPI_STATS)
+    assert int(st2[0]) == 0
+    assert rel_err(o2[:3], out[:3]) < 1e-11
+    for k in grads:
+        assert rel_err(g2[k], grads[k]) < 1e-9, (k, rel_err(g2[k], grads[k]))
+    assert any(not torch.equal(g2[k], grads[k]) for k in grads), "TGP_PLAN_NO_EPI_STATS ran the same kernels"
+    # (1000 inducing points in 3 dimensions: cond(K_MM) ~ 1e10 even at this lengthscale -- two correct float64 evaluations of
+    #  dELBO/dZ agree to ~4e-7 there; the two HIP paths above, sharing the factorisation, agree to 1e-9)
+    compare(out, grads, g, tol_grad=1e-6 if D == 3 else TOL_GRAD)
 
 
 def test_big_minibatch_step_is_bit_reproducible():

@@ -33,6 +33,7 @@ namespace tgp {
 #define BIG_NKL 64    /* KL partial blocks */
 #define BIG_SSL 32    /* row slabs of the s = A'^T mubar partial sums */
 #define BIG_NCMAX 16384
+static_assert(BIG_XW == GXW, "EPI 4 of k_gemm reads the augmented coordinates with this row length");
 
 struct BigPlan {
   int N, D, M, S, nblk, P, RP, lik, kernel;
@@ -41,7 +42,8 @@ struct BigPlan {
   size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb, spart;
   size_t Kmm, Lm, J, Lq, S_, Hp, G, Q, R1, tmp;
   size_t Zaug, U, T, Xaug;
-  size_t Kc, A, B, Ab;
+  size_t Kc, A, B, Ab, Kn;   // Kn: K once more, [NC][MP] (the layout the fused statistics epilogue multiplies its tile by)
+  size_t Tp2; int nct;       // EPI 4: per tile row of the K_bar product, 16 nct x MP partial statistics
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
   size_t cstat, sp;  // epilogue statistics: 3 x (MP/64) x NC column partials (sum A^2, sum m A, sum B^2); (NC/64) x MP row partials of A mubar
@@ -87,7 +89,7 @@ static BigAux* big_aux() {
 static BigPlan plan_parity(const BigPlan& p, int par) {
   BigPlan q = p;
   const size_t d = (size_t)par * p.cstride;
-  q.Xaug += d; q.Kc += d; q.A += d; q.B += d; q.Ab += d;
+  q.Xaug += d; q.Kc += d; q.A += d; q.B += d; q.Ab += d; q.Kn += d;
   return q;
 }
 
@@ -134,12 +136,14 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.U = o; o += (size_t)p.MP * BIG_XW;
   p.T = o; o += (size_t)p.MP * BIG_XW;
   p.Xaug = o; o += (size_t)p.NC * BIG_XW;
-  p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
+  p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn; p.Kn = o; o += mn;
   p.cstride = 0;
   if (p.nchunks >= 2 && !(plan & TGP_PLAN_NO_CHUNK_OVERLAP)) {
-    p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
+    p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab, Kn are contiguous
     o += p.cstride;
   }
+  p.nct = (2 * p.DP + 1 + 15) / 16;
+  p.Tp2 = o; o += (size_t)(p.NC / 128) * 16 * p.nct * p.MP;
   p.cstat = o; o += (size_t)3 * (p.MP / 64) * p.NC;
   p.sp = o; o += (size_t)(p.NC / 64) * p.MP;
   p.JT = o; o += mm; p.LqT = o; o += mm;
@@ -224,7 +228,10 @@ static int gemm_normalise(GemmArgs& g) {
     const long paired = ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1);
     long unpaired = (nrow * nj * (nj + 1) / 2 + 255) / 256;
     if (unpaired < nj) unpaired = nj;
-    if (unpaired * 108 < paired * 100) {
+    // (a product with a long epilogue -- EPI 4 reads a second tile and runs a contraction -- always unpaired: paired workgroups
+    //  are all equally long and reach their epilogues together, leaving the matrix pipes idle twice per launch; tiles of
+    //  different lengths overlap one workgroup's epilogue with the other's main loop)
+    if (unpaired * 108 < paired * 100 || g.nct > 0) {
       g.pair = 0;
       g.xcd = 4;
     }
@@ -273,12 +280,16 @@ bool gemm_runs_big_tiles(bool ta, bool tb, const GemmArgs& g_in) {
 int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   if (gemm_normalise(g)) return -1;
-  const bool stats = g.stat0 != nullptr || g.stat1 != nullptr;
+  const bool stats = g.stat0 != nullptr || g.stat1 != nullptr || g.nct > 0;
   if (gemm_small_tiles(ta, g)) {
     if (stats) return -1;   // (callers ask gemm_runs_big_tiles first)
     return launch_gemm64(tb, g, st);
   }
   const bool mod = gemm_has_mod(g), epi = gemm_has_epi(g);
+  if (g.nct > 0) {   // EPI 4: no C, the tile o add contracted over its rows with rowv (the statistics GEMM in the epilogue)
+    if (!ta || tb || mod || g.ksplit != 1 || g.add == nullptr || g.rowv == nullptr || g.stat1 == nullptr || g.beta != 0.0) return -1;
+    return launch_gemm_t<true, false, false, 4>(g, st);
+  }
   if (stats) {
     // the two statistic epilogues of the m-major chunk pipeline: plain product + column statistics (2), epilogue + row dots (3)
     if (mod || tb || g.ksplit != 1) return -1;
@@ -1136,9 +1147,11 @@ __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __res
 
 // K[m][n] = k(zs_m, xs_n) (gweight: its derivative weight k_g instead); block = 32 inducing rows x 128 data columns, a thread
 // keeps its data row's scaled coordinates in registers and walks 16 inducing rows (stores coalesced along n)
+// `both`: K also in the layout [NC][MP] (p.Kn), written from an LDS copy of the block so that both stores are coalesced
 __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws,
-                                                  int gweight) {
+                                                  int gweight, int both) {
   __shared__ double zl[32 * 16];
+  __shared__ double kl[128 * 33];
   const int tid = threadIdx.x, c = tid & 127, mg = tid >> 7, DP = p.DP;
   const int n = blockIdx.x * 128 + c, m0 = blockIdx.y * 32;
   for (int i = tid; i < 32 * DP; i += 256) zl[i] = ws[p.Zs + (size_t)m0 * DP + i];
@@ -1156,8 +1169,34 @@ __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __rest
       const double t = xs[d] - zl[ml * DP + d];
       d2 += t * t;
     }
-    Kc[(size_t)m * p.NC + n] = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
+    const double kv = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
+    Kc[(size_t)m * p.NC + n] = kv;
+    if (both) kl[c * 33 + ml] = kv;
   }
+  if (both) {
+    __syncthreads();
+    double* __restrict__ Kn = ws + p.Kn;
+    for (int e = tid; e < 128 * 32; e += 256) {      // row n of the block: 32 consecutive inducing columns
+      const int nl = e >> 5, ml = e & 31;
+      Kn[(size_t)(blockIdx.x * 128 + nl) * p.MP + m0 + ml] = kl[nl * 33 + ml];
+    }
+  }
+}
+
+// Tpart[z][m][c] (+)= sum over the tile-row slabs of slice z of the EPI 4 partials Tp2[slab][c][m]; the unused columns of T zeroed
+__global__ __launch_bounds__(256) void k_big_tred(BigPlan p, double* __restrict__ ws, int accumulate) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int m = (int)(e % p.MP), c = (int)(e / p.MP), z = blockIdx.y, nc = 16 * p.nct;
+  if (c >= BIG_XW) return;
+  double* o = ws + p.Tpart + (size_t)z * p.MP * BIG_XW + (size_t)m * BIG_XW + c;
+  if (c >= nc) {
+    if (!accumulate) *o = 0.0;
+    return;
+  }
+  const int nslab = p.NC / 128, per = (nslab + BIG_KST - 1) / BIG_KST, s0 = z * per, s1 = min(nslab, s0 + per);
+  double s = 0.0;
+  for (int k = s0; k < s1; ++k) s += ws[p.Tp2 + ((size_t)k * nc + c) * p.MP + m];
+  *o = (accumulate ? *o : 0.0) + s;
 }
 
 // mu_n = sum_m m_m A_mn ; v_n = s2 - sum_m A_mn^2 + sum_m B_mn^2   (sparse_MF_SP.py:354-355,376-382)
@@ -1729,6 +1768,14 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   return 0;
 }
 
+// The statistics T = (K_bar o K) [xs, xs^2, 1] in the epilogue of the product that forms K_bar (EPI 4; VERDICT r5 #1a): for the
+// RBF kernel (one weight matrix), when the chunk is large enough for 128 x 128 tiles, unless TGP_PLAN_NO_EPI_STATS
+static bool chunk_fuse_t(const BigPlan& p) {
+  if (!p.fuse || p.kernel != TGP_KERNEL_SCALE_RBF) return false;
+  GemmArgs g = gemm_args(nullptr, p.MP, nullptr, p.NC, nullptr, p.NC, p.MP, p.NC, p.MP, 1.0, 0.0, TRI_A_UPPER);
+  return gemm_runs_big_tiles(false, false, g);
+}
+
 // K' tiles of one chunk (and, for a training step, its augmented coordinates)
 static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, double* ws, bool train, hipStream_t st) {
   const int MP = p.MP, NC = p.NC;
@@ -1736,7 +1783,7 @@ static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, doubl
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
+  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0, (train && chunk_fuse_t(p)) ? 1 : 0);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1870,6 +1917,18 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       const bool fuse_s = p.fuse && ta3;
       if (fuse_s) { a3.stat1 = ws + p.sp; a3.ldstat = MP; }
       GEMM(ta3, false, a3);
+      if (chunk_fuse_t(p)) {
+        // K_bar^T = Abar^T J is formed tile by tile ([NC][MP] orientation: rows = data rows, the contraction index of T) and never
+        // stored: the epilogue multiplies the tile by K, contracts it with the chunk's augmented coordinates and leaves one
+        // 16 nct x MP partial per tile row; k_big_tred folds those into the T slabs
+        (void)ta4;
+        GemmArgs a4 = gemm_args(ws + pc.Ab, NC, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+        a4.xcd = 1;
+        a4.add = ws + pc.Kn; a4.ldadd = MP; a4.rowv = ws + pc.Xaug; a4.stat1 = ws + p.Tp2; a4.ldstat = MP; a4.nct = p.nct;
+        GEMM(true, false, a4);
+        hipLaunchKernelGGL(k_big_tred, dim3((unsigned)((size_t)MP * BIG_XW / 256), BIG_KST), dim3(256), 0, st, pc, ws, ci ? 1 : 0);
+        LAUNCH_CHECK();
+      } else {
       // Kbar = J^T Abar  (into the B buffer)
       GemmArgs a4 = chunk_product(pc, ws, p.J, p.JT, true, ws + pc.Ab, ws + pc.B, 1.0, &ta4);
       GEMM(ta4, false, a4);
@@ -1881,10 +1940,11 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
         GemmArgs atk = at;
         atk.C = ws + p.TpartK;
         GEMM(false, false, atk);
-        hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
+        hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1, 0);
         LAUNCH_CHECK();
       }
       GEMM(false, false, at);
+      }
       // G slabs (+)= A diag(vbar) A^T, lower block triangle
       GemmArgs ag = gemm_args(ws + pc.A, NC, ws + pc.A, NC, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
       ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;

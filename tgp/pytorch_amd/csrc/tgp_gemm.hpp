@@ -50,9 +50,14 @@ struct GemmArgs {
   // statistics of the output formed in the epilogue (EPI 2 / 3; nullptr = off), partial sums per 64-row / 64-column wave tile:
   //   EPI 2: stat0[(i / 64) * ldstat + j] = sum over the 64 rows i.. of C[i][j]^2 ; stat1[...] = sum of rowv[i] C[i][j]
   //   EPI 3: stat1[(j / 64) * ldstat + i] = sum over the 64 columns j.. of add[i][j] colv[j]
+  //   EPI 4 (no C store): the tile, multiplied element-wise by add[i][j], is contracted over its ROWS with the augmented
+  //          coordinates rowv[i][0 .. 16 nct) (row length GXW): stat1[((i / 128) * 16 nct + c) * ldstat + j] = sum over the tile's
+  //          128 rows of C[i][j] add[i][j] rowv[i][c] -- the statistics GEMM T of the general-M path in the epilogue of the
+  //          product that forms K_bar (tgp_big.hip)
   double* stat0;
   double* stat1;
   int ldstat;
+  int nct;
   int ksplit;          // >= 1
   size_t cz;           // doubles between slab outputs
   int pair;            // set by the launcher: triangular op(B), column tiles j and n/128-1-j handled by one workgroup
@@ -71,7 +76,7 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
   g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.a_mul = nullptr; g.k_scale = nullptr; g.add = nullptr; g.ldadd = 0; g.gamma = 0.0;
   g.col_scale = nullptr; g.row_scale = nullptr; g.rowv = nullptr; g.colv = nullptr; g.ksplit = 1; g.cz = 0; g.xcd = 0; g.pair = 0;
-  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0;
+  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0; g.nct = 0;
   return g;
 }
 
@@ -82,6 +87,7 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
 #define GLDX 17       /* x-major LDS stage [128][17]: odd stride, conflict-free stores of 128-byte global row segments */
 #define GSTAGE 2304   /* doubles per stage buffer = max(16*144, 128*17) */
 #define GEMM_LDS_BYTES (4 * GSTAGE * sizeof(double))
+#define GXW 128       /* row length of the augmented-coordinate matrix of EPI 4 (tgp_big.hip BIG_XW) */
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -239,7 +245,59 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
     // between two stores makes the second wait for the first to complete (one memory round trip per element).
     // EPI = 1: every optional read (row vectors once, column vectors and the beta*C / gamma*add matrix per
     // 16-column group) is issued ahead of the stores it feeds.  The launcher never sets beta and add together.
-    if (EPI == 0 || EPI == 2) {
+    if (EPI == 4) {
+      // E = alpha acc o add, in place (tile-row group by group: 16 loads in flight); lane (q, r), register (a, b, rr) holds row
+      // 16 a + q + 4 rr, column 16 b + r -- the B-operand layout of a 16 x 16 x 4 product whose k runs over rows 16 a + 4 rr + {0..3}
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        double kn[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            kn[b][rr] = gemm_ld1(g.add + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldadd + j0 + wj + 16 * b + r);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) acc[a][b][rr] = g.alpha * acc[a][b][rr] * kn[b][rr];
+      }
+      __syncthreads();      // every wave is done with the last stage: the stage buffers carry the cross-wave sums below
+      double* red = As;     // 64 lanes x 16 doubles per (column half, coordinate group)
+      for (int ct = 0; ct < g.nct; ++ct) {
+        d4 tacc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) tacc[b] = {0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          double xa[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) xa[rr] = gemm_ld1(g.rowv + (size_t)(i0 + wi + 16 * a + 4 * rr + q) * GXW + 16 * ct + r);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tacc[b] = TGP_MFMA(xa[rr], acc[a][b][rr], tacc[b]);
+        }
+        // tacc[b][rr'] = sum over this wave's 64 rows: coordinate 16 ct + q + 4 rr', column 16 b + r.  The two waves of a column
+        // half add up through LDS (upper row half first: fixed order), the lower one stores.
+        double* slot = red + ((size_t)(wave & 1) * 64 + lane) * 17;
+        if (wave >> 1) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) slot[4 * b + rr] = tacc[b][rr];
+        }
+        __syncthreads();
+        if (!(wave >> 1)) {
+          double* out = g.stat1 + ((size_t)(i0 >> 7) * 16 * g.nct + 16 * ct) * g.ldstat + j0 + wj;
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              gemm_st1(out + (size_t)(q + 4 * rr) * g.ldstat + 16 * b + r, tacc[b][rr] + slot[4 * b + rr]);
+        }
+        __syncthreads();    // the slots are free for the next coordinate group
+      }
+    } else if (EPI == 0 || EPI == 2) {
       double rv2[4][4];
       if (EPI == 2) {       // (requested ahead of the stores: loads and stores share vmcnt)
 #pragma unroll
