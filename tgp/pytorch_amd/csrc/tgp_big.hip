@@ -6,13 +6,12 @@
 //
 //   prepare   : K_MM, blocked right-looking Cholesky (128-wide: in-LDS potrf+trtri of the diagonal block, panel and
 //               trailing update as GEMMs), block-row inverse J = L^-1, S = Lq Lq^T, H' = J^T (S - I), w = J^T m, KL
-//   row chunks: rows are processed NC (<= 16384) at a time; the chunk matrices are the DESIGN.md operands themselves, laid out
-//               [MP][NC] ("m-major", round 6: the small M x M factor is op(A) of every product, the chunk matrix op(B), stored
-//               [k][n] -- the operand layout the GEMM runs fastest on; rounds 1-5 kept the transposes [NC][MP]):
-//               K = K_MN -> A = J K -> B = Lq^T A -> (mu, v): column sums formed in the epilogues of those two products ->
-//               likelihood (k_ell_gauss / k_ell_flow) -> Abar = (2 Lq B - 2 A) diag(vbar) + m mubar^T (GEMM epilogue, which also
-//               forms s += A mubar) -> Kbar = J^T Abar -> T += (Kbar o K) [xs, xs^2, 1] (split-K) -> G += A diag(vbar) A^T
-//               (split-K SYRK)
+//   row chunks: rows are processed NC (<= 16384) at a time; the chunk matrices are the TRANSPOSES of the DESIGN.md
+//               operands, laid out [NC][MP] (one data row = 8 KB contiguous), so that the triangular GEMMs stream
+//               contiguous 1 MB row blocks and the two reductions over rows (G, T) read k-major, fully coalesced:
+//               K' = K_NM -> A' = K' J^T -> B' = A' Lq -> (mu, v) -> likelihood (k_ell_gauss / k_ell_flow) ->
+//               Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T (GEMM epilogue) -> Kbar' = Abar' J ->
+//               T += (Kbar' o K')^T [xs, xs^2, 1] (split-K)   G += A'^T diag(vbar) A' (split-K SYRK)   s += A'^T mubar
 //   backward  : Lbar = -tril(w s^T + 2 H' G), Lambar = 2 tril(G Lq) - kl(...), Q = Phi(L^T Lbar) + Phi(.)^T,
 //               Kbar_MM = 1/2 J^T Q J, U = (Kbar_MM o K_MM) [Zs, Zs^2, 1], parameter gradients.
 // Replaces the same reference lines as tgp_mm.hip / tgp_rows.hpp (models/sparse_MF_SP.py:274-431,552-626).
@@ -42,12 +41,11 @@ struct BigPlan {
   size_t hdr, ils, ls, Zs, mpad, w, sv, klpart, svb, spart;
   size_t Kmm, Lm, J, Lq, S_, Hp, G, Q, R1, tmp;
   size_t Zaug, U, T, Xaug;
-  size_t Kc, A, B, Ab, Kn;   // Kn: K once more, [NC][MP] (the layout the fused statistics epilogue multiplies its tile by)
+  size_t Kc, A, B, Ab;
   size_t Tp2; int nct;       // EPI 4: per tile row of the K_bar product, 16 nct x MP partial statistics
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
-  size_t cstat, sp;  // epilogue statistics: 3 x (MP/64) x NC column partials (sum A^2, sum m A, sum B^2); (NC/64) x MP row partials of A mubar
-  size_t JT, LqT;    // J^T and Lq^T, row-major (the products pick the stored orientation their tiling runs fastest on)
+  size_t cstat, sp;  // epilogue statistics: 3 x (MP/64) x NC row partials (sum A'^2, sum m A', sum B'^2); (NC/64) x MP column partials of A'^T mubar
   int fuse;          // row statistics in the GEMM epilogues (0: kernels of their own, TGP_PLAN_NO_EPI_STATS or 64 x 64 tiles)
   size_t cstride;  // second set of chunk buffers {Xaug, K', A', B', Abar'} (0 = none): forward of chunk c+1 overlaps backward of chunk c
   size_t Sk;  // split-K slabs of the M x M products
@@ -89,7 +87,7 @@ static BigAux* big_aux() {
 static BigPlan plan_parity(const BigPlan& p, int par) {
   BigPlan q = p;
   const size_t d = (size_t)par * p.cstride;
-  q.Xaug += d; q.Kc += d; q.A += d; q.B += d; q.Ab += d; q.Kn += d;
+  q.Xaug += d; q.Kc += d; q.A += d; q.B += d; q.Ab += d;
   return q;
 }
 
@@ -136,17 +134,16 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
   p.U = o; o += (size_t)p.MP * BIG_XW;
   p.T = o; o += (size_t)p.MP * BIG_XW;
   p.Xaug = o; o += (size_t)p.NC * BIG_XW;
-  p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn; p.Kn = o; o += mn;
+  p.Kc = o; o += mn; p.A = o; o += mn; p.B = o; o += mn; p.Ab = o; o += mn;
   p.cstride = 0;
   if (p.nchunks >= 2 && !(plan & TGP_PLAN_NO_CHUNK_OVERLAP)) {
-    p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab, Kn are contiguous
+    p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
     o += p.cstride;
   }
   p.nct = (2 * p.DP + 1 + 15) / 16;
   p.Tp2 = o; o += (size_t)(p.NC / 128) * 16 * p.nct * p.MP;
   p.cstat = o; o += (size_t)3 * (p.MP / 64) * p.NC;
   p.sp = o; o += (size_t)(p.NC / 64) * p.MP;
-  p.JT = o; o += mm; p.LqT = o; o += mm;
   p.fuse = (plan & TGP_PLAN_NO_EPI_STATS) ? 0 : 1;
   p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
   p.Gpart = o; o += (size_t)p.ksg * mm;
@@ -287,18 +284,19 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   }
   const bool mod = gemm_has_mod(g), epi = gemm_has_epi(g);
   if (g.nct > 0) {   // EPI 4: no C, the tile o add contracted over its rows with rowv (the statistics GEMM in the epilogue)
-    if (!ta || tb || mod || g.ksplit != 1 || g.add == nullptr || g.rowv == nullptr || g.stat1 == nullptr || g.beta != 0.0) return -1;
-    return launch_gemm_t<true, false, false, 4>(g, st);
+    if (ta || tb || mod || g.ksplit != 1 || g.add == nullptr || g.rowv == nullptr || g.stat1 == nullptr || g.beta != 0.0) return -1;
+    return launch_gemm_t<false, false, false, 4>(g, st);
   }
   if (stats) {
-    // the two statistic epilogues of the m-major chunk pipeline: plain product + column statistics (2), epilogue + row dots (3)
-    if (mod || tb || g.ksplit != 1) return -1;
+    // the statistic epilogues of the chunk pipeline: plain product + row / column statistics of C (2), epilogue + dots of the
+    // `add` tile (3)
+    if (mod || ta || g.ksplit != 1) return -1;
     if (epi) {
-      if (g.stat1 == nullptr || g.add == nullptr || g.colv == nullptr) return -1;
-      return ta ? launch_gemm_t<true, false, false, 3>(g, st) : launch_gemm_t<false, false, false, 3>(g, st);
+      if (g.stat1 == nullptr || g.add == nullptr || g.colv == nullptr || g.rowv == nullptr || !tb) return -1;
+      return launch_gemm_t<false, true, false, 3>(g, st);
     }
-    if (g.stat0 == nullptr || (g.stat1 != nullptr && g.rowv == nullptr)) return -1;
-    return ta ? launch_gemm_t<true, false, false, 2>(g, st) : launch_gemm_t<false, false, false, 2>(g, st);
+    if (g.stat0 == nullptr || (g.stat1 != nullptr && (g.statdir ? g.colv : g.rowv) == nullptr)) return -1;
+    return tb ? launch_gemm_t<false, true, false, 2>(g, st) : launch_gemm_t<false, false, false, 2>(g, st);
   }
   if (mod) return epi ? launch_gemm_l<true, 1>(ta, tb, g, st) : launch_gemm_l<true, 0>(ta, tb, g, st);
   return epi ? launch_gemm_l<false, 1>(ta, tb, g, st) : launch_gemm_l<false, 0>(ta, tb, g, st);
@@ -758,21 +756,6 @@ __global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double
   ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
   ws[p.J + e] = 0.0;
   ws[p.Lq + e] = lq;
-  // Lq^T beside it (the chunk products take whichever stored orientation their tiling runs fastest on): element (row, col) of
-  // the transpose read from Lam directly -- the strided access is a load, the stores stay coalesced
-  ws[p.LqT + e] = (row < M && col < M && row <= col) ? md.Lam[(size_t)col * M + row] : 0.0;
-}
-
-// dst = src^T (MP x MP, 32 x 32 tiles through LDS): J^T after the factorisation
-__global__ __launch_bounds__(256) void k_big_transpose(const double* __restrict__ src, double* __restrict__ dst, int MP) {
-  __shared__ double t[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) t[ty + 8 * u][tx] = src[(size_t)(i0 + ty + 8 * u) * MP + j0 + tx];
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 4; ++u) dst[(size_t)(j0 + ty + 8 * u) * MP + i0 + tx] = t[tx][ty + 8 * u];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1123,7 +1106,7 @@ __global__ __launch_bounds__(WVEC_THREADS) void k_big_wvec(BigPlan p, double* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// row-chunk kernels (chunk matrices [MP][NC], column n = data row c0 + n)
+// row-chunk kernels (matrices [MP][NC], column n = data row c0 + n)
 // ---------------------------------------------------------------------------------------------------
 // Xaug[n][:] = [xs, xs^2, 1, 0...] (zero rows for the padding)
 __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws) {
@@ -1145,41 +1128,32 @@ __global__ __launch_bounds__(256) void k_big_xaug(BigPlan p, const double* __res
   ws[p.Xaug + e] = x;
 }
 
-// K[m][n] = k(zs_m, xs_n) (gweight: its derivative weight k_g instead); block = 32 inducing rows x 128 data columns, a thread
-// keeps its data row's scaled coordinates in registers and walks 16 inducing rows (stores coalesced along n)
-// `both`: K also in the layout [NC][MP] (p.Kn), written from an LDS copy of the block so that both stores are coalesced
+// K'[n][m] = k(xs_n, zs_m) (gweight: its derivative weight k_g instead); block = 32 data rows x 128 inducing columns
 __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __restrict__ X, int nrows, double* __restrict__ ws,
-                                                  int gweight, int both) {
-  __shared__ double zl[32 * 16];
-  __shared__ double kl[128 * 33];
-  const int tid = threadIdx.x, c = tid & 127, mg = tid >> 7, DP = p.DP;
-  const int n = blockIdx.x * 128 + c, m0 = blockIdx.y * 32;
-  for (int i = tid; i < 32 * DP; i += 256) zl[i] = ws[p.Zs + (size_t)m0 * DP + i];
-  const int nn = n < nrows ? n : nrows - 1;  // padding columns repeat the last row: finite values, zero adjoints
-  double xs[16];
+                                                  int gweight) {
+  __shared__ double xl[32 * 16];
+  const int tid = threadIdx.x, c = tid & 127, rg = tid >> 7, DP = p.DP;
+  const int m = blockIdx.x * 128 + c, n0 = blockIdx.y * 32;
+  for (int i = tid; i < 32 * DP; i += 256) {
+    const int nl = i / DP, d = i % DP;
+    int n = n0 + nl;
+    n = n < nrows ? n : nrows - 1;  // padding rows repeat the last row: finite values, zero adjoints
+    xl[i] = d < p.D ? X[(size_t)n * p.D + d] * ws[p.ils + d] : 0.0;
+  }
+  double zs[16];
 #pragma unroll
-  for (int d = 0; d < 16; ++d) xs[d] = d < p.D ? X[(size_t)nn * p.D + d] * ws[p.ils + d] : 0.0;
+  for (int d = 0; d < 16; ++d) zs[d] = d < DP ? ws[p.Zs + (size_t)m * DP + d] : 0.0;
   __syncthreads();
   const double s2 = ws[p.hdr + H_S2];
   double* __restrict__ Kc = ws + p.Kc;
   for (int u = 0; u < 16; ++u) {
-    const int ml = mg * 16 + u, m = m0 + ml;
+    const int nl = rg * 16 + u;
     double d2 = 0.0;
     for (int d = 0; d < DP; ++d) {
-      const double t = xs[d] - zl[ml * DP + d];
+      const double t = xl[nl * DP + d] - zs[d];
       d2 += t * t;
     }
-    const double kv = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
-    Kc[(size_t)m * p.NC + n] = kv;
-    if (both) kl[c * 33 + ml] = kv;
-  }
-  if (both) {
-    __syncthreads();
-    double* __restrict__ Kn = ws + p.Kn;
-    for (int e = tid; e < 128 * 32; e += 256) {      // row n of the block: 32 consecutive inducing columns
-      const int nl = e >> 5, ml = e & 31;
-      Kn[(size_t)(blockIdx.x * 128 + nl) * p.MP + m0 + ml] = kl[nl * 33 + ml];
-    }
+    Kc[(size_t)(n0 + nl) * p.MP + m] = m < p.M ? (gweight ? cov_gweight(p.kernel, s2, d2) : cov_value(p.kernel, s2, d2)) : 0.0;
   }
 }
 
@@ -1199,8 +1173,31 @@ __global__ __launch_bounds__(256) void k_big_tred(BigPlan p, double* __restrict_
   *o = (accumulate ? *o : 0.0) + s;
 }
 
-// mu_n = sum_m m_m A_mn ; v_n = s2 - sum_m A_mn^2 + sum_m B_mn^2   (sparse_MF_SP.py:354-355,376-382)
-// (a) from the column partials the two products left in their epilogues (EPI 2: one row of partials per 64 rows of A, B)
+// mu_n = sum_m m_m A'_nm ; v_n = s2 - sum_m A'_nm^2 + sum_m B'_nm^2   (sparse_MF_SP.py:354-355,376-382); wave per row
+__global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
+                                                      double* __restrict__ v, int nrows) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= nrows) return;
+  const double* __restrict__ A = ws + p.A + (size_t)n * p.MP;
+  const double* __restrict__ B = ws + p.B + (size_t)n * p.MP;
+  const double* __restrict__ mp = ws + p.mpad;
+  double sm = 0.0, sa = 0.0, sb = 0.0;
+  for (int m = 2 * lane; m < p.MP; m += 128) {
+    const d2 a = *reinterpret_cast<const d2*>(A + m), b = *reinterpret_cast<const d2*>(B + m);
+    const d2 mm_ = *reinterpret_cast<const d2*>(mp + m);
+    sm = fma(mm_[0], a[0], sm); sm = fma(mm_[1], a[1], sm);
+    sa = fma(a[0], a[0], sa); sa = fma(a[1], a[1], sa);
+    sb = fma(b[0], b[0], sb); sb = fma(b[1], b[1], sb);
+  }
+  sm = wave_sum(sm); sa = wave_sum(sa); sb = wave_sum(sb);
+  if (lane == 0) {
+    mu[n] = sm;
+    v[n] = ws[p.hdr + H_S2] - sa + sb;
+  }
+}
+
+// The same from the row partials the two products left in their epilogues (EPI 2, statdir 1: one row of partials per 64
+// columns of A', B'); k_big_moments is the stand-alone form (TGP_PLAN_NO_EPI_STATS, or products that ran on 64 x 64 tiles)
 __global__ __launch_bounds__(256) void k_big_moments_p(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
                                                         double* __restrict__ v, int nrows) {
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -1218,41 +1215,9 @@ __global__ __launch_bounds__(256) void k_big_moments_p(BigPlan p, double* __rest
   mu[n] = sm;
   v[n] = ws[p.hdr + H_S2] - sa + sb;
 }
-// (b) from the matrices (TGP_PLAN_NO_EPI_STATS, or products that ran on 64 x 64 tiles): block = 16 columns x 16 row phases
-// (128-byte row segments; NC / 16 blocks -- a small chunk is what takes this path, and 64-column blocks left it 20 workgroups)
-__global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
-                                                      double* __restrict__ v, int nrows) {
-  __shared__ double red[3][16][17];
-  const int tid = threadIdx.x, c = tid & 15, g = tid >> 4, n = blockIdx.x * 16 + c;
-  const double* __restrict__ A = ws + p.A + n;
-  const double* __restrict__ B = ws + p.B + n;
-  const double* __restrict__ mp = ws + p.mpad;
-  double sm = 0.0, sa = 0.0, sb = 0.0;
-  for (int m = g; m < p.MP; m += 64) {       // MP is a multiple of 128: four rows per trip, all in range
-    double a[4], b[4], w[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = A[(size_t)(m + 16 * u) * p.NC]; b[u] = B[(size_t)(m + 16 * u) * p.NC]; w[u] = mp[m + 16 * u]; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { sm = fma(w[u], a[u], sm); sa = fma(a[u], a[u], sa); sb = fma(b[u], b[u], sb); }
-  }
-  red[0][g][c] = sm; red[1][g][c] = sa; red[2][g][c] = sb;
-  __syncthreads();
-  if (g == 0 && n < nrows) {
-    double t[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double x = 0.0;
-#pragma unroll
-      for (int gg = 0; gg < 16; ++gg) x += red[k][gg][c];
-      t[k] = x;
-    }
-    mu[n] = t[0];
-    v[n] = ws[p.hdr + H_S2] - t[1] + t[2];
-  }
-}
 
-// s_m partial (+)= sum over a column slab of A[m][n] mubar_n, BIG_SSL slabs per chunk; block (0, BIG_SSL) accumulates sum_n vbar_n
-// (a) from the row partials the Abar product left in its epilogue (EPI 3: one row of partials per 64 columns): thread per m
+// s partials from the column partials the Abar' product left in its epilogue (EPI 3, statdir 1: one row of partials per 64 data
+// rows): thread per m; block (0, BIG_SSL) accumulates sum_n vbar_n.  k_big_coldot below is the stand-alone form.
 __global__ __launch_bounds__(256) void k_big_sred(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
   __shared__ double red[4];
   const int tid = threadIdx.x;
@@ -1274,36 +1239,39 @@ __global__ __launch_bounds__(256) void k_big_sred(BigPlan p, double* __restrict_
   double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
   *o = (accumulate ? *o : 0.0) + s;
 }
-// (b) from the matrix: a wave per (row m, slab), lanes along n
+
+// s_m partial (+)= sum_{n in row slab} A'[n][m] mubar_n : grid (MP/64, BIG_SSL), block = 64 columns x 4 row phases;
+// block (0, BIG_SSL) accumulates sum_n vbar_n
 __global__ __launch_bounds__(256) void k_big_coldot(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
-  __shared__ double red[4];
-  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
   if ((int)blockIdx.y == BIG_SSL) {
     if (blockIdx.x != 0) return;
     const double* __restrict__ vb = ws + p.vb + c0;
     double s = 0.0;
     for (int n = tid; n < p.NC; n += 256) s += vb[n];
     s = wave_sum(s);
-    if (lane == 0) red[g] = s;
+    if (c == 0) red[g][0] = s;
     __syncthreads();
-    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
+    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]));
     return;
   }
-  const int m = blockIdx.x * 4 + g;
-  const int per = ((p.NC + BIG_SSL - 1) / BIG_SSL + 63) & ~63, n0 = blockIdx.y * per, n1 = min(p.NC, n0 + per);
-  const double* __restrict__ A = ws + p.A + (size_t)m * p.NC;
+  const int m = blockIdx.x * 64 + c;
+  const int per = (p.NC + BIG_SSL - 1) / BIG_SSL, n0 = blockIdx.y * per, n1 = min(p.NC, n0 + per);
+  const double* __restrict__ A = ws + p.A;
   const double* __restrict__ mub = ws + p.mub + c0;
   double s0 = 0.0, s1 = 0.0;
-  int n = n0 + lane;
-  for (; n + 64 < n1; n += 128) {
-    s0 = fma(A[n], mub[n], s0);
-    s1 = fma(A[n + 64], mub[n + 64], s1);
+  int n = n0 + g;
+  for (; n + 4 < n1; n += 8) {
+    s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
+    s1 = fma(A[(size_t)(n + 4) * p.MP + m], mub[n + 4], s1);
   }
-  for (; n < n1; n += 64) s0 = fma(A[n], mub[n], s0);
-  const double s = wave_sum(s0 + s1);
-  if (lane == 0) {
+  for (; n < n1; n += 4) s0 = fma(A[(size_t)n * p.MP + m], mub[n], s0);
+  red[g][c] = s0 + s1;
+  __syncthreads();
+  if (g == 0) {
     double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
-    *o = (accumulate ? *o : 0.0) + s;
+    *o = (accumulate ? *o : 0.0) + ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
   }
 }
 
@@ -1734,8 +1702,6 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
     hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_transpose, dim3(MP / 32, MP / 32), dim3(256), 0, st, ws + p.J, ws + p.JT, MP);   // (after the ladder: a retry rewrites J)
-  LAUNCH_CHECK();
   if (hipError_t e = hipStreamWaitEvent(sx, fk.ev[0], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
   if (train) {
     hipLaunchKernelGGL(k_big_kl, dim3(BIG_NKL), dim3(256), 0, sx, p, md, ws);
@@ -1768,13 +1734,15 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   return 0;
 }
 
-// The statistics T = (K_bar o K) [xs, xs^2, 1] in the epilogue of the product that forms K_bar (EPI 4; VERDICT r5 #1a): for the
-// RBF kernel (one weight matrix), when the chunk is large enough for 128 x 128 tiles, unless TGP_PLAN_NO_EPI_STATS
-static bool chunk_fuse_t(const BigPlan& p) {
-  if (!p.fuse || p.kernel != TGP_KERNEL_SCALE_RBF) return false;
-  GemmArgs g = gemm_args(nullptr, p.MP, nullptr, p.NC, nullptr, p.NC, p.MP, p.NC, p.MP, 1.0, 0.0, TRI_A_UPPER);
-  return gemm_runs_big_tiles(false, false, g);
+// Which of the chunk's element-wise passes ride in GEMM epilogues (VERDICT r5 #1a; TGP_PLAN_NO_EPI_STATS turns them off): only where
+// the chunk products run on k_gemm's 128 x 128 tiles (k_gemm64 has no statistic epilogues), and the statistics T only for the RBF
+// kernel (one weight matrix)
+static bool chunk_big_tiles(const BigPlan& p) {
+  GemmArgs g = gemm_args(nullptr, p.MP, nullptr, p.MP, nullptr, p.MP, p.NC, p.MP, p.MP, 1.0, 0.0, TRI_B_UPPER);
+  return gemm_runs_big_tiles(false, true, g);
 }
+static bool chunk_fuse(const BigPlan& p) { return p.fuse && chunk_big_tiles(p); }
+static bool chunk_fuse_t(const BigPlan& p) { return chunk_fuse(p) && p.kernel == TGP_KERNEL_SCALE_RBF; }
 
 // K' tiles of one chunk (and, for a training step, its augmented coordinates)
 static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, double* ws, bool train, hipStream_t st) {
@@ -1783,31 +1751,9 @@ static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, doubl
     hipLaunchKernelGGL(k_big_xaug, dim3((unsigned)((size_t)NC * BIG_XW / 256)), dim3(256), 0, st, p, Xc, nrows, ws);
     LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0, (train && chunk_fuse_t(p)) ? 1 : 0);
+  hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, p, Xc, nrows, ws, 0);
   LAUNCH_CHECK();
   return 0;
-}
-
-// The four triangular products of a chunk, C [MP][NC] = op(F) X with F one of the M x M factors (lower L-shaped: J, Lq; or their
-// transposes) and X a chunk matrix.  Both stored orientations of F exist (J / J^T, Lq / Lq^T): the 128 x 128 tiling reads
-// op(A) fastest k-major (TA: 58.8 against 55.9 TF/s at 15 744 rows, profiles/r06_gemm_mmajor_probe.txt), the 64 x 64 tiling of
-// small chunks wants it stored [m][k].  `F` = the factor stored row-major, `FT` = its transpose stored row-major; `upper`:
-// op(A) = F^T (upper triangular) instead of F.
-static GemmArgs chunk_product(const BigPlan& p, double* ws, size_t F, size_t FT, bool upper, const double* X, double* C, double alpha,
-                              bool* ta_out) {
-  const int MP = p.MP, NC = p.NC;
-  const int tri = upper ? TRI_A_UPPER : TRI_A_LOWER;
-  // stored [m][k]: op(A) = F -> F itself; op(A) = F^T -> FT.   stored [k][m] (TA): op(A) = F -> FT; op(A) = F^T -> F.
-  GemmArgs plain = gemm_args(ws + (upper ? FT : F), MP, X, NC, C, NC, MP, NC, MP, alpha, 0.0, tri);
-  plain.xcd = 6;
-  if (!gemm_runs_big_tiles(false, false, plain)) {
-    *ta_out = false;
-    return plain;
-  }
-  GemmArgs g = gemm_args(ws + (upper ? F : FT), MP, X, NC, C, NC, MP, NC, MP, alpha, 0.0, tri);
-  g.xcd = 6;
-  *ta_out = true;
-  return g;
 }
 
 // forward part of one chunk: Kc (unless `have_k`: made during the factorisation), A, B, moments
@@ -1816,20 +1762,22 @@ static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, doub
   const int MP = p.MP, NC = p.NC, np = MP / 64;
   if (!have_k)
     if (int rc = big_chunk_kernel(p, Xc, nrows, ws, train, st)) return rc;
-  // A = J K (J lower), B = Lq^T A (Lq^T upper); the column sums the moments need are formed in the epilogues (EPI 2) where
-  // the products run on 128 x 128 tiles
-  bool ta1, ta2;
-  GemmArgs a1 = chunk_product(p, ws, p.J, p.JT, false, ws + p.Kc, ws + p.A, 1.0, &ta1);
-  GemmArgs a2 = chunk_product(p, ws, p.Lq, p.LqT, true, ws + p.A, ws + p.B, 1.0, &ta2);
-  const bool fuse = p.fuse && ta1 && ta2;   // (ta = the 128 x 128 tiling was chosen)
+  // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD.  The row sums the moments
+  // need (sum A'^2, sum m A', sum B'^2) are formed in the epilogues of the two products (EPI 2, one partial per 64 columns):
+  // k_big_moments read both matrices again (256 MB per 16 384-row chunk) to form them
+  const bool fuse = chunk_fuse(p);
+  GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
+  a1.xcd = 1;
+  GemmArgs a2 = gemm_args(ws + p.A, MP, ws + p.Lq, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+  a2.xcd = 1;
   if (fuse) {
-    a1.stat0 = ws + p.cstat; a1.stat1 = ws + p.cstat + (size_t)np * NC; a1.rowv = ws + p.mpad; a1.ldstat = NC;
-    a2.stat0 = ws + p.cstat + (size_t)2 * np * NC; a2.ldstat = NC;
+    a1.stat0 = ws + p.cstat; a1.stat1 = ws + p.cstat + (size_t)np * NC; a1.colv = ws + p.mpad; a1.ldstat = NC; a1.statdir = 1;
+    a2.stat0 = ws + p.cstat + (size_t)2 * np * NC; a2.ldstat = NC; a2.statdir = 1;
   }
-  GEMM(ta1, false, a1);
-  GEMM(ta2, false, a2);
+  GEMM(false, true, a1);
+  GEMM(false, false, a2);
   if (fuse) hipLaunchKernelGGL(k_big_moments_p, dim3((nrows + 255) / 256), dim3(256), 0, st, p, ws, mu, v, nrows);
-  else hipLaunchKernelGGL(k_big_moments, dim3(NC / 16), dim3(256), 0, st, p, ws, mu, v, nrows);
+  else hipLaunchKernelGGL(k_big_moments, dim3((nrows + 3) / 4), dim3(256), 0, st, p, ws, mu, v, nrows);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1909,48 +1857,46 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       // (the G SYRK and s = A'^T mubar need only A', vbar, mubar and could run beside the chain Abar' -> Kbar' -> T on the
       //  fork stream: measured, the two branches take exactly the sum of their solo times -- the launches are bound by
       //  matrix throughput, not by idle CUs -- so they stay in line)
-      // Abar = (2 Lq B - 2 A) diag(vbar) + m mubar^T ; the same epilogue forms the row partials of s = A mubar (EPI 3)
-      bool ta3, ta4;
-      GemmArgs a3 = chunk_product(pc, ws, p.Lq, p.LqT, false, ws + pc.B, ws + pc.Ab, 2.0, &ta3);
-      a3.add = ws + pc.A; a3.ldadd = NC; a3.gamma = -2.0;
-      a3.col_scale = ws + p.vb + c0; a3.rowv = ws + p.mpad; a3.colv = ws + p.mub + c0;
-      const bool fuse_s = p.fuse && ta3;
-      if (fuse_s) { a3.stat1 = ws + p.sp; a3.ldstat = MP; }
-      GEMM(ta3, false, a3);
+      // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T ; the same epilogue forms the column partials of s = A'^T mubar (EPI 3)
+      const bool fuse = chunk_fuse(p);
+      GemmArgs a3 = gemm_args(ws + pc.B, MP, ws + p.Lq, MP, ws + pc.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
+      a3.add = ws + pc.A; a3.ldadd = MP; a3.gamma = -2.0;
+      a3.row_scale = ws + p.vb + c0; a3.rowv = ws + p.mub + c0; a3.colv = ws + p.mpad;
+      a3.xcd = 1;
+      if (fuse) { a3.stat1 = ws + p.sp; a3.ldstat = MP; a3.statdir = 1; }
+      GEMM(false, true, a3);
+      // Kbar' = Abar' J
+      GemmArgs a4 = gemm_args(ws + pc.Ab, MP, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
+      a4.xcd = 1;
       if (chunk_fuse_t(p)) {
-        // K_bar^T = Abar^T J is formed tile by tile ([NC][MP] orientation: rows = data rows, the contraction index of T) and never
-        // stored: the epilogue multiplies the tile by K, contracts it with the chunk's augmented coordinates and leaves one
-        // 16 nct x MP partial per tile row; k_big_tred folds those into the T slabs
-        (void)ta4;
-        GemmArgs a4 = gemm_args(ws + pc.Ab, NC, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
-        a4.xcd = 1;
-        a4.add = ws + pc.Kn; a4.ldadd = MP; a4.rowv = ws + pc.Xaug; a4.stat1 = ws + p.Tp2; a4.ldstat = MP; a4.nct = p.nct;
-        GEMM(true, false, a4);
+        // ... formed tile by tile and never stored: the epilogue (EPI 4) multiplies the tile by K', contracts it over its data
+        // rows with the chunk's augmented coordinates and leaves one 16 nct x MP partial per tile row; k_big_tred folds those
+        // into the T slabs.  (The statistics GEMM read K_bar' and K' again -- 258 MB per chunk -- and K_bar' was written for it.)
+        a4.add = ws + pc.Kc; a4.ldadd = MP; a4.rowv = ws + pc.Xaug; a4.stat1 = ws + p.Tp2; a4.ldstat = MP; a4.nct = p.nct;
+        GEMM(false, false, a4);
         hipLaunchKernelGGL(k_big_tred, dim3((unsigned)((size_t)MP * BIG_XW / 256), BIG_KST), dim3(256), 0, st, pc, ws, ci ? 1 : 0);
         LAUNCH_CHECK();
       } else {
-      // Kbar = J^T Abar  (into the B buffer)
-      GemmArgs a4 = chunk_product(pc, ws, p.J, p.JT, true, ws + pc.Ab, ws + pc.B, 1.0, &ta4);
-      GEMM(ta4, false, a4);
-      // T slabs (+)= (Kbar o K_g) Xaug.  RBF: K_g = K.  MATERN32: first the statistics with K itself (only their
-      // ones column is used: d/d outputscale), then K is overwritten by its derivative weight K_g
-      GemmArgs at = gemm_args(ws + pc.B, NC, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
-      at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
-      if (p.kernel != TGP_KERNEL_SCALE_RBF) {
-        GemmArgs atk = at;
-        atk.C = ws + p.TpartK;
-        GEMM(false, false, atk);
-        hipLaunchKernelGGL(k_big_knm, dim3(NC / 128, MP / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1, 0);
-        LAUNCH_CHECK();
+        GEMM(false, false, a4);   // (into the B' buffer)
+        // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
+        // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
+        GemmArgs at = gemm_args(ws + pc.B, MP, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+        at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
+        if (p.kernel != TGP_KERNEL_SCALE_RBF) {
+          GemmArgs atk = at;
+          atk.C = ws + p.TpartK;
+          GEMM(true, false, atk);
+          hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
+          LAUNCH_CHECK();
+        }
+        GEMM(true, false, at);
       }
-      GEMM(false, false, at);
-      }
-      // G slabs (+)= A diag(vbar) A^T, lower block triangle
-      GemmArgs ag = gemm_args(ws + pc.A, NC, ws + pc.A, NC, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
+      // G slabs (+)= A'^T diag(vbar) A', lower block triangle
+      GemmArgs ag = gemm_args(ws + pc.A, MP, ws + pc.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
       ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;
-      GEMM(false, true, ag);
-      if (fuse_s) hipLaunchKernelGGL(k_big_sred, dim3(MP / 256, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
-      else hipLaunchKernelGGL(k_big_coldot, dim3(MP / 4, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
+      GEMM(true, false, ag);
+      if (fuse) hipLaunchKernelGGL(k_big_sred, dim3(MP / 256, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
+      else hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
       LAUNCH_CHECK();
       if (aux) HIPCK(hipEventRecord(aux->eB[par], st));
     }

@@ -54,10 +54,14 @@ struct GemmArgs {
   //          coordinates rowv[i][0 .. 16 nct) (row length GXW): stat1[((i / 128) * 16 nct + c) * ldstat + j] = sum over the tile's
   //          128 rows of C[i][j] add[i][j] rowv[i][c] -- the statistics GEMM T of the general-M path in the epilogue of the
   //          product that forms K_bar (tgp_big.hip)
+  // `statdir` 1 turns EPI 2 / 3 by 90 degrees (the chunk matrices of tgp_big.hip are stored [NC][MP]: data rows are tile rows):
+  //   EPI 2: stat0[(j / 64) * ldstat + i] = sum over the 64 columns j.. of C[i][j]^2 ; stat1[...] = sum of colv[j] C[i][j]
+  //   EPI 3: stat1[(i / 64) * ldstat + j] = sum over the 64 rows i.. of add[i][j] rowv[i]
   double* stat0;
   double* stat1;
   int ldstat;
   int nct;
+  int statdir;
   int ksplit;          // >= 1
   size_t cz;           // doubles between slab outputs
   int pair;            // set by the launcher: triangular op(B), column tiles j and n/128-1-j handled by one workgroup
@@ -65,8 +69,6 @@ struct GemmArgs {
                        // re-read the same op(A) rows), 2 all tiles of a k SLAB share an XCD (split-K operands),
                        // 3 (set by the launcher for TRI_C_LOWER + split-K) compact lower-triangle enumeration,
                        // 4 (set by the launcher for an unpaired triangular op(B)) per-XCD heavy-column-first order
-                       // 6 weight-ranked order for a triangular op(A) whose tiles are all computed (the m-major chunk
-                       //   products: small op(A), big op(B)): heaviest tile rows first, the second 256 ids in reverse
 };
 
 inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, double* C, int ldc, int m, int n, int k,
@@ -76,7 +78,7 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
   g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.a_mul = nullptr; g.k_scale = nullptr; g.add = nullptr; g.ldadd = 0; g.gamma = 0.0;
   g.col_scale = nullptr; g.row_scale = nullptr; g.rowv = nullptr; g.colv = nullptr; g.ksplit = 1; g.cz = 0; g.xcd = 0; g.pair = 0;
-  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0; g.nct = 0;
+  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0; g.nct = 0; g.statdir = 0;
   return g;
 }
 
@@ -298,12 +300,14 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
         __syncthreads();    // the slots are free for the next coordinate group
       }
     } else if (EPI == 0 || EPI == 2) {
-      double rv2[4][4];
+      double rv2[4][4], cv2[4];
       if (EPI == 2) {       // (requested ahead of the stores: loads and stores share vmcnt)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) rv2[a][rr] = g.stat1 ? gemm_ld1(g.rowv + i0 + wi + 16 * a + q + 4 * rr) : 0.0;
+          for (int rr = 0; rr < 4; ++rr) rv2[a][rr] = (g.stat1 && !g.statdir) ? gemm_ld1(g.rowv + i0 + wi + 16 * a + q + 4 * rr) : 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cv2[b] = (g.stat1 && g.statdir) ? gemm_ld1(g.colv + j0 + wj + 16 * b + r) : 0.0;
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b)
@@ -312,7 +316,29 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
             gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r, g.alpha * acc[a][b][rr]);
-      if (EPI == 2) {
+      if (EPI == 2 && g.statdir) {
+        // row i of this wave's 64 x 64 tile: 4 column groups in this lane's registers, then the 16 lanes of the row's group
+        const size_t pcol = (size_t)((j0 + wj) >> 6) * g.ldstat;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            double sq = 0.0, dt = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const double x = g.alpha * acc[a][b][rr];
+              sq = fma(x, x, sq);
+              dt = fma(cv2[b], x, dt);
+            }
+            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
+            if (g.stat1) { dt += __shfl_xor(dt, 1); dt += __shfl_xor(dt, 2); dt += __shfl_xor(dt, 4); dt += __shfl_xor(dt, 8); }
+            if (r == 0) {
+              const int row = i0 + wi + 16 * a + q + 4 * rr;
+              gemm_st1(g.stat0 + pcol + row, sq);
+              if (g.stat1) gemm_st1(g.stat1 + pcol + row, dt);
+            }
+          }
+      } else if (EPI == 2) {
         // column j of this wave's 64 x 64 tile: 16 rows in this lane's registers, then the four 16-lane groups (fixed order)
         const size_t prow = (size_t)((i0 + wi) >> 6) * g.ldstat;
 #pragma unroll
@@ -351,6 +377,7 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
         cv[b] = g.colv ? gemm_ld1(g.colv + col) : 0.0;
       }
       const size_t pcol = EPI == 3 ? (size_t)((j0 + wj) >> 6) * g.ldstat : 0;
+      double sdc[4] = {0.0, 0.0, 0.0, 0.0};       // statdir 1: running column sums of add o rowv over this lane's 16 rows
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         double rs[4], rv[4], ein[4][4];
@@ -371,13 +398,26 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
             double x = g.alpha * acc[a][b][rr] + ca * ein[b][rr];
             x = x * cs[b] * rs[rr] + rv[rr] * cv[b] + cb * ein[b][rr];
             gemm_st1(C + (size_t)row * g.ldc + j0 + wj + 16 * b + r, x);
-            if (EPI == 3) sd = fma(ein[b][rr], cv[b], sd);
+            if (EPI == 3) {
+              if (g.statdir) sdc[b] = fma(ein[b][rr], rv[rr], sdc[b]);
+              else sd = fma(ein[b][rr], cv[b], sd);
+            }
           }
-          if (EPI == 3) {
+          if (EPI == 3 && !g.statdir) {
             // row `row` of this wave's tile: its 4 column groups are in sd, then the 16 lanes of the row's lane group
             sd += __shfl_xor(sd, 1); sd += __shfl_xor(sd, 2); sd += __shfl_xor(sd, 4); sd += __shfl_xor(sd, 8);
             if (r == 0) gemm_st1(g.stat1 + pcol + row, sd);
           }
+        }
+      }
+      if (EPI == 3 && g.statdir) {
+        // column j: the 16 rows of this lane are in sdc, then the four 16-lane groups (fixed order)
+        const size_t prow = (size_t)((i0 + wi) >> 6) * g.ldstat;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          double x = sdc[b];
+          x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+          if (q == 0) gemm_st1(g.stat1 + prow + j0 + wj + 16 * b + r, x);
         }
       }
     }
@@ -412,18 +452,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     by = xc + 8 * (sq % nrx);
     bx = (g.tri & TRI_B_LOWER) ? w : gx - 1 - w;
     if (by * GT >= g.m) return;   // the launcher rounds the tile rows up to a multiple of 8
-  } else if (g.xcd == 6) {
-    // Triangular op(A), every tile computed, k range growing with the tile row (TRI_A_LOWER) or shrinking (TRI_A_UPPER): ids in
-    // order of decreasing work.  On an idle chip ids i and i + 256 share a CU (two resident workgroups per CU, tools/probes/
-    // wg_placement.hip), so in plain decreasing order an 8-block tile meets a 5-block one (13 block times on that CU against
-    // an average of 11 at 10 000 rows); with ids 256..511 taken in REVERSE the heaviest tiles meet the lightest of that
-    // group (10-11).  Natural XCD spread: measured best for this shape (profiles/r06_gemm_mmajor_probe.txt).
-    const int gx = gridDim.x, gy = gridDim.y, W = gx * gy, L = bx + gx * by;
-    const int hi = W < 512 ? W : 512;
-    const int rk = (L >= 256 && L < hi) ? 256 + (hi - 1 - L) : L;
-    const int wr = rk / gx;                        // 0 = heaviest tile row
-    bx = rk % gx;
-    by = (g.tri & TRI_A_UPPER) ? wr : gy - 1 - wr;
   } else if (g.xcd == 3) {
     // compact split-K enumeration of the lower block triangle: gridDim.x = ntl * ksplit, slab-major, and the ids
     // that share an XCD (same id mod 8) take a contiguous run of (slab, tile) pairs -- equal load per XCD and the
