@@ -304,7 +304,7 @@ def main():
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="bound (s) of the communicator bootstrap; a rank that cannot "
                     "complete it ends the whole job with exit code 3")
     ap.add_argument("--plan", type=int, default=0, help="tgp_model.plan of the engine's calls (include/tgp_hip.h TGP_PLAN_*): A/B of "
-                    "equivalent kernels, e.g. 32 = the general-M path's row statistics by kernels of their own; 0 = the library's choice")
+                    "equivalent kernels, e.g. 1 = the 16-rows-per-wave row kernel, 16 = the general-M chunk pipeline without its two-buffer overlap; 0 = the library's choice")
     ap.add_argument("--traffic-json", default=None, help="per-launch HBM bytes of the dominant kernel from a rocprofv3 "
                     "--pmc pass, keyed by the source hash of the library it was measured on (default: "
                     "profiles/rows_traffic.json); a summary of other sources is rejected and roofline.traffic is null")

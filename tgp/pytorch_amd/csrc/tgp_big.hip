@@ -32,7 +32,6 @@ namespace tgp {
 #define BIG_NKL 64    /* KL partial blocks */
 #define BIG_SSL 32    /* row slabs of the s = A'^T mubar partial sums */
 #define BIG_NCMAX 16384
-static_assert(BIG_XW == GXW, "EPI 4 of k_gemm reads the augmented coordinates with this row length");
 
 struct BigPlan {
   int N, D, M, S, nblk, P, RP, lik, kernel;
@@ -42,11 +41,8 @@ struct BigPlan {
   size_t Kmm, Lm, J, Lq, S_, Hp, G, Q, R1, tmp;
   size_t Zaug, U, T, Xaug;
   size_t Kc, A, B, Ab;
-  size_t Tp2; int nct;       // EPI 4: per tile row of the K_bar product, 16 nct x MP partial statistics
   size_t mu, v, mub, vb;
   size_t Gpart, Tpart, likslot, likws;
-  size_t cstat, sp;  // epilogue statistics: 3 x (MP/64) x NC row partials (sum A'^2, sum m A', sum B'^2); (NC/64) x MP column partials of A'^T mubar
-  int fuse;          // row statistics in the GEMM epilogues (0: kernels of their own, TGP_PLAN_NO_EPI_STATS or 64 x 64 tiles)
   size_t cstride;  // second set of chunk buffers {Xaug, K', A', B', Abar'} (0 = none): forward of chunk c+1 overlaps backward of chunk c
   size_t Sk;  // split-K slabs of the M x M products
   size_t Kmmg, TpartK, TK, UK;  // MATERN32 only: derivative-weight K_MM, statistics of (Kbar o K) next to those of (Kbar o K_g)
@@ -140,11 +136,6 @@ static int make_big_plan(BigPlan& p, int N, int D, int M, int S, int nblk, int P
     p.cstride = o - p.Xaug;  // Xaug, Kc, A, B, Ab are contiguous
     o += p.cstride;
   }
-  p.nct = (2 * p.DP + 1 + 15) / 16;
-  p.Tp2 = o; o += (size_t)(p.NC / 128) * 16 * p.nct * p.MP;
-  p.cstat = o; o += (size_t)3 * (p.MP / 64) * p.NC;
-  p.sp = o; o += (size_t)(p.NC / 64) * p.MP;
-  p.fuse = (plan & TGP_PLAN_NO_EPI_STATS) ? 0 : 1;
   p.mu = o; o += p.NP; p.v = o; o += p.NP; p.mub = o; o += p.NP; p.vb = o; o += p.NP;
   p.Gpart = o; o += (size_t)p.ksg * mm;
   p.Tpart = o; o += (size_t)BIG_KST * p.MP * BIG_XW;
@@ -176,7 +167,7 @@ size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP
 // ---------------------------------------------------------------------------------------------------
 // GEMM launcher
 // ---------------------------------------------------------------------------------------------------
-template <bool TA, bool TB, bool MOD, int EPI>
+template <bool TA, bool TB, bool MOD, bool EPI>
 static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   static bool attr_done = false;
   const void* f = reinterpret_cast<const void*>(k_gemm<TA, TB, MOD, EPI>);
@@ -194,7 +185,7 @@ static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
-template <bool MOD, int EPI>
+template <bool MOD, bool EPI>
 static int launch_gemm_l(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
   if (ta && tb) return launch_gemm_t<true, true, MOD, EPI>(g, st);
   if (ta) return launch_gemm_t<true, false, MOD, EPI>(g, st);
@@ -225,10 +216,7 @@ static int gemm_normalise(GemmArgs& g) {
     const long paired = ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1);
     long unpaired = (nrow * nj * (nj + 1) / 2 + 255) / 256;
     if (unpaired < nj) unpaired = nj;
-    // (a product with a long epilogue -- EPI 4 reads a second tile and runs a contraction -- always unpaired: paired workgroups
-    //  are all equally long and reach their epilogues together, leaving the matrix pipes idle twice per launch; tiles of
-    //  different lengths overlap one workgroup's epilogue with the other's main loop)
-    if (unpaired * 108 < paired * 100 || g.nct > 0) {
+    if (unpaired * 108 < paired * 100) {
       g.pair = 0;
       g.xcd = 4;
     }
@@ -239,67 +227,40 @@ static int gemm_normalise(GemmArgs& g) {
 }
 static bool gemm_has_mod(const GemmArgs& g) { return g.a_mul != nullptr || g.k_scale != nullptr; }
 static bool gemm_has_epi(const GemmArgs& g) {
-  // (rowv without colv is the weight vector of the EPI 2 column statistics, not a rank-1 term)
-  return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || (g.rowv && g.colv);
+  return g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
 }
 
 static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st);
 
-// Products without operand modifiers and with op(A) stored [m][k], one of whose operands may be triangular, whose 128 x 128
-// tiling leaves the chip mostly idle: 64 x 64 tiles (k_gemm64).  `g` normalised.
-// Times in units of one 128^3 k-block on a CU: the big tiling's longest workgroup / balance, against the small tiling's
-// (a 64^3 block is 1/8 of it, two resident workgroups share a CU).
-static bool gemm_small_tiles(bool ta, const GemmArgs& g) {
-  const int tB = g.tri & (TRI_B_LOWER | TRI_B_UPPER), tA = g.tri & (TRI_A_LOWER | TRI_A_UPPER);
-  if (ta || gemm_has_mod(g) || g.ksplit != 1 || (g.tri & TRI_C_LOWER) || (tA && tB) || g.k % 64 != 0) return false;
-  const long nrow = g.m / GT, nj = g.n / GT, kb = g.k / GT;
-  const long total = tB ? nrow * nj * (nj + 1) / 2 : (tA ? nj * nrow * (nrow + 1) / 2 : nrow * nj * kb);
-  const long longest = tB ? nj : (tA ? nrow : kb);
-  long big = g.pair ? ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1) : (total + 255) / 256;
-  if (!g.pair && big < longest) big = longest;
-  // small tiling, in eighths of a block time: total / 256 CUs, or the longest tile at half rate
-  const long nj2 = g.n / 64, rows2 = g.m / 64, kb2 = g.k / 64;
-  const long total2 = tB ? rows2 * nj2 * (nj2 + 1) / 2 : (tA ? nj2 * rows2 * (rows2 + 1) / 2 : rows2 * nj2 * kb2);
-  long small8 = (total2 + 255) / 256;
-  const long longest2 = 2 * (tB ? nj2 : (tA ? rows2 : kb2));
-  if (small8 < longest2) small8 = longest2;
-  return small8 * 10 < big * 8 * 7;   // predicted at least 30 % faster
-}
-
-// true when launch_gemm would run this product on k_gemm (128 x 128 tiles), whose epilogue can form the row / column
-// statistics (stat0 / stat1); k_gemm64 cannot
-bool gemm_runs_big_tiles(bool ta, bool tb, const GemmArgs& g_in) {
-  GemmArgs g = g_in;
-  if (gemm_normalise(g)) return false;
-  return !gemm_small_tiles(ta, g);
-}
-
 int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   GemmArgs g = g_in;
   if (gemm_normalise(g)) return -1;
-  const bool stats = g.stat0 != nullptr || g.stat1 != nullptr || g.nct > 0;
-  if (gemm_small_tiles(ta, g)) {
-    if (stats) return -1;   // (callers ask gemm_runs_big_tiles first)
-    return launch_gemm64(tb, g, st);
-  }
-  const bool mod = gemm_has_mod(g), epi = gemm_has_epi(g);
-  if (g.nct > 0) {   // EPI 4: no C, the tile o add contracted over its rows with rowv (the statistics GEMM in the epilogue)
-    if (ta || tb || mod || g.ksplit != 1 || g.add == nullptr || g.rowv == nullptr || g.stat1 == nullptr || g.beta != 0.0) return -1;
-    return launch_gemm_t<false, false, false, 4>(g, st);
-  }
-  if (stats) {
-    // the statistic epilogues of the chunk pipeline: plain product + row / column statistics of C (2), epilogue + dots of the
-    // `add` tile (3)
-    if (mod || ta || g.ksplit != 1) return -1;
-    if (epi) {
-      if (g.stat1 == nullptr || g.add == nullptr || g.colv == nullptr || g.rowv == nullptr || !tb) return -1;
-      return launch_gemm_t<false, true, false, 3>(g, st);
+  {
+    // products without operand modifiers, with a (possibly triangular) op(B), whose 128 x 128 tiling leaves the chip mostly
+    // idle: 64 x 64 tiles.
+    // Times in units of one 128^3 k-block on a CU: the big tiling's longest workgroup / balance, against the small
+    // tiling's (a 64^3 block is 1/8 of it, two resident workgroups share a CU).
+    const bool plain = !ta && !gemm_has_mod(g) && g.ksplit == 1 && !(g.tri & ~(TRI_B_LOWER | TRI_B_UPPER)) && g.k % 64 == 0;
+    if (plain) {
+      const long nrow = g.m / GT, nj = g.n / GT, kb = g.k / GT;
+      const bool tri = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) != 0;
+      const long per_row = tri ? nj * (nj + 1) / 2 : nj * kb;
+      const long longest = tri ? nj : kb;
+      long big = g.pair ? ((nrow * ((nj + 1) / 2) + 255) / 256) * (nj + 1) : (nrow * per_row + 255) / 256;
+      if (!g.pair && big < longest) big = longest;
+      // small tiling, in eighths of a block time: total / 256 CUs, or the longest tile at half rate
+      const long nj2 = 2 * nj, rows2 = (g.m + 63) / 64;
+      const long per_row2 = tri ? nj2 * (nj2 + 1) / 2 : nj2 * 2 * kb;
+      long small8 = (rows2 * per_row2 + 255) / 256;
+      const long longest2 = 2 * (tri ? nj2 : 2 * kb);
+      if (small8 < longest2) small8 = longest2;
+      if (small8 * 10 < big * 8 * 7) return launch_gemm64(tb, g, st);   // predicted at least 30 % faster
     }
-    if (g.stat0 == nullptr || (g.stat1 != nullptr && (g.statdir ? g.colv : g.rowv) == nullptr)) return -1;
-    return tb ? launch_gemm_t<false, true, false, 2>(g, st) : launch_gemm_t<false, false, false, 2>(g, st);
   }
-  if (mod) return epi ? launch_gemm_l<true, 1>(ta, tb, g, st) : launch_gemm_l<true, 0>(ta, tb, g, st);
-  return epi ? launch_gemm_l<false, 1>(ta, tb, g, st) : launch_gemm_l<false, 0>(ta, tb, g, st);
+  const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
+  const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
+  if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
+  return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,8 +447,6 @@ __device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, doubl
   int kb = 0, ke = g.k;
   if (g.tri & TRI_B_LOWER) kb = max(kb, j0);
   if (g.tri & TRI_B_UPPER) ke = min(ke, j0 + 64);
-  if (g.tri & TRI_A_LOWER) ke = min(ke, i0 + 64);
-  if (g.tri & TRI_A_UPPER) kb = max(kb, i0);
   d2 ra[8], rb[8];
   auto load_stage = [&](int k0) {
 #pragma unroll
@@ -586,22 +545,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm64(G64Args g, int gx, int gy8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char g64_smem[];
   double* As = reinterpret_cast<double*>(g64_smem);
   double* Bs = As + 64 * FAC_LD;
-  int bx, by;
-  if (g.tri & (TRI_A_LOWER | TRI_A_UPPER)) {
-    // triangular op(A) (the m-major chunk products at small NC): heaviest tile rows first, natural XCD spread
-    const int L = blockIdx.x, wr = L / gx, gy = g.m / 64;
-    bx = L % gx;
-    by = (g.tri & TRI_A_UPPER) ? wr : gy - 1 - wr;
-    if (wr >= gy) return;
-  } else {
-    // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
-    const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
-    const int w = sq / nrx;
-    by = xc + 8 * (sq % nrx);
-    bx = w;
-    if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
-    if (by * 64 >= g.m) return;
-  }
+  // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
+  const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
+  const int w = sq / nrx, by = xc + 8 * (sq % nrx);
+  int bx = w;
+  if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
+  if (by * 64 >= g.m) return;
   if (g.tb) g64_tile<true, EPI>(g, by * 64, bx * 64, As, Bs);
   else g64_tile<false, EPI>(g, by * 64, bx * 64, As, Bs);
 }
@@ -1157,22 +1106,6 @@ __global__ __launch_bounds__(256) void k_big_knm(BigPlan p, const double* __rest
   }
 }
 
-// Tpart[z][m][c] (+)= sum over the tile-row slabs of slice z of the EPI 4 partials Tp2[slab][c][m]; the unused columns of T zeroed
-__global__ __launch_bounds__(256) void k_big_tred(BigPlan p, double* __restrict__ ws, int accumulate) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int m = (int)(e % p.MP), c = (int)(e / p.MP), z = blockIdx.y, nc = 16 * p.nct;
-  if (c >= BIG_XW) return;
-  double* o = ws + p.Tpart + (size_t)z * p.MP * BIG_XW + (size_t)m * BIG_XW + c;
-  if (c >= nc) {
-    if (!accumulate) *o = 0.0;
-    return;
-  }
-  const int nslab = p.NC / 128, per = (nslab + BIG_KST - 1) / BIG_KST, s0 = z * per, s1 = min(nslab, s0 + per);
-  double s = 0.0;
-  for (int k = s0; k < s1; ++k) s += ws[p.Tp2 + ((size_t)k * nc + c) * p.MP + m];
-  *o = (accumulate ? *o : 0.0) + s;
-}
-
 // mu_n = sum_m m_m A'_nm ; v_n = s2 - sum_m A'_nm^2 + sum_m B'_nm^2   (sparse_MF_SP.py:354-355,376-382); wave per row
 __global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
                                                       double* __restrict__ v, int nrows) {
@@ -1194,50 +1127,6 @@ __global__ __launch_bounds__(256) void k_big_moments(BigPlan p, double* __restri
     mu[n] = sm;
     v[n] = ws[p.hdr + H_S2] - sa + sb;
   }
-}
-
-// The same from the row partials the two products left in their epilogues (EPI 2, statdir 1: one row of partials per 64
-// columns of A', B'); k_big_moments is the stand-alone form (TGP_PLAN_NO_EPI_STATS, or products that ran on 64 x 64 tiles)
-__global__ __launch_bounds__(256) void k_big_moments_p(BigPlan p, double* __restrict__ ws, double* __restrict__ mu,
-                                                        double* __restrict__ v, int nrows) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= nrows) return;
-  const int np = p.MP / 64;
-  const double* __restrict__ pa = ws + p.cstat + n;
-  const double* __restrict__ pm = pa + (size_t)np * p.NC;
-  const double* __restrict__ pb = pm + (size_t)np * p.NC;
-  double sa = 0.0, sm = 0.0, sb = 0.0;
-  for (int k = 0; k < np; ++k) {
-    sa += pa[(size_t)k * p.NC];
-    sm += pm[(size_t)k * p.NC];
-    sb += pb[(size_t)k * p.NC];
-  }
-  mu[n] = sm;
-  v[n] = ws[p.hdr + H_S2] - sa + sb;
-}
-
-// s partials from the column partials the Abar' product left in its epilogue (EPI 3, statdir 1: one row of partials per 64 data
-// rows): thread per m; block (0, BIG_SSL) accumulates sum_n vbar_n.  k_big_coldot below is the stand-alone form.
-__global__ __launch_bounds__(256) void k_big_sred(BigPlan p, double* __restrict__ ws, size_t c0, int accumulate) {
-  __shared__ double red[4];
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.y == BIG_SSL) {
-    if (blockIdx.x != 0) return;
-    const double* __restrict__ vb = ws + p.vb + c0;
-    double s = 0.0;
-    for (int n = tid; n < p.NC; n += 256) s += vb[n];
-    s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    if (tid == 0) ws[p.svb] = (accumulate ? ws[p.svb] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3]));
-    return;
-  }
-  const int m = blockIdx.x * 256 + tid, P = p.NC / 64;
-  const int per = (P + BIG_SSL - 1) / BIG_SSL, k0 = blockIdx.y * per, k1 = min(P, k0 + per);
-  double s = 0.0;
-  for (int k = k0; k < k1; ++k) s += ws[p.sp + (size_t)k * p.MP + m];
-  double* o = ws + p.spart + (size_t)blockIdx.y * p.MP + m;
-  *o = (accumulate ? *o : 0.0) + s;
 }
 
 // s_m partial (+)= sum_{n in row slab} A'[n][m] mubar_n : grid (MP/64, BIG_SSL), block = 64 columns x 4 row phases;
@@ -1734,16 +1623,6 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   return 0;
 }
 
-// Which of the chunk's element-wise passes ride in GEMM epilogues (VERDICT r5 #1a; TGP_PLAN_NO_EPI_STATS turns them off): only where
-// the chunk products run on k_gemm's 128 x 128 tiles (k_gemm64 has no statistic epilogues), and the statistics T only for the RBF
-// kernel (one weight matrix)
-static bool chunk_big_tiles(const BigPlan& p) {
-  GemmArgs g = gemm_args(nullptr, p.MP, nullptr, p.MP, nullptr, p.MP, p.NC, p.MP, p.MP, 1.0, 0.0, TRI_B_UPPER);
-  return gemm_runs_big_tiles(false, true, g);
-}
-static bool chunk_fuse(const BigPlan& p) { return p.fuse && chunk_big_tiles(p); }
-static bool chunk_fuse_t(const BigPlan& p) { return chunk_fuse(p) && p.kernel == TGP_KERNEL_SCALE_RBF; }
-
 // K' tiles of one chunk (and, for a training step, its augmented coordinates)
 static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, double* ws, bool train, hipStream_t st) {
   const int MP = p.MP, NC = p.NC;
@@ -1759,25 +1638,17 @@ static int big_chunk_kernel(const BigPlan& p, const double* Xc, int nrows, doubl
 // forward part of one chunk: Kc (unless `have_k`: made during the factorisation), A, B, moments
 static int big_chunk_forward(const BigPlan& p, const double* Xc, int nrows, double* ws, double* mu, double* v, bool train,
                              hipStream_t st, bool have_k = false) {
-  const int MP = p.MP, NC = p.NC, np = MP / 64;
+  const int MP = p.MP, NC = p.NC;
   if (!have_k)
     if (int rc = big_chunk_kernel(p, Xc, nrows, ws, train, st)) return rc;
-  // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD.  The row sums the moments
-  // need (sum A'^2, sum m A', sum B'^2) are formed in the epilogues of the two products (EPI 2, one partial per 64 columns):
-  // k_big_moments read both matrices again (256 MB per 16 384-row chunk) to form them
-  const bool fuse = chunk_fuse(p);
+  // A' = K' J^T (J^T upper), B' = A' Lq (Lq lower); the 8 column tiles of a row block share an XCD
   GemmArgs a1 = gemm_args(ws + p.Kc, MP, ws + p.J, MP, ws + p.A, MP, NC, MP, MP, 1.0, 0.0, TRI_B_UPPER);
   a1.xcd = 1;
+  GEMM(false, true, a1);
   GemmArgs a2 = gemm_args(ws + p.A, MP, ws + p.Lq, MP, ws + p.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
   a2.xcd = 1;
-  if (fuse) {
-    a1.stat0 = ws + p.cstat; a1.stat1 = ws + p.cstat + (size_t)np * NC; a1.colv = ws + p.mpad; a1.ldstat = NC; a1.statdir = 1;
-    a2.stat0 = ws + p.cstat + (size_t)2 * np * NC; a2.ldstat = NC; a2.statdir = 1;
-  }
-  GEMM(false, true, a1);
   GEMM(false, false, a2);
-  if (fuse) hipLaunchKernelGGL(k_big_moments_p, dim3((nrows + 255) / 256), dim3(256), 0, st, p, ws, mu, v, nrows);
-  else hipLaunchKernelGGL(k_big_moments, dim3((nrows + 3) / 4), dim3(256), 0, st, p, ws, mu, v, nrows);
+  hipLaunchKernelGGL(k_big_moments, dim3((nrows + 3) / 4), dim3(256), 0, st, p, ws, mu, v, nrows);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1857,46 +1728,33 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       // (the G SYRK and s = A'^T mubar need only A', vbar, mubar and could run beside the chain Abar' -> Kbar' -> T on the
       //  fork stream: measured, the two branches take exactly the sum of their solo times -- the launches are bound by
       //  matrix throughput, not by idle CUs -- so they stay in line)
-      // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T ; the same epilogue forms the column partials of s = A'^T mubar (EPI 3)
-      const bool fuse = chunk_fuse(p);
+      // Abar' = vbar o (2 B' Lq^T - 2 A') + mubar m^T
       GemmArgs a3 = gemm_args(ws + pc.B, MP, ws + p.Lq, MP, ws + pc.Ab, MP, NC, MP, MP, 2.0, 0.0, TRI_B_UPPER);
       a3.add = ws + pc.A; a3.ldadd = MP; a3.gamma = -2.0;
       a3.row_scale = ws + p.vb + c0; a3.rowv = ws + p.mub + c0; a3.colv = ws + p.mpad;
       a3.xcd = 1;
-      if (fuse) { a3.stat1 = ws + p.sp; a3.ldstat = MP; a3.statdir = 1; }
       GEMM(false, true, a3);
-      // Kbar' = Abar' J
+      // Kbar' = Abar' J  (into the B' buffer)
       GemmArgs a4 = gemm_args(ws + pc.Ab, MP, ws + p.J, MP, ws + pc.B, MP, NC, MP, MP, 1.0, 0.0, TRI_B_LOWER);
       a4.xcd = 1;
-      if (chunk_fuse_t(p)) {
-        // ... formed tile by tile and never stored: the epilogue (EPI 4) multiplies the tile by K', contracts it over its data
-        // rows with the chunk's augmented coordinates and leaves one 16 nct x MP partial per tile row; k_big_tred folds those
-        // into the T slabs.  (The statistics GEMM read K_bar' and K' again -- 258 MB per chunk -- and K_bar' was written for it.)
-        a4.add = ws + pc.Kc; a4.ldadd = MP; a4.rowv = ws + pc.Xaug; a4.stat1 = ws + p.Tp2; a4.ldstat = MP; a4.nct = p.nct;
-        GEMM(false, false, a4);
-        hipLaunchKernelGGL(k_big_tred, dim3((unsigned)((size_t)MP * BIG_XW / 256), BIG_KST), dim3(256), 0, st, pc, ws, ci ? 1 : 0);
+      GEMM(false, false, a4);
+      // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
+      // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
+      GemmArgs at = gemm_args(ws + pc.B, MP, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
+      at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
+      if (p.kernel != TGP_KERNEL_SCALE_RBF) {
+        GemmArgs atk = at;
+        atk.C = ws + p.TpartK;
+        GEMM(true, false, atk);
+        hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
         LAUNCH_CHECK();
-      } else {
-        GEMM(false, false, a4);   // (into the B' buffer)
-        // T slabs (+)= (Kbar' o K'_g)^T Xaug.  RBF: K'_g = K'.  MATERN32: first the statistics with K' itself (only their
-        // ones column is used: d/d outputscale), then K' is overwritten by its derivative weight K'_g
-        GemmArgs at = gemm_args(ws + pc.B, MP, ws + pc.Xaug, BIG_XW, ws + p.Tpart, BIG_XW, MP, BIG_XW, NC, 1.0, ci ? 1.0 : 0.0);
-        at.a_mul = ws + pc.Kc; at.ksplit = BIG_KST; at.cz = (size_t)MP * BIG_XW; at.xcd = 2;
-        if (p.kernel != TGP_KERNEL_SCALE_RBF) {
-          GemmArgs atk = at;
-          atk.C = ws + p.TpartK;
-          GEMM(true, false, atk);
-          hipLaunchKernelGGL(k_big_knm, dim3(MP / 128, NC / 32), dim3(256), 0, st, pc, X + c0 * p.D, nrows, ws, 1);
-          LAUNCH_CHECK();
-        }
-        GEMM(true, false, at);
       }
+      GEMM(true, false, at);
       // G slabs (+)= A'^T diag(vbar) A', lower block triangle
       GemmArgs ag = gemm_args(ws + pc.A, MP, ws + pc.A, MP, ws + p.Gpart, MP, MP, MP, NC, 1.0, ci ? 1.0 : 0.0, TRI_C_LOWER);
       ag.k_scale = ws + p.vb + c0; ag.ksplit = p.ksg; ag.cz = mm; ag.xcd = 2;
       GEMM(true, false, ag);
-      if (fuse) hipLaunchKernelGGL(k_big_sred, dim3(MP / 256, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
-      else hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
+      hipLaunchKernelGGL(k_big_coldot, dim3(MP / 64, BIG_SSL + 1), dim3(256), 0, st, pc, ws, c0, ci ? 1 : 0);
       LAUNCH_CHECK();
       if (aux) HIPCK(hipEventRecord(aux->eB[par], st));
     }

@@ -47,21 +47,6 @@ struct GemmArgs {
   const double* row_scale;
   const double* rowv;
   const double* colv;
-  // statistics of the output formed in the epilogue (EPI 2 / 3; nullptr = off), partial sums per 64-row / 64-column wave tile:
-  //   EPI 2: stat0[(i / 64) * ldstat + j] = sum over the 64 rows i.. of C[i][j]^2 ; stat1[...] = sum of rowv[i] C[i][j]
-  //   EPI 3: stat1[(j / 64) * ldstat + i] = sum over the 64 columns j.. of add[i][j] colv[j]
-  //   EPI 4 (no C store): the tile, multiplied element-wise by add[i][j], is contracted over its ROWS with the augmented
-  //          coordinates rowv[i][0 .. 16 nct) (row length GXW): stat1[((i / 128) * 16 nct + c) * ldstat + j] = sum over the tile's
-  //          128 rows of C[i][j] add[i][j] rowv[i][c] -- the statistics GEMM T of the general-M path in the epilogue of the
-  //          product that forms K_bar (tgp_big.hip)
-  // `statdir` 1 turns EPI 2 / 3 by 90 degrees (the chunk matrices of tgp_big.hip are stored [NC][MP]: data rows are tile rows):
-  //   EPI 2: stat0[(j / 64) * ldstat + i] = sum over the 64 columns j.. of C[i][j]^2 ; stat1[...] = sum of colv[j] C[i][j]
-  //   EPI 3: stat1[(i / 64) * ldstat + j] = sum over the 64 rows i.. of add[i][j] rowv[i]
-  double* stat0;
-  double* stat1;
-  int ldstat;
-  int nct;
-  int statdir;
   int ksplit;          // >= 1
   size_t cz;           // doubles between slab outputs
   int pair;            // set by the launcher: triangular op(B), column tiles j and n/128-1-j handled by one workgroup
@@ -78,7 +63,6 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
   g.alpha = alpha; g.beta = beta; g.tri = tri;
   g.a_mul = nullptr; g.k_scale = nullptr; g.add = nullptr; g.ldadd = 0; g.gamma = 0.0;
   g.col_scale = nullptr; g.row_scale = nullptr; g.rowv = nullptr; g.colv = nullptr; g.ksplit = 1; g.cz = 0; g.xcd = 0; g.pair = 0;
-  g.stat0 = nullptr; g.stat1 = nullptr; g.ldstat = 0; g.nct = 0; g.statdir = 0;
   return g;
 }
 
@@ -89,7 +73,6 @@ inline GemmArgs gemm_args(const double* A, int lda, const double* B, int ldb, do
 #define GLDX 17       /* x-major LDS stage [128][17]: odd stride, conflict-free stores of 128-byte global row segments */
 #define GSTAGE 2304   /* doubles per stage buffer = max(16*144, 128*17) */
 #define GEMM_LDS_BYTES (4 * GSTAGE * sizeof(double))
-#define GXW 128       /* row length of the augmented-coordinate matrix of EPI 4 (tgp_big.hip BIG_XW) */
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -161,14 +144,12 @@ __device__ __forceinline__ double gemm_frag(const double* __restrict__ L, int k,
   return KMAJ ? L[k * GLDK + x] : L[x * GLDX + k];
 }
 
-// MOD: a_mul / k_scale in use; EPI: 0 = store only; 1 = the epilogue reads beta*C or gamma*add (separate instantiations: the
-// plain GEMM keeps its registers); 2 = store only + per-column statistics of the tile (stat0, stat1); 3 = 1 + per-row dot
-// products of the `add` tile with colv (stat1) -- the element-wise passes over the chunk matrices that used to be kernels of
-// their own (k_big_moments, k_big_coldot), formed while the tile is in registers (VERDICT r5 #1a).
+// MOD: a_mul / k_scale in use; EPI: the epilogue reads beta*C or gamma*add (separate instantiations: the plain
+// GEMM keeps its registers).
 //
 // One 128 x 128 output tile.  Kept out of line on purpose: the kernel calls it once or twice (tile pairing) and the
 // register allocator, given the two calls inlined in a loop, spilled ~80 VGPRs of accumulator state.
-template <bool TA, bool TB, bool MOD, int EPI>
+template <bool TA, bool TB, bool MOD, bool EPI>
 __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, int j0, int bz, double* As, double* Bs) {
   // the kernel's only parameter, re-read from the kernarg segment with scalar loads instead of travelling through
   // the call in vector registers or scratch (the address arrives in VGPRs: make it provably uniform first)
@@ -247,68 +228,7 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
     // between two stores makes the second wait for the first to complete (one memory round trip per element).
     // EPI = 1: every optional read (row vectors once, column vectors and the beta*C / gamma*add matrix per
     // 16-column group) is issued ahead of the stores it feeds.  The launcher never sets beta and add together.
-    if (EPI == 4) {
-      // E = alpha acc o add, in place (tile-row group by group: 16 loads in flight); lane (q, r), register (a, b, rr) holds row
-      // 16 a + q + 4 rr, column 16 b + r -- the B-operand layout of a 16 x 16 x 4 product whose k runs over rows 16 a + 4 rr + {0..3}
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        double kn[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            kn[b][rr] = gemm_ld1(g.add + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldadd + j0 + wj + 16 * b + r);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) acc[a][b][rr] = g.alpha * acc[a][b][rr] * kn[b][rr];
-      }
-      __syncthreads();      // every wave is done with the last stage: the stage buffers carry the cross-wave sums below
-      double* red = As;     // 64 lanes x 16 doubles per (column half, coordinate group)
-      for (int ct = 0; ct < g.nct; ++ct) {
-        d4 tacc[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) tacc[b] = {0, 0, 0, 0};
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          double xa[4];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) xa[rr] = gemm_ld1(g.rowv + (size_t)(i0 + wi + 16 * a + 4 * rr + q) * GXW + 16 * ct + r);
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) tacc[b] = TGP_MFMA(xa[rr], acc[a][b][rr], tacc[b]);
-        }
-        // tacc[b][rr'] = sum over this wave's 64 rows: coordinate 16 ct + q + 4 rr', column 16 b + r.  The two waves of a column
-        // half add up through LDS (upper row half first: fixed order), the lower one stores.
-        double* slot = red + ((size_t)(wave & 1) * 64 + lane) * 17;
-        if (wave >> 1) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) slot[4 * b + rr] = tacc[b][rr];
-        }
-        __syncthreads();
-        if (!(wave >> 1)) {
-          double* out = g.stat1 + ((size_t)(i0 >> 7) * 16 * g.nct + 16 * ct) * g.ldstat + j0 + wj;
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              gemm_st1(out + (size_t)(q + 4 * rr) * g.ldstat + 16 * b + r, tacc[b][rr] + slot[4 * b + rr]);
-        }
-        __syncthreads();    // the slots are free for the next coordinate group
-      }
-    } else if (EPI == 0 || EPI == 2) {
-      double rv2[4][4], cv2[4];
-      if (EPI == 2) {       // (requested ahead of the stores: loads and stores share vmcnt)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) rv2[a][rr] = (g.stat1 && !g.statdir) ? gemm_ld1(g.rowv + i0 + wi + 16 * a + q + 4 * rr) : 0.0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) cv2[b] = (g.stat1 && g.statdir) ? gemm_ld1(g.colv + j0 + wj + 16 * b + r) : 0.0;
-      }
+    if (!EPI) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -316,115 +236,46 @@ __device__ __attribute__((noinline)) void gemm_tile(uint64_t kernarg, int i0, in
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr)
             gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r, g.alpha * acc[a][b][rr]);
-      if (EPI == 2 && g.statdir) {
-        // row i of this wave's 64 x 64 tile: 4 column groups in this lane's registers, then the 16 lanes of the row's group
-        const size_t pcol = (size_t)((j0 + wj) >> 6) * g.ldstat;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            double sq = 0.0, dt = 0.0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const double x = g.alpha * acc[a][b][rr];
-              sq = fma(x, x, sq);
-              dt = fma(cv2[b], x, dt);
-            }
-            sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
-            if (g.stat1) { dt += __shfl_xor(dt, 1); dt += __shfl_xor(dt, 2); dt += __shfl_xor(dt, 4); dt += __shfl_xor(dt, 8); }
-            if (r == 0) {
-              const int row = i0 + wi + 16 * a + q + 4 * rr;
-              gemm_st1(g.stat0 + pcol + row, sq);
-              if (g.stat1) gemm_st1(g.stat1 + pcol + row, dt);
-            }
-          }
-      } else if (EPI == 2) {
-        // column j of this wave's 64 x 64 tile: 16 rows in this lane's registers, then the four 16-lane groups (fixed order)
-        const size_t prow = (size_t)((i0 + wi) >> 6) * g.ldstat;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          double sq = 0.0, dt = 0.0;
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const double x = g.alpha * acc[a][b][rr];
-              sq = fma(x, x, sq);
-              dt = fma(rv2[a][rr], x, dt);
-            }
-          sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-          dt += __shfl_xor(dt, 16); dt += __shfl_xor(dt, 32);
-          if (q == 0) {
-            gemm_st1(g.stat0 + prow + j0 + wj + 16 * b + r, sq);
-            if (g.stat1) gemm_st1(g.stat1 + prow + j0 + wj + 16 * b + r, dt);
-          }
-        }
-      }
     } else {
-      // Tile-row group by tile-row group (a): what is live beside the 64 accumulators is one group's 16 elements of the extra
-      // matrix, its 4 + 4 row factors and the 4 + 4 column factors -- the column-group order of rounds 1-5 kept all 32 row
-      // factors (and, with the row dots of EPI 3, 16 running sums) live across the whole epilogue and spilled ~50 registers.
       const bool ha = g.add != nullptr;
       const double* __restrict__ E = ha ? g.add : C;
       const int lde = ha ? g.ldadd : g.ldc;
       const bool he = ha || g.beta != 0.0;
-      const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
-      double cs[4], cv[4];
+      double rs[4][4], rv[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = i0 + wi + 16 * a + q + 4 * rr;
+          rs[a][rr] = g.row_scale ? gemm_ld1(g.row_scale + row) : 1.0;
+          rv[a][rr] = g.rowv ? gemm_ld1(g.rowv + row) : 0.0;
+        }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int col = j0 + wj + 16 * b + r;
-        cs[b] = g.col_scale ? gemm_ld1(g.col_scale + col) : 1.0;
-        cv[b] = g.colv ? gemm_ld1(g.colv + col) : 0.0;
-      }
-      const size_t pcol = EPI == 3 ? (size_t)((j0 + wj) >> 6) * g.ldstat : 0;
-      double sdc[4] = {0.0, 0.0, 0.0, 0.0};       // statdir 1: running column sums of add o rowv over this lane's 16 rows
+        const double cs = g.col_scale ? gemm_ld1(g.col_scale + col) : 1.0;
+        const double cv = g.colv ? gemm_ld1(g.colv + col) : 0.0;
+        double ein[4][4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        double rs[4], rv[4], ein[4][4];
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = i0 + wi + 16 * a + q + 4 * rr;
-          rs[rr] = g.row_scale ? gemm_ld1(g.row_scale + row) : 1.0;
-          rv[rr] = g.rowv ? gemm_ld1(g.rowv + row) : 0.0;
+          for (int rr = 0; rr < 4; ++rr)
+            ein[a][rr] = he ? gemm_ld1(E + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * lde + col) : 0.0;
+        const double ca = ha ? g.gamma : 0.0, cb = ha ? 0.0 : g.beta;
 #pragma unroll
-          for (int b = 0; b < 4; ++b) ein[b][rr] = he ? gemm_ld1(E + (size_t)row * lde + j0 + wj + 16 * b + r) : 0.0;
-        }
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = i0 + wi + 16 * a + q + 4 * rr;
-          double sd = 0.0;
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            double x = g.alpha * acc[a][b][rr] + ca * ein[b][rr];
-            x = x * cs[b] * rs[rr] + rv[rr] * cv[b] + cb * ein[b][rr];
-            gemm_st1(C + (size_t)row * g.ldc + j0 + wj + 16 * b + r, x);
-            if (EPI == 3) {
-              if (g.statdir) sdc[b] = fma(ein[b][rr], rv[rr], sdc[b]);
-              else sd = fma(ein[b][rr], cv[b], sd);
-            }
+          for (int rr = 0; rr < 4; ++rr) {
+            double x = g.alpha * acc[a][b][rr] + ca * ein[a][rr];
+            x = x * cs * rs[a][rr] + rv[a][rr] * cv + cb * ein[a][rr];
+            gemm_st1(C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + col, x);
           }
-          if (EPI == 3 && !g.statdir) {
-            // row `row` of this wave's tile: its 4 column groups are in sd, then the 16 lanes of the row's lane group
-            sd += __shfl_xor(sd, 1); sd += __shfl_xor(sd, 2); sd += __shfl_xor(sd, 4); sd += __shfl_xor(sd, 8);
-            if (r == 0) gemm_st1(g.stat1 + pcol + row, sd);
-          }
-        }
-      }
-      if (EPI == 3 && g.statdir) {
-        // column j: the 16 rows of this lane are in sdc, then the four 16-lane groups (fixed order)
-        const size_t prow = (size_t)((i0 + wi) >> 6) * g.ldstat;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          double x = sdc[b];
-          x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-          if (q == 0) gemm_st1(g.stat1 + prow + j0 + wj + 16 * b + r, x);
-        }
       }
     }
   }
 }
 
-template <bool TA, bool TB, bool MOD, int EPI>
+template <bool TA, bool TB, bool MOD, bool EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   double* As = reinterpret_cast<double*>(gemm_smem);  // 2 stage buffers
@@ -485,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
 // that does not depend on the current step rides in the same launches instead of costing launches -- or cross-queue
 // graph dependencies, ~10 us each under replay -- of its own.  The second GemmArgs sits behind the first in the kernel
 // argument segment (gemm_tile reads its arguments through scalar loads from that segment).
-template <bool TA1, bool TB1, bool MOD1, int EPI1, bool TA2, bool TB2, bool MOD2, int EPI2>
+template <bool TA1, bool TB1, bool MOD1, bool EPI1, bool TA2, bool TB2, bool MOD2, bool EPI2>
 __global__ __launch_bounds__(256, 2) void k_gemm_pair(GemmArgs a, GemmArgs b, int na, int gxa, int gya, int gxb, int gyb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   double* As = reinterpret_cast<double*>(gemm_smem);

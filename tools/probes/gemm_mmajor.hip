@@ -1,3 +1,5 @@
+// (Measured at commit 9d413c0, whose k_gemm had the tile orders `xcd 5` / `xcd 6` and whose launcher took a triangular op(A); the
+//  shipped library is round 5's GEMM again -- see profiles/NOTES.md round 6.)
 // Round 6 (VERDICT r5 #1c): the chunk products of the general-M path in the layout the pipeline ships (chunk matrices [NC][MP],
 // "n-major": the big operand is op(A), x-major) against the m-major layout (chunk matrices [MP][NC]: the small M x M factor is
 // op(A), the big operand op(B) stored [k][n], k-major), with the triangular trimming and tile orders each would launch with.
