@@ -90,7 +90,9 @@ __global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ pa
 }
 
 // transformed shared flow parameters into LDS (same rule as k_prep_a); whole block, ends with a barrier
-__device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, double* tp, double* tg) {
+// `ti` (optional): 1 / tp[i] for every shared parameter, so that a step-tanh step takes 1 / softplus(d_k) from the table instead of
+// running a reciprocal chain per step and sweep
+__device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, double* tp, double* tg, double* ti = nullptr) {
   for (int b = threadIdx.x; b < fp.nblk; b += blockDim.x) {
     const int kind = fp.blk[4 * b], K = fp.blk[4 * b + 1], poff = fp.blk[4 * b + 2], flags = fp.blk[4 * b + 3];
     if (flags & TGP_FLAG_PER_ROW) continue;
@@ -100,8 +102,10 @@ __device__ inline void flow_params_lds(const tgp_model& md, const FlowProg& fp, 
       bool res;
       if (kind == TGP_FLOW_STEPTANH) res = (j & 1);
       else res = (flags & TGP_FLAG_RESTRICT) && j == (kind == TGP_FLOW_AFFINE ? 0 : 1);
-      tp[poff + j] = res ? softplus_d(x) : x;
+      const double tv = res ? softplus_d(x) : x;
+      tp[poff + j] = tv;
       tg[poff + j] = res ? sigmoid_d(x) : 1.0;
+      if (ti != nullptr) ti[poff + j] = rcp_fast(tv);
     }
   }
   __syncthreads();
@@ -130,8 +134,9 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   double* red = accr + (size_t)RP * 256;                    // 16
   double* tp = red + 16;                                    // P+2
   double* tg = tp + (P + 2) / 2 * 2;                        // P+2
+  double* ti = tg + (P + 2) / 2 * 2;                        // P+2: reciprocals (flow_rcp_param)
   for (int i = tid; i < 4 * (P > 0 ? P : 1) + RP * 256; i += 256) accw[i] = 0.0;
-  flow_params_lds(md, fp, tp, tg);
+  flow_params_lds(md, fp, tp, tg, ti);
   // lane group q takes the quadrature nodes s = q + LPR (NB j + u).  Every lane runs the same trip count (wave-wide
   // sums inside the reverse sweep); nodes past S and padding rows carry weight 0.
   const int qn = lane / RW;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
   const bool valid = n < md.N;
   const int nc = valid ? n : md.N - 1;
   const double eta = md.log_var_noise[0], einv = exp(-eta);
-  FlowDev F{fp.blk, fp.nblk, tp, tg};
+  FlowDev F{fp.blk, fp.nblk, tp, tg, ti};
   double ellp = 0.0, etap = 0.0, cm = 0.0, cv = 0.0;
   const double m_ = mu[nc], sq = sqrt(2.0 * v[nc]), y = Y[nc];
   const double* rp = rowp ? rowp + (size_t)nc * RP : nullptr;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_ell_flow(tgp_model md, FlowProg fp, con
       etap += wsn[u] * (-0.5 + 0.5 * einv * r * r);
       c[u] = md.scale * einv * wsn[u] * r;
     }
-    flow_backward_ckpt<NB>(F, c, rp, stack + tid, 256, aw, lane == 0, accr + tid, 256);
+    flow_backward_ckpt<NB>(F, c, rp, stack + tid, 256, aw, lane, accr + tid, 256);
 #pragma unroll
     for (int u = 0; u < NB; ++u) { cm += c[u]; cv += c[u] * xsn[u]; }
   }
@@ -201,9 +206,10 @@ __global__ __launch_bounds__(256) void k_flow_eval(tgp_model md, FlowProg fp, co
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* tp = reinterpret_cast<double*>(smem_raw);
   double* tg = tp + (md.P + 2) / 2 * 2;
+  double* ti = tg + (md.P + 2) / 2 * 2;
   __shared__ double redl[4];
-  flow_params_lds(md, fp, tp, tg);
-  FlowDev F{fp.blk, fp.nblk, tp, tg};
+  flow_params_lds(md, fp, tp, tg, ti);
+  FlowDev F{fp.blk, fp.nblk, tp, tg, ti};
   // four elements per thread, a grid stride apart (coalesced), evaluated stage by stage (flow_forward_n)
   constexpr int NB = 4;
   const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
@@ -417,7 +423,7 @@ int launch_ell_gauss(const double* Y, const double* mu, const double* v, int N, 
 
 static int flow_lds(const tgp_model& md, int nblk, int NB, size_t* bytes) {
   const size_t d = (size_t)(nblk > 0 ? nblk : 1) * NB * 256 + (size_t)(md.P > 0 ? md.P : 1) * 4 + (size_t)md.RP * 256 + 16 +
-                   2 * (size_t)(md.P + 2);
+                   3 * (size_t)(md.P + 2);
   *bytes = d * sizeof(double);
   return *bytes > 160 * 1024 - 1024 ? TGP_E_LDS : 0;
 }
@@ -460,7 +466,7 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
 int launch_flow_eval(const tgp_model& md, const FlowProg& fp, const double* f, int S, int N, const double* rowp, double* G, double* dG,
                      double* logdG, hipStream_t st, double* sum_out, double* ws) {
   const size_t total = (size_t)S * N;
-  const size_t lds = 2 * (size_t)(md.P + 2) * sizeof(double);
+  const size_t lds = 3 * (size_t)(md.P + 2) * sizeof(double);
   const unsigned nb = (unsigned)((total + 1023) / 1024);
   hipLaunchKernelGGL(k_flow_eval, dim3(nb), dim3(256), lds, st, md, fp, f, total, N, rowp, G, dG, logdG,
                      sum_out != nullptr ? ws : (double*)nullptr);
