@@ -106,8 +106,6 @@ extern "C" {
  *     TGP_PLAN_ROWS4_NW4 / TGP_PLAN_ROWS4_NW8  k_rows4 with 4 / 8 waves per workgroup (ignored where its LDS plan or the
  *                          workspace's slab count does not allow it)
  *   bit 4     TGP_PLAN_NO_CHUNK_OVERLAP  general-M path: one set of chunk buffers, forward and backward of the chunks in line
- *   bit 5     TGP_PLAN_NO_CORESIDENT     fused path: the M x M backward launch behind the slab reduction on the caller's stream (rounds
- *                                        1-5) instead of resident beside the row launch on a helper stream
  *   bits 8-23 TGP_PLAN_CHUNK_ROWS(n)     general-M path: row chunks of at most n rows (rounded up to 128; 0 = 16 384) */
 #define TGP_PLAN_ROWS_AUTO 0
 #define TGP_PLAN_ROWS_K16 1
@@ -116,7 +114,6 @@ extern "C" {
 #define TGP_PLAN_ROWS4_NW8 4
 #define TGP_PLAN_ROWS_MASK 15
 #define TGP_PLAN_NO_CHUNK_OVERLAP 16
-#define TGP_PLAN_NO_CORESIDENT 32
 #define TGP_PLAN_CHUNK_ROWS(n) (((((n) + 127) / 128) & 0xffff) << 8)
 #define TGP_PLAN_CHUNK_OF(plan) ((((plan) >> 8) & 0xffff) * 128)
 

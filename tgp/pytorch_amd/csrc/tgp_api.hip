@@ -113,24 +113,6 @@ int tgp_elbo_step_f64(const tgp_model* model, const double* X, const double* Y, 
   return tgp_elbo_step_phases_f64(model, X, Y, rowp, out, grads, mu, v, status, workspace, workspace_bytes, 7u, stream);
 }
 
-// helper stream + events of the co-resident backward launch (one set per host thread, like the general-M path's)
-struct StepFork {
-  hipStream_t aux = nullptr;
-  hipEvent_t ev[2] = {};
-  bool ok = false, tried = false;
-};
-static StepFork* step_fork() {
-  static thread_local StepFork f;
-  if (!f.tried) {
-    f.tried = true;
-    f.ok = hipStreamCreateWithFlags(&f.aux, hipStreamNonBlocking) == hipSuccess;
-    for (auto& e : f.ev)
-      if (f.ok) f.ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    if (!f.ok) (void)hipGetLastError();
-  }
-  return f.ok ? &f : nullptr;
-}
-
 static int elbo_step_impl(const tgp_model* model, const double* X, const double* Y, const double* rowp, double* out,
                           const tgp_grads* grads, double* mu, double* v, int32_t* status, void* workspace,
                           size_t workspace_bytes, uint32_t phases, const tgp_adam_args* adam, void* stream) {
@@ -202,27 +184,8 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
     p.nslots = fp.nslots;
   }
   if (workspace_bytes < p.total * sizeof(double)) return TGP_E_WORKSPACE;
-  // A whole step in one call on k_rows (its passenger blocks carry the hand-off): the M x M backward launch goes to a helper stream
-  // behind the prepare launch and is RESIDENT beside the row launch and the reduction (Plan.cores, tgp_mm.hip) -- its 4 MT + 1
-  // workgroups fit on the CUs the row blocks leave idle, fetch their operands while the rows run, and start on the sums the
-  // moment k_reduce's last workgroup has counted itself.  Event fork / join: valid eagerly and under capture of `stream`.
-  const uint32_t all = TGP_PHASE_PREPARE | TGP_PHASE_ROWS | TGP_PHASE_BACKWARD;
-  StepFork* fk = nullptr;
-  if ((phases & all) == all && p.nw4 == 0 && p.nblocks + 5 * p.MT + 1 <= 256 && !(model->plan & TGP_PLAN_NO_CORESIDENT)) fk = step_fork();
-  p.cores = fk != nullptr ? 1 : 0;
   if (phases & TGP_PHASE_PREPARE)
     if (int rc = launch_prepare(p, md, fp, ws, status, st)) return rc;
-  if (fk != nullptr) {
-    if (hipError_t e = hipEventRecord(fk->ev[0], st); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
-    if (hipError_t e = hipStreamWaitEvent(fk->aux, fk->ev[0], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
-    // (the row launch is ISSUED FIRST: the first-created successor of a fork keeps the parent's hardware queue under graph replay)
-    if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st, status)) return rc;
-    if (int rc = launch_backward_mm(p, md, *grads, out, ws, status, fk->aux, adam != nullptr ? &ad : nullptr, false)) return rc;
-    if (int rc = launch_reduce(p, ws, status, st)) return rc;
-    if (hipError_t e = hipEventRecord(fk->ev[1], fk->aux); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
-    if (hipError_t e = hipStreamWaitEvent(st, fk->ev[1], 0); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
-    return 0;
-  }
   if (phases & TGP_PHASE_ROWS)
     if (int rc = launch_rows(p, md, fp, X, Y, rowp, grads->rowp, mu, v, ws, true, st)) return rc;
   if (phases & TGP_PHASE_BACKWARD)

@@ -61,9 +61,6 @@ struct Plan {
   int rpb;     // data rows per row block (= per slab): 4 * rw or 4 * nw4
   int nslots;  // store-mode flow stack slots
   int zs_lds;  // k_prep_a keeps Zs in LDS (set by the launcher from the LDS budget)
-  int cores;   // 1: k_bwd runs as a graph branch BESIDE the row kernel and k_reduce (round 6): the passenger blocks of k_rows count
-               //    themselves in status[4] once J, H'^T, w are out (written through), k_reduce's workgroups in status[5]; k_bwd's
-               //    roles fetch what depends on neither before they wait for those words
   size_t slab_G, slab_T, slab_S, slab_C, slab_len;  // offsets inside one slab / slab length
   // workspace offsets (doubles)
   size_t hdr, ils, ls, Zs, mpad, w, tp, tg;

@@ -39,8 +39,7 @@ struct AdamDev {
   int32_t* step_dev = nullptr;
 };
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, int32_t* status,
-                       hipStream_t st, const AdamDev* adam = nullptr, bool with_reduce = true);
-int launch_reduce(const Plan& p, double* ws, int32_t* status, hipStream_t st);
+                       hipStream_t st, const AdamDev* adam = nullptr);
 int launch_kmm(const double* Z, const double* raw_ls, const double* raw_os, int M, int D, double jitter, double* K,
                hipStream_t st);
 int launch_knm(const double* X, const double* Z, const double* raw_ls, const double* raw_os, int N, int M, int D,
@@ -58,8 +57,7 @@ int rows_per_wave(const Plan& p, const FlowProg& fp, bool train, int sel = 0);
 // does the training launch of the row kernel fit a CU's LDS with `nslots` flow-stack slots (its leanest form: one node in flight)?
 bool rows_train_lds_fits(const Plan& p, int nslots);
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
-                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st,
-                int32_t* status = nullptr);
+                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st);
 
 // tgp_big.hip (general-M path, 128 < M <= TGP_BIG_MAX_M)
 size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel, int plan = 0);

@@ -405,30 +405,7 @@ size_t prep_a_lds_bytes(const Plan& p) {
 // element instead of four (57 -> 14 KB of G per column block of k_bwd, whose CU pulls ~45 GB/s).
 // ---------------------------------------------------------------------------------------------------
 #define RED_ELEMS (256 / TGP_RSPLIT)
-// the store half of k_reduce for element e: the shares of part_s combined in share order, G tiles mirrored
-__device__ __forceinline__ void reduce_store(const Plan& p, double* __restrict__ ws, size_t e, const double (*part_s)[256 / TGP_RSPLIT],
-                                             int el) {
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < TGP_RSPLIT; ++k) s += part_s[k][el];      // share order, as the consumers of rounds 1-4 added the partials
-  if (e < p.slab_T) {
-    // tile t = (ti,tj), ti >= tj, row-major over the lower triangle of tiles
-    const int t = (int)(e >> 8), in_t = (int)(e & 255), row = in_t >> 4, col = in_t & 15;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    // Diagonal tiles: the MFMA result (a_i vbar) . a_j is not bitwise equal to (a_j vbar) . a_i, so keep the lower
-    // half and mirror it -- G is then exactly symmetric and no element has two writers (run-to-run reproducible).
-    if (ti == tj && col > row) return;
-    double* G = ws + p.Gp;
-    st_wt(&G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col], s);     // (write-through: k_bwd's column blocks start on these)
-    st_wt(&G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row], s);
-  } else {
-    st_wt(&ws[p.redp + e], s);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws, int32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws) {
 #ifdef TGP_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) ws[p.dbg + 200 + 16] = (double)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -457,16 +434,25 @@ __global__ __launch_bounds__(256) void k_reduce(Plan p, double* __restrict__ ws,
   }
   part_s[sh][el] = b1 > b0 ? (s0 + s1) + (s2 + s3) : 0.0;
   __syncthreads();
-  if (p.cores) {
-    // k_bwd is resident beside this launch and starts on the sums the moment every workgroup here has counted itself
-    // (status[5]): the stores below are written through, every wave drains, barrier, one thread counts -- no early return
-    if (sh == 0 && in) reduce_store(p, ws, e, part_s, el);
-    handoff_barrier();
-    if (tid == 0) sync_add(status + 5, 1);
-    return;
-  }
   if (sh != 0 || !in) return;
-  reduce_store(p, ws, e, part_s, el);
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < TGP_RSPLIT; ++k) s += part_s[k][el];      // share order, as the consumers of rounds 1-4 added the partials
+  if (e < p.slab_T) {
+    // tile t = (ti,tj), ti >= tj, row-major over the lower triangle of tiles
+    const int t = (int)(e >> 8), in_t = (int)(e & 255), row = in_t >> 4, col = in_t & 15;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    // Diagonal tiles: the MFMA result (a_i vbar) . a_j is not bitwise equal to (a_j vbar) . a_i, so keep the lower
+    // half and mirror it -- G is then exactly symmetric and no element has two writers (run-to-run reproducible).
+    if (ti == tj && col > row) return;
+    double* G = ws + p.Gp;
+    st_wt(&G[(size_t)(ti * 16 + row) * p.MP + tj * 16 + col], s);     // (write-through: k_bwd's column blocks start on these)
+    st_wt(&G[(size_t)(tj * 16 + col) * p.MP + ti * 16 + row], s);
+  } else {
+    st_wt(&ws[p.redp + e], s);
+  }
 }
 
 __device__ __forceinline__ double red_tail(const Plan& p, const double* __restrict__ ws, size_t e) { return ws[p.redp + e]; }
@@ -544,21 +530,6 @@ __device__ __forceinline__ bool bwd_timed_out(const int32_t* __restrict__ status
   return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)TGP_STATUS_SYNC_TIMEOUT;
 }
 
-// Plan.cores (round 6): k_bwd is a graph branch beside the row kernel and k_reduce.  status[4] = passenger blocks of the row launch
-// that have J, H'^T, w out (MT of them), status[5] = workgroups of k_reduce that have their sums out; both counted behind
-// written-through stores + drain + barrier (tgp_prep.hpp), both zeroed by the final role.  What a role needs from neither it
-// requests before it waits; what it loads behind a word it loads with plain loads: this launch's L2s were invalidated at its
-// start and nothing on the chip reads those buffers between that and the producers' stores.
-__device__ __forceinline__ int bwd_nred(const Plan& p) { return (int)((p.slab_len + RED_ELEMS - 1) / RED_ELEMS); }
-__device__ __forceinline__ void bwd_wait_passengers(const Plan& p, int32_t* __restrict__ status) {
-  const int need = p.MT;
-  bwd_wait(status + 4, [&](int x) { return x >= need; }, status);
-}
-__device__ __forceinline__ void bwd_wait_reduce(const Plan& p, int32_t* __restrict__ status) {
-  const int need = bwd_nred(p);
-  bwd_wait(status + 5, [&](int x) { return x >= need; }, status);
-}
-
 // G(:, c) -> LDS, s(c-block) -> LDS, Lbar block zeroed (both column roles), in two steps so that
 // the caller can put its own operand requests BEHIND these loads and in front of their first use
 // (16-byte loads: two adjacent columns per thread -- what a CU pulls from the Infinity Cache is counted in requests)
@@ -622,7 +593,7 @@ __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md,
   BW_STAMP(c == 0, 4);
   bwd_d2 gv[BWD_G_NIT];
   double sv0;
-  if (!p.cores) bwd_g_issue(p, ws, c0, gv, sv0);
+  bwd_g_issue(p, ws, c0, gv, sv0);
   // ---- behind the G requests: this wave's L_q fragments, its four elements of the factor, their optimiser state ----
   constexpr int PF = TGP_PF2;
   const double* __restrict__ Lq = ws + p.Lq;
@@ -645,10 +616,6 @@ __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md,
     lamv[rr] = md.Lam[e];
     if (upd) { am[rr] = ad.m[ad.lam_off + e]; av[rr] = ad.v[ad.lam_off + e]; }
   }
-  if (p.cores) {   // (status is this role's only use of the pointer as a writer: a wait that expires reports through it)
-    bwd_wait_reduce(p, const_cast<int32_t*>(status));
-    bwd_g_issue(p, ws, c0, gv, sv0);
-  }
   bwd_g_commit(p, Gs, LbL, svL, gv, sv0);
   __syncthreads();
   d4 acc = {0, 0, 0, 0};
@@ -668,8 +635,7 @@ __device__ __forceinline__ void bwd_lam_role(const Plan& p, const tgp_model& md,
 
 // column block c:  Lbar(:, c) = -tril(w s^T + 2 H' G)(:, c) -> LDS;  Q(i, c) = [Phi(L^T Lbar) + Phi(L^T Lbar)^T](i, c), i >= c
 // -> global, mirrored
-__device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ ws, double* sm, int c, int32_t* sb,
-                                           int32_t* __restrict__ status) {
+__device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ ws, double* sm, int c, int32_t* sb) {
   static_assert(TGP_MAX_MT <= BWD_THREADS / 64, "one tile per wave");
   const int MP = p.MP, MT = p.MT;
   double* Gs = sm;                     // MP x 16
@@ -680,7 +646,7 @@ __device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ w
   BW_STAMP(c == 0, 0);
   bwd_d2 gv[BWD_G_NIT];
   double sv0;
-  if (!p.cores) bwd_g_issue(p, ws, c0, gv, sv0);
+  bwd_g_issue(p, ws, c0, gv, sv0);
   // ---- behind the G requests and in front of their first use: the operands of BOTH products of this wave's tile (rows
   //      i0 = 16 (c + wave)) -- 100 KB of H'^T and L fragments per workgroup at ~30 GB/s per CU from the Infinity Cache used to
   //      sit on the chain behind the staging barrier
@@ -695,25 +661,12 @@ __device__ __forceinline__ void bwd_q_role(const Plan& p, double* __restrict__ w
   const int i0 = tw ? c0 : 16 * (c + wave);
   const int n1 = has ? MP / 4 : 0, n2 = has || tw ? (MP - i0) / 4 : 0;
   double hp[PF], pq[PF], wv[4];
-  if (p.cores) {
-    // beside the row launch: L is the prepare launch's (requested at once), H'^T and w the passenger blocks' (behind their
-    // word, while the row blocks still run), G and s the reduction's -- 14 of this block's 171 KB are left behind the last wait
-#pragma unroll
-    for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i0 + 4 * s_ + q) * MP + i0 + r] : 0.0;
-    bwd_wait_passengers(p, status);
-  }
 #pragma unroll
   for (int s_ = 0; s_ < PF; ++s_) hp[s_] = s_ < n1 ? HpT[(size_t)(4 * s_ + q) * MP + i0 + r] : 0.0;
-  if (!p.cores) {
 #pragma unroll
-    for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i0 + 4 * s_ + q) * MP + i0 + r] : 0.0;
-  }
+  for (int s_ = 0; s_ < PF; ++s_) pq[s_] = s_ < n2 ? Lm[(size_t)(i0 + 4 * s_ + q) * MP + i0 + r] : 0.0;
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) wv[rr] = has ? w[i0 + q + 4 * rr] : 0.0;
-  if (p.cores) {
-    bwd_wait_reduce(p, status);
-    bwd_g_issue(p, ws, c0, gv, sv0);
-  }
   bwd_g_commit(p, Gs, LbL, svL, gv, sv0);
   __syncthreads();
   BW_STAMP(c == 0, 1);
@@ -788,7 +741,6 @@ __device__ __forceinline__ void bwd_row_role(const Plan& p, double* __restrict__
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) kmv[rr] = (ws + p.Kmm)[(size_t)(i0 + q + 4 * rr) * MP + j0w + r];
   if (tid < 16 * DP) zsL[tid] = (ws + p.Zs)[(size_t)i0 * DP + tid];
-  if (p.cores) bwd_wait_passengers(p, status);     // J is the passenger blocks'
   for (int e = tid; e < (MP - i0) * 16; e += BWD_THREADS) Ja[e] = J[(size_t)(i0 + (e >> 4)) * MP + i0 + (e & 15)];
   // second product of wave j: k over the rows of this half's column tiles at or below tile j (J[k, j] = 0 for k < j)
   const int ks0 = 16 * (jbw > kb0 ? jbw : kb0), ks1 = 16 * kb1;
@@ -878,7 +830,6 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
     }
   };
   // ---- everything that depends on k_reduce only: before the wait ----
-  if (p.cores) bwd_wait_reduce(p, status);
   for (int i = tid; i < M; i += NT) put(g.m, i, red_tail(p, ws, p.slab_S + i) - md.kl_scale * md.m[i]);
   if (g.theta != nullptr)
     for (int i = tid; i < p.P; i += NT) put(g.theta, i, red_tail(p, ws, p.slab_C + C_THETA + i));
@@ -981,7 +932,6 @@ __device__ __forceinline__ void bwd_final_role(const Plan& p, const tgp_model& m
   __syncthreads();   // EVERY wave of this workgroup has seen the count before it is zeroed (a wave still polling would never see it again)
   if (tid == 0) {
     sync_st(sb + SB_PROG, 0); sync_st(sb + SB_LEFT, 0);
-    if (p.cores) { sync_st(status + 4, 0); sync_st(status + 5, 0); }   // the passengers' and the reduction's words: their launches are over
     if (ad.p != nullptr && !timed_out) atomicAdd(&ad.step_dev[0], 1);
   }
   BW_STAMP(true, 15);
@@ -994,7 +944,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_bwd(Plan p, tgp_model md, tgp_g
   const int MT = p.MT, b = (int)blockIdx.x;
   int32_t* sb = status + 6;
   if (b < MT) {
-    bwd_q_role(p, ws, sm, b, sb, status);
+    bwd_q_role(p, ws, sm, b, sb);
     bwd_leave(sb);
   } else if (b < 2 * MT) {
     bwd_lam_role(p, md, g, ws, ad, sm, b - MT, status);
@@ -1291,18 +1241,11 @@ int launch_prepare(const Plan& p_in, const tgp_model& md, const FlowProg& fp, do
   return 0;
 }
 
-int launch_reduce(const Plan& p, double* ws, int32_t* status, hipStream_t st) {
-  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + RED_ELEMS - 1) / RED_ELEMS)), dim3(256), 0, st, p, ws, status);
-  LAUNCH_CHECK();
-  return 0;
-}
-
-// `with_reduce` false: the caller has launched (or will launch) k_reduce itself -- Plan.cores, where k_bwd goes to another stream
 int launch_backward_mm(const Plan& p, const tgp_model& md, const tgp_grads& g, double* out, double* ws, int32_t* status,
-                       hipStream_t st, const AdamDev* adam, bool with_reduce) {
+                       hipStream_t st, const AdamDev* adam) {
   const AdamDev ad = adam != nullptr ? *adam : AdamDev();
-  if (with_reduce)
-    if (int rc = launch_reduce(p, ws, status, st)) return rc;
+  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p.slab_len + RED_ELEMS - 1) / RED_ELEMS)), dim3(256), 0, st, p, ws);
+  LAUNCH_CHECK();
   const size_t lds_col = (size_t)(2 * p.MP * 16 + 16), lds_row = (size_t)p.MT * 256 + 16 * p.DP + (size_t)p.MP * 16,
                lds_fin = (size_t)p.M * (p.D + 1) + (adam != nullptr && ad.n - ad.lam_n <= BWD_MIRROR_MAX ? (size_t)(ad.n - ad.lam_n) : 0) + p.M;   // + the LDS mirror of the gradients + cs
   const size_t lds = sizeof(double) * (lds_col > lds_row ? (lds_col > lds_fin ? lds_col : lds_fin) : (lds_row > lds_fin ? lds_row : lds_fin));

@@ -43,14 +43,11 @@ bool rows_train_lds_fits(const Plan& p, int nslots) {
 }
 
 int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const double* X, const double* Y,
-                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st,
-                int32_t* status) {
+                const double* rowp, double* g_rowp, double* mu, double* v, double* ws, bool train, hipStream_t st) {
   RowArgs a;
   a.p = p;
   a.X = X; a.Y = Y; a.rowp = rowp; a.g_rowp = g_rowp; a.mu = mu; a.v = v; a.ws = ws;
   a.prog = fp; a.xs = md.xs; a.wn = md.wn; a.scale = md.scale;
-  a.status = status;
-  if (status == nullptr) a.p.cores = 0;
   const size_t lim = 160 * 1024 - 1024;
   int mode = 0;
   size_t lds = row_lds(p, 0, 0).total * sizeof(double);

@@ -45,7 +45,6 @@ struct RowArgs {
   const double* xs;
   const double* wn;
   double scale;
-  int32_t* status;   // hand-off words (Plan.cores: the passenger blocks count themselves in status[4])
 };
 
 // LDS carve-up (offsets in doubles)
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < MT; ++i) {
         if (i < c) continue;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) st_wt(&a.ws[p.J + (size_t)(16 * i + 4 * rr + q) * MP + 16 * c + nl], Jt[i][rr]);
+        for (int rr = 0; rr < 4; ++rr) a.ws[p.J + (size_t)(16 * i + 4 * rr + q) * MP + 16 * c + nl] = Jt[i][rr];
       }
     }
     for (int jj = wv; jj < MT; jj += 4) {
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int s4 = 0; s4 < 4; ++s4) h = TGP_MFMA(Jt[kb][s4], bf[kb][s4], h);
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) st_wt(&a.ws[p.HpT + (size_t)(16 * jj + nl) * MP + 16 * c + 4 * rr + q], h[rr]);
+      for (int rr = 0; rr < 4; ++rr) a.ws[p.HpT + (size_t)(16 * jj + nl) * MP + 16 * c + 4 * rr + q] = h[rr];
     }
     if (wv == 3) {
       double sw = 0.0;
@@ -299,13 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int rr = 0; rr < 4; ++rr) sw += Jt[i][rr] * mf[i][rr];
       }
       sw = quad_sum(sw);
-      if (q == 0) st_wt(&a.ws[p.w + 16 * c + nl], sw);
-    }
-    if (p.cores) {
-      // k_bwd runs beside this launch: its column blocks fetch H'^T and w as soon as all MT passenger blocks have counted
-      // themselves (the stores above are written through; every wave drains them, the workgroup passes its barrier, one thread counts)
-      handoff_barrier();
-      if (threadIdx.x == 0) sync_add(a.status + 4, 1);
+      if (q == 0) a.ws[p.w + 16 * c + nl] = sw;
     }
     return;
   }

@@ -23,7 +23,6 @@ KERNELS = {"scale_rbf": KERNEL_SCALE_RBF, "scale_matern32": KERNEL_SCALE_MATERN3
 # tgp_model.plan (include/tgp_hip.h TGP_PLAN_*): kernel-selection overrides of ONE call; 0 = the library's choice
 PLAN_ROWS_AUTO, PLAN_ROWS_K16, PLAN_ROWS_K, PLAN_ROWS4_NW4, PLAN_ROWS4_NW8 = 0, 1, 2, 3, 4
 PLAN_NO_CHUNK_OVERLAP = 16
-PLAN_NO_CORESIDENT = 32
 
 
 def plan_chunk_rows(n):
