@@ -1,7 +1,7 @@
 #!/bin/bash
 # The command sequence behind profiles/<tag>_* (run on the GPU box through gpurun; raw outputs under gpurun_out/<tag>,
 # tools/probes/copy_profiles.sh copies the summaries into profiles/).   tools/probes/profile_round.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/../.." && pwd)}
 O=gpurun_out/$TAG
 cd "$R" || exit 1
@@ -50,6 +50,9 @@ for w in tgp_airline_mb10k tgp_airline_mb10k_rank8; do
 done
 TGP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline 2> /dev/null | grep "^{" > $O/bench_selflaunch_2ranks_1gpu_gloo_strong.json
 cut -c1-230 $O/bench_selflaunch_2ranks_1gpu_gloo_strong.json
+python bench.py --allreduce-only 2> /dev/null | grep "^{" > $O/allreduce_only_1rank.json; cut -c1-300 $O/allreduce_only_1rank.json
+# ---- the same bench lines on the previous round's tree, alternately, on THIS box (a git worktree of its commit under ab_r05/, built there)
+[ -d ab_r05 ] && bash tools/probes/ab_r05.sh > $O/ab_previous_round.txt 2>&1 && cat $O/ab_previous_round.txt
 # ---- kernel stats ----
 cd /tmp
 PG=$(fresh prof_graph); PI=$(fresh prof_graph_idtgp); PE=$(fresh prof_eager); PB=$(fresh prof_big); PM=$(fresh prof_mb); PBE=$(fresh prof_big_eager)
