@@ -440,13 +440,28 @@ struct G64Args {
   const double* colv;
 };
 
+// Round 6: 8 waves per workgroup.  The 4-wave form ran one wave per SIMD whenever a tile had its CU to itself -- the heavy tiles of a
+// triangular product in the tail of the launch -- and a lone wave exposes every LDS store, barrier and fragment read of the
+// single-buffered stage: the longest tile (16 k-blocks at M = 1024) took 60 us where its MFMAs are 30, and set the launch's time
+// (72 us for 20 us of work per CU at 1 280 rows).  Now the k range of a tile is split over TWO groups of 4 waves (own stage buffers,
+// two waves per SIMD: one group's MFMAs cover the other's staging), the second group's accumulators reach the first through LDS
+// (fixed order: group 0 + group 1) and group 0 runs the epilogue.  One workgroup per CU.
+#define G64_THREADS 512
+#define G64_LDK 80                                      /* row length of the k-major B stage */
+#define G64_GRP ((size_t)64 * FAC_LD + 64 * G64_LDK)    /* doubles of stage buffers per wave group */
+#define G64_LDS_BYTES (2 * G64_GRP * sizeof(double))
 template <bool TB, bool EPI>
-__device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, double* As, double* Bs) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+__device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, double* smem) {
+  const int tid8 = threadIdx.x, grp = tid8 >> 8, tid = tid8 & 255, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  double* As = smem + (size_t)grp * G64_GRP;
+  double* Bs = As + 64 * FAC_LD;     // TB: [x][FAC_LD] like As ; else k-major [k][G64_LDK] (no transposing store: see store_stage)
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   int kb = 0, ke = g.k;
   if (g.tri & TRI_B_LOWER) kb = max(kb, j0);
   if (g.tri & TRI_B_UPPER) ke = min(ke, j0 + 64);
+  // group 0: the first n0 = ceil(nblk / 2) k-blocks, group 1 the rest; both run n0 trips (the barriers are the workgroup's)
+  const int nblk = (ke - kb) / 64, n0 = (nblk + 1) / 2, nmine = grp ? nblk - n0 : n0;
+  const int kmine = kb + (grp ? n0 * 64 : 0);
   d2 ra[8], rb[8];
   auto load_stage = [&](int k0) {
 #pragma unroll
@@ -463,10 +478,9 @@ __device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, doubl
       const int e = tid + 256 * u, x = e >> 5, k2 = e & 31;
       *reinterpret_cast<d2*>(As + x * FAC_LD + 2 * k2) = ra[u];
       if (TB) *reinterpret_cast<d2*>(Bs + x * FAC_LD + 2 * k2) = rb[u];
-      else {
-        Bs[(2 * k2) * FAC_LD + x] = rb[u][0];        // here x is the k row (e >> 5) and k2 the column pair
-        Bs[(2 * k2 + 1) * FAC_LD + x] = rb[u][1];
-      }
+      // (round 6: B stored [k][n] keeps that layout in LDS -- the transposing pair of scalar stores of rounds 3-5 put the 32
+      //  lanes of a row on 4 banks; rows of 80 doubles: 16-byte stores and the fragment reads of a half wave are conflict-free)
+      else *reinterpret_cast<d2*>(Bs + x * G64_LDK + 2 * k2) = rb[u];       // here x is the k row (e >> 5) and k2 the column pair
     }
   };
   d4 acc[2][2];
@@ -474,25 +488,46 @@ __device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, doubl
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = {0, 0, 0, 0};
-  if (kb < ke) load_stage(kb);
-  for (int k0 = kb; k0 < ke; k0 += 64) {
-    store_stage();
+  if (nmine > 0) load_stage(kmine);
+  for (int it = 0; it < n0; ++it) {
+    const bool act = it < nmine;
+    if (act) store_stage();
     __syncthreads();
-    if (k0 + 64 < ke) load_stage(k0 + 64);
+    if (it + 1 < nmine) load_stage(kmine + 64 * (it + 1));
+    if (act) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      double af[2], bf[2];
+      for (int s = 0; s < 16; ++s) {
+        double af[2], bf[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = As[(wi + 16 * a + r) * FAC_LD + 4 * s + q];
+        for (int a = 0; a < 2; ++a) af[a] = As[(wi + 16 * a + r) * FAC_LD + 4 * s + q];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bf[b] = Bs[(wj + 16 * b + r) * FAC_LD + 4 * s + q];
+        for (int b = 0; b < 2; ++b) bf[b] = TB ? Bs[(wj + 16 * b + r) * FAC_LD + 4 * s + q] : Bs[(4 * s + q) * G64_LDK + wj + 16 * b + r];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = TGP_MFMA(af[a], bf[b], acc[a][b]);
+          for (int b = 0; b < 2; ++b) acc[a][b] = TGP_MFMA(af[a], bf[b], acc[a][b]);
+      }
     }
     __syncthreads();
   }
+  // group 1's accumulators -> LDS (its own, now idle, stage buffers: 4 waves x 64 lanes x 16 doubles), group 0 adds them
+  double* xch = smem + G64_GRP + (size_t)(wave * 64 + lane) * 17;
+  if (grp) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) xch[(2 * a + b) * 4 + rr] = acc[a][b][rr];
+  }
+  __syncthreads();
+  if (grp) return;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[a][b][rr] += xch[(2 * a + b) * 4 + rr];
   if (!EPI) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -541,23 +576,22 @@ __device__ __forceinline__ void g64_tile(const G64Args& g, int i0, int j0, doubl
 }
 
 template <bool EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm64(G64Args g, int gx, int gy8) {
+__global__ __launch_bounds__(G64_THREADS) void k_gemm64(G64Args g, int gx, int gy8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char g64_smem[];
-  double* As = reinterpret_cast<double*>(g64_smem);
-  double* Bs = As + 64 * FAC_LD;
+  double* smem = reinterpret_cast<double*>(g64_smem);
   // per-XCD heaviest-column-first order: XCD xc owns the tile rows xc, xc + 8, ...
   const int L = blockIdx.x, xc = L & 7, sq = L >> 3, nrx = gy8 >> 3;
   const int w = sq / nrx, by = xc + 8 * (sq % nrx);
   int bx = w;
   if (g.tri & TRI_B_UPPER) bx = gx - 1 - w;
   if (by * 64 >= g.m) return;
-  if (g.tb) g64_tile<true, EPI>(g, by * 64, bx * 64, As, Bs);
-  else g64_tile<false, EPI>(g, by * 64, bx * 64, As, Bs);
+  if (g.tb) g64_tile<true, EPI>(g, by * 64, bx * 64, smem);
+  else g64_tile<false, EPI>(g, by * 64, bx * 64, smem);
 }
 
 static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st) {
   static bool attr_done[2] = {false, false};
-  const size_t lds = (size_t)2 * 64 * FAC_LD * sizeof(double);
+  const size_t lds = G64_LDS_BYTES;
   const bool epi = gemm_has_epi(g);
   const void* f = epi ? reinterpret_cast<const void*>(k_gemm64<true>) : reinterpret_cast<const void*>(k_gemm64<false>);
   if (!attr_done[epi]) {
@@ -571,8 +605,8 @@ static int launch_gemm64(bool tb, const GemmArgs& g, hipStream_t st) {
   a.add = g.add; a.ldadd = g.ldadd; a.gamma = g.gamma; a.beta = g.beta; a.col_scale = g.col_scale; a.row_scale = g.row_scale;
   a.rowv = g.rowv; a.colv = g.colv;
   const int gx = g.n / 64, gy8 = (g.m / 64 + 7) & ~7;
-  if (epi) hipLaunchKernelGGL(k_gemm64<true>, dim3((unsigned)(gx * gy8)), dim3(256), lds, st, a, gx, gy8);
-  else hipLaunchKernelGGL(k_gemm64<false>, dim3((unsigned)(gx * gy8)), dim3(256), lds, st, a, gx, gy8);
+  if (epi) hipLaunchKernelGGL(k_gemm64<true>, dim3((unsigned)(gx * gy8)), dim3(G64_THREADS), lds, st, a, gx, gy8);
+  else hipLaunchKernelGGL(k_gemm64<false>, dim3((unsigned)(gx * gy8)), dim3(G64_THREADS), lds, st, a, gx, gy8);
   LAUNCH_CHECK();
   return 0;
 }
