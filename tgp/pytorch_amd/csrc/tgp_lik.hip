@@ -18,14 +18,19 @@ namespace tgp {
 // k_ell_flow: lanes per data row.  4 by default (64 rows per workgroup); 16 for small problems (16 rows per workgroup): a
 // rank's 1 250 rows of an 8-GPU minibatch were 20 workgroups, each lane walking 8 quadrature nodes through 30 tanh steps
 // and back -- 91 us of one dependent chain, whatever N; with 16 lanes per row a lane has 2 nodes and 79 workgroups run.
+// Round 6: 32 lanes per row (8 rows per workgroup, one node per lane at S = 32) below 2 560 rows -- the 1 250-row share again: 79
+// workgroups leave three quarters of the SIMDs without a wave, and a lane's chain is as long as its nodes.
 #define ELL_LPR16_MAXN 12288
-static int ell_flow_lpr(int N) { return N <= ELL_LPR16_MAXN ? 16 : 4; }
+#define ELL_LPR32_MAXN 2560
+static int ell_flow_lpr(int N) { return N <= ELL_LPR32_MAXN ? 32 : (N <= ELL_LPR16_MAXN ? 16 : 4); }
 
 // Sized for ANY call with at most N rows: a caller that sizes once for its largest chunk (the general-M path) may
 // launch a ragged last chunk that falls into the 16-lanes-per-row mode and then has MORE workgroups than the largest one.
 size_t lik_workspace_doubles(int N, int P, int RP) {
   const size_t nb16 = (size_t)((N < ELL_LPR16_MAXN ? N : ELL_LPR16_MAXN) + 15) / 16, nb64 = (size_t)(N + 63) / 64;
-  const size_t nb = (nb16 > nb64 ? nb16 : nb64) + 1;  // k_ell_flow: one partial per workgroup
+  const size_t nb32 = (size_t)((N < ELL_LPR32_MAXN ? N : ELL_LPR32_MAXN) + 7) / 8;
+  const size_t nbm = nb16 > nb64 ? nb16 : nb64;
+  const size_t nb = (nbm > nb32 ? nbm : nb32) + 1;  // k_ell_flow: one partial per workgroup
   return nb * (size_t)(2 + P) + 2 * (size_t)P + 64;
 }
 
@@ -435,12 +440,12 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
   // the shared-parameter partials are then paid once), else fewer
   size_t lds = 0;
   const int LPR = ell_flow_lpr(md.N);
-  int NB = LPR == 4 ? (md.S > 16 ? 8 : 4) : (md.S > 32 ? 4 : (md.S > 16 ? 2 : 1));
+  int NB = LPR == 4 ? (md.S > 16 ? 8 : 4) : (LPR == 16 ? (md.S > 32 ? 4 : (md.S > 16 ? 2 : 1)) : (md.S > 64 ? 4 : (md.S > 32 ? 2 : 1)));
   while (NB > 1 && (flow_lds(md, fp.nblk, NB, &lds) != 0 || lds > 120 * 1024)) NB >>= 1;
   if (int rc = flow_lds(md, fp.nblk, NB, &lds)) return rc;
   const int rows = 256 / LPR;
   const int nb = (md.N + rows - 1) / rows;
-  static size_t cur[8] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+  static size_t cur[10] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
 #define ELLF_LAUNCH(lpr, nbv, slot)                                                                                         \
   do {                                                                                                                      \
     if (int rc = ensure_lds(reinterpret_cast<const void*>(k_ell_flow<lpr, nbv>), lds, &cur[slot])) return rc;               \
@@ -451,10 +456,14 @@ int launch_ell_flow(const tgp_model& md, const FlowProg& fp, const double* Y, co
     else if (NB == 4) ELLF_LAUNCH(4, 4, 1);
     else if (NB == 2) ELLF_LAUNCH(4, 2, 2);
     else ELLF_LAUNCH(4, 1, 3);
-  } else {
+  } else if (LPR == 16) {
     if (NB == 4) ELLF_LAUNCH(16, 4, 4);
     else if (NB == 2) ELLF_LAUNCH(16, 2, 5);
     else ELLF_LAUNCH(16, 1, 6);
+  } else {
+    if (NB == 4) ELLF_LAUNCH(32, 4, 7);
+    else if (NB == 2) ELLF_LAUNCH(32, 2, 8);
+    else ELLF_LAUNCH(32, 1, 9);
   }
 #undef ELLF_LAUNCH
   LAUNCH_CHECK();
