@@ -92,22 +92,22 @@ def rows_kernel_flops(w):
     return 3.0 * fwd
 
 
-# ---- the builder's PREDICTION of a multi-GPU line (VERDICT r4 #5b): per-kernel times measured on ONE MI355X (profiles/r05_*,
+# ---- the builder's PREDICTION of a multi-GPU line (VERDICT r4 #5b): per-kernel times measured on ONE MI355X (profiles/r06_*,
 # microseconds) + a stated estimate of the collective, so that the first SCALE record can be judged against a number.
 # Every multi-GPU entry is UNMEASURED ON HARDWARE: no multi-GPU node was available to the builder in any round.
 EXPECT = {
     # fused path (M <= 128): prepare + [rows(N_rank)] + slab reduction + the M x M adjoint launch; with more than one rank the
     # Adam update is a launch of its own behind the collective (one rank: inside the adjoint launch)
     # rows: in-step duration of the row kernel the library picks at that many rows per rank (k_rows<..,10> at 8611, k_rows4 with
-    # 8-wave workgroups at 4306, 4-wave below; profiles/r05_rows_kernel_time.txt back-to-back + 1.3 us in-step: the kernel
+    # 8-wave workgroups at 4306, 4-wave below; profiles/r06_rows_kernel_time.txt back-to-back + 1.3 us in-step: the kernel
     # statistics of the 1-GPU step); bwd: k_bwd without the update in it
-    "tgp_power_tanh3x2": dict(prep=24.5, rows={8611: 46.1, 4306: 41.2, 2153: 33.6, 1077: 33.5}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
-    "tgp_power_sal2": dict(prep=24.5, rows={8611: 42.0, 4306: 37.6, 2153: 31.1, 1077: 30.8}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
-    "svgp_power": dict(prep=24.5, rows={8611: 35.8, 4306: 32.0, 2153: 26.4, 1077: 26.2}, reduce=4.5, bwd=20.2, bwd_w=19.4, adam=4.6),
+    "tgp_power_tanh3x2": dict(prep=24.3, rows={8611: 43.6, 4306: 41.5, 2153: 33.4, 1077: 33.2}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
+    "tgp_power_sal2": dict(prep=24.3, rows={8611: 40.2, 4306: 37.9, 2153: 30.9, 1077: 30.7}, reduce=4.9, bwd=20.2, bwd_w=19.4, adam=4.6),
+    "svgp_power": dict(prep=24.3, rows={8611: 33.8, 4306: 32.3, 2153: 26.2, 1077: 26.1}, reduce=4.5, bwd=20.2, bwd_w=19.4, adam=4.6),
     # general-M path: the single-GPU step of the workload (weak scaling: every rank runs it on its own shard) and, for the
     # minibatch split 8 ways, the measured per-rank share (tgp_airline_mb10k_rank8)
-    "tgp_airline_tanh5x6": dict(ms=31.4),
-    "tgp_airline_mb10k": dict(ms=2.25, strong_ms={8: 1.26}),
+    "tgp_airline_tanh5x6": dict(ms=31.3),
+    "tgp_airline_mb10k": dict(ms=2.25, strong_ms={8: 1.205}),
 }
 
 
@@ -134,7 +134,7 @@ def expected_line(workload, w, world, scaling, n_doubles, measured_ms_1gpu=None)
                  "%.1f us (ESTIMATE: 8 us + 2 us per ring step + wire time; unmeasured on hardware)"
                  % (e["prep"], nr, e["rows"][key], e["reduce"], bwd, " + k_adam_dev %.1f" % e["adam"] if world > 1 else "",
                     n_doubles, ar))
-        return {"ms_per_step": us * 1e-3, "value": 1e6 / us, "basis": basis, "measured_on": "1 x MI355X per-kernel times, profiles/r05_*"}
+        return {"ms_per_step": us * 1e-3, "value": 1e6 / us, "basis": basis, "measured_on": "1 x MI355X per-kernel times, profiles/r06_*"}
     if measured_ms_1gpu is None and e is not None and "ms" in e:
         measured_ms_1gpu = e.get("strong_ms", {}).get(world) if scaling == "strong" and world > 1 else e["ms"]
     if measured_ms_1gpu is not None:
