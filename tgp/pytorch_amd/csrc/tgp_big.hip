@@ -167,31 +167,8 @@ size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP
 // ---------------------------------------------------------------------------------------------------
 // GEMM launcher
 // ---------------------------------------------------------------------------------------------------
-template <bool TA, bool TB, bool MOD, bool EPI>
-static int launch_gemm_t(const GemmArgs& g, hipStream_t st) {
-  static bool attr_done = false;
-  const void* f = reinterpret_cast<const void*>(k_gemm<TA, TB, MOD, EPI>);
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
-    attr_done = true;
-  }
-  const int nj = g.n / GT, nb = g.m / GT;
-  dim3 grid(g.pair ? (nj + 1) / 2 : nj, nb, g.ksplit), block(256);
-  if (g.xcd == 3) grid = dim3(nb * (nb + 1) / 2 * g.ksplit, 1, 1);
-  if (g.xcd == 4) grid.y = (nb + 7) & ~7;   // whole groups of 8 tile rows (one per XCD); the padding rows return at once
-  hipLaunchKernelGGL((k_gemm<TA, TB, MOD, EPI>), grid, block, GEMM_LDS_BYTES, st, g);
-  LAUNCH_CHECK();
-  return 0;
-}
-
-template <bool MOD, bool EPI>
-static int launch_gemm_l(bool ta, bool tb, const GemmArgs& g, hipStream_t st) {
-  if (ta && tb) return launch_gemm_t<true, true, MOD, EPI>(g, st);
-  if (ta) return launch_gemm_t<true, false, MOD, EPI>(g, st);
-  if (tb) return launch_gemm_t<false, true, MOD, EPI>(g, st);
-  return launch_gemm_t<false, false, MOD, EPI>(g, st);
-}
+// (the 128 x 128 kernels and their launchers are a translation unit of their own, tgp_gemm128.hip: they are built with
+// another instruction scheduler -- see the Makefile)
 
 // argument checks and the launcher-set fields (pair, xcd); 0 or -1
 static int gemm_normalise(GemmArgs& g) {
@@ -259,8 +236,7 @@ int launch_gemm(bool ta, bool tb, const GemmArgs& g_in, hipStream_t st) {
   }
   const bool mod = g.a_mul != nullptr || g.k_scale != nullptr;
   const bool epi = g.add != nullptr || g.beta != 0.0 || g.col_scale || g.row_scale || g.rowv || g.colv;
-  if (mod) return epi ? launch_gemm_l<true, true>(ta, tb, g, st) : launch_gemm_l<true, false>(ta, tb, g, st);
-  return epi ? launch_gemm_l<false, true>(ta, tb, g, st) : launch_gemm_l<false, false>(ta, tb, g, st);
+  return launch_gemm128(ta, tb, mod, epi, g, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -626,22 +602,7 @@ static int launch_gemm_pair_ft_ff(const GemmArgs& a_in, const GemmArgs& b_in, hi
   const int gxa = a.pair ? (a.n / GT + 1) / 2 : a.n / GT, gya = a.m / GT;
   const int gxb = b.pair ? (b.n / GT + 1) / 2 : b.n / GT, gyb = b.m / GT;
   const int na = gxa * gya, nbk = gxb * gyb;
-  static bool attr_done[2] = {false, false};
-  const void* f = epi ? reinterpret_cast<const void*>(k_gemm_pair<false, true, false, true, false, false, false, true>)
-                      : reinterpret_cast<const void*>(k_gemm_pair<false, true, false, false, false, false, false, false>);
-  if (!attr_done[epi]) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
-    attr_done[epi] = true;
-  }
-  if (epi)
-    hipLaunchKernelGGL((k_gemm_pair<false, true, false, true, false, false, false, true>), dim3(na + nbk), dim3(256), GEMM_LDS_BYTES, st,
-                       a, b, na, gxa, gya, gxb, gyb);
-  else
-    hipLaunchKernelGGL((k_gemm_pair<false, true, false, false, false, false, false, false>), dim3(na + nbk), dim3(256), GEMM_LDS_BYTES, st,
-                       a, b, na, gxa, gya, gxb, gyb);
-  LAUNCH_CHECK();
-  return 0;
+  return launch_gemm128_pair_ft_ff(epi, a, b, na, gxa, gya, gxb, gyb, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -366,6 +366,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pair(GemmArgs a, GemmArgs b, in
   }
 }
 
-int launch_gemm(bool ta, bool tb, const GemmArgs& g, hipStream_t st);  // tgp_big.hip
+int launch_gemm(bool ta, bool tb, const GemmArgs& g, hipStream_t st);  // tgp_big.hip (checks, tiling choice)
+// tgp_gemm128.hip: the 128 x 128 kernels' launchers, on arguments launch_gemm has normalised
+int launch_gemm128(bool ta, bool tb, bool mod, bool epi, const GemmArgs& g, hipStream_t st);
+int launch_gemm128_pair_ft_ff(bool epi, const GemmArgs& a, const GemmArgs& b, int na, int gxa, int gya, int gxb, int gyb,
+                              hipStream_t st);
 
 }  // namespace tgp

@@ -5,7 +5,7 @@ mkdir -p "$ROOT/tools/probes/stamp"
 cd "$ROOT/tgp/pytorch_amd/csrc"
 O=../../../tools/probes/stamp
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DTGP_STAMPS $TGP_EXTRA"   # (the Makefile's flags)
-for f in tgp_api tgp_comm tgp_mm tgp_lik tgp_rows tgp_big tgp_kmeans tgp_mlp; do /opt/rocm/bin/hipcc $F -c $f.hip -o $O/$f.o & done
+for f in tgp_api tgp_comm tgp_mm tgp_lik tgp_rows tgp_big tgp_gemm128 tgp_kmeans tgp_mlp; do /opt/rocm/bin/hipcc $F -c $f.hip -o $O/$f.o & done
 wait
 for n in 1 2 3 4 5 6 7 8; do /opt/rocm/bin/hipcc $F -mllvm -amdgpu-sched-strategy=iterative-ilp -DTGP_MT=$n -c tgp_rows_inst.hip -o $O/mt$n.o & done
 wait
