@@ -18,6 +18,7 @@
 #include "tgp_dev.hpp"
 #include "tgp_gemm.hpp"
 #include "tgp_launch.hpp"
+#include "tgp_prep.hpp"   // hand-off primitives (sync_wait / sync_add / st_agent / ld_agent)
 
 namespace tgp {
 
@@ -258,7 +259,8 @@ struct FacJob {
 #define FAC_LD 68
 #define FAC_LDS_BYTES ((size_t)160 * FAC_LD * sizeof(double))
 
-template <int WM, int WN, bool TB>
+// SC1: the result is stored write-through (st_agent): a workgroup of the SAME launch reads it (k_fac_potrf's diagonal tiles)
+template <int WM, int WN, bool TB, bool SC1 = false>
 __device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double* As, double* Bs) {
   constexpr int TM = 32 * WM, TN = 32 * WN;
   constexpr int NA = TM * 32 / 256;                 // d2 loads per thread for a [TM][64] half of A (8 .. 16 .. 4)
@@ -344,17 +346,23 @@ __device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
-        g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr];
+        st_maybe<SC1>(g.C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r,
+                      g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr]);
 }
 
+template <bool SC1 = false>
 __device__ __forceinline__ void fac_job(const FacJob& g, int L, double* As, double* Bs) {
   const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
   const int gx = g.n / TN, bx = L % gx, by = L / gx;
   const int i0 = by * TM, j0 = bx * TN;
   if (g.lower && j0 > i0) return;
-  if (g.shape == 0) { if (g.tb) fac_tile<1, 4, true>(g, i0, j0, As, Bs); else fac_tile<1, 4, false>(g, i0, j0, As, Bs); }
-  else if (g.shape == 1) { if (g.tb) fac_tile<4, 1, true>(g, i0, j0, As, Bs); else fac_tile<4, 1, false>(g, i0, j0, As, Bs); }
-  else { if (g.tb) fac_tile<2, 2, true>(g, i0, j0, As, Bs); else fac_tile<2, 2, false>(g, i0, j0, As, Bs); }
+  if constexpr (SC1) {   // (the trailing update's tiles only)
+    fac_tile<2, 2, true, true>(g, i0, j0, As, Bs);
+  } else {
+    if (g.shape == 0) { if (g.tb) fac_tile<1, 4, true>(g, i0, j0, As, Bs); else fac_tile<1, 4, false>(g, i0, j0, As, Bs); }
+    else if (g.shape == 1) { if (g.tb) fac_tile<4, 1, true>(g, i0, j0, As, Bs); else fac_tile<4, 1, false>(g, i0, j0, As, Bs); }
+    else { if (g.tb) fac_tile<2, 2, true>(g, i0, j0, As, Bs); else fac_tile<2, 2, false>(g, i0, j0, As, Bs); }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_fac_pair(FacJob a, FacJob b, int na) {
@@ -720,9 +728,10 @@ __device__ unsigned long long g_potrf_stamps[8 * 48];
 #define POTRF_LD 129
 #define POTRF_LDS_BYTES ((128 * POTRF_LD + 8 * 256) * sizeof(double))
 
-__global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
-                                                              int32_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// SHARED_IN: the block was written by workgroups of the SAME launch (k_fac_potrf) -- it is read past the L2 (ld_agent)
+template <bool SHARED_IN>
+__device__ __forceinline__ void potrf_block(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
+                                            int32_t* __restrict__ status, unsigned char* smem_raw) {
   double* A = reinterpret_cast<double*>(smem_raw);  // 128 x 129: lower = block -> L ; strict-upper TILES hold J^T tiles
   double* Dt = A + 128 * POTRF_LD;                  // 8 x 256: inverses of the diagonal 16x16 tiles
   __shared__ int s_info, s_next;
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
       v[k] = 0.0;
-      if (ct <= (k >> 2)) v[k] = Lb[(size_t)(4 * k + rsub) * ld + col];
+      if (ct <= (k >> 2)) v[k] = ld_maybe<SHARED_IN>(Lb + (size_t)(4 * k + rsub) * ld + col);
     }
 #pragma unroll
     for (int k = 0; k < 32; ++k)
@@ -996,6 +1005,58 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
   __syncthreads();
   BSTAMP(40);
   if (tid == 0 && s_info != 0 && status[0] == 0) status[0] = (int)o + s_info;
+}
+
+__global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
+                                                              int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  potrf_block<false>(Lm, Jm, ld, kb, status, smem_raw);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Round 6: step kb's trailing update (+ the inverse's push) and the NEXT diagonal block's factorisation in ONE launch.
+// k_big_potrf(kb + 1) needs three 64 x 64 tiles of the update -- the lower tiles of the next diagonal block -- and used to wait
+// for all of them (105 at the first step) and for a launch boundary; now those three tiles are workgroups 0-2, they store
+// write-through and count themselves in status[4] (the hand-off protocol of tgp_prep.hpp), workgroup 3 polls that word and runs
+// the diagonal block beside the rest of the update.  Producers carry the lowest indices (dispatch order: no deadlock); the
+// potrf workgroup clears the word (the next launch finds it zero); a wait that expires is reported like the fused path's
+// (status[0] = TGP_STATUS_SYNC_TIMEOUT, sticky count in status[3]).  One block size for both roles: the k = 128 products are
+// 4-wave tiles, so waves 4-7 of their workgroups leave at once (S_BARRIER waits on the surviving waves of a workgroup only).
+// Per step: 3 launches -> 2, and the diagonal block off the update's tail: the chain of a step 50 -> ~41 us.
+// ---------------------------------------------------------------------------------------------------
+enum { FP_WORD = 4 };   // status[4]: diagonal tiles of the running update that are in memory
+__global__ __launch_bounds__(POTRF_THREADS) void k_fac_potrf(FacJob a, FacJob b, int na, double* __restrict__ Lm,
+                                                              double* __restrict__ Jm, int ld, int kb, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int id = blockIdx.x;
+  if (id == 3) {
+    if (threadIdx.x < 64) {
+      const int v = sync_wait(status + FP_WORD, [](int x) { return x >= 3; });
+      if (threadIdx.x == 0) {
+        if (v == (int)0x80000000) {
+          __hip_atomic_store(status, (int32_t)TGP_STATUS_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sync_st(status + FP_WORD, 0);
+      }
+    }
+    __syncthreads();
+    potrf_block<true>(Lm, Jm, ld, kb, status, smem_raw);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  double* As = reinterpret_cast<double*>(smem_raw);
+  double* Bs = As + 128 * FAC_LD;
+  const int gx = a.n / 64;
+  if (id < 3) {
+    fac_job<true>(a, id == 0 ? 0 : gx + id - 1, As, Bs);   // tiles (0,0), (1,0), (1,1) of the trailing matrix
+    handoff_barrier();
+    if (threadIdx.x == 0) sync_add(status + FP_WORD, 1);
+    return;
+  }
+  const int t = id - 4, nd = na - 3;
+  if (t < nd) fac_job(a, t < gx - 1 ? t + 1 : t + 3, As, Bs);
+  else fac_job(b, t - nd, As, Bs);
 }
 #ifdef TGP_STAMPS
 }  // namespace tgp
@@ -1510,6 +1571,22 @@ static BigFork& big_fork() {
   return f;
 }
 
+// the trailing update a (+ the inverse's push b, b.m == 0: none) and the factorisation of diagonal block kb in one launch
+static int launch_fac_potrf(const FacJob& a, const FacJob& b, double* Lm, double* J, int MP, int kb, int32_t* status, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fac_potrf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)POTRF_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+    attr_done = true;
+  }
+  static_assert(POTRF_LDS_BYTES >= 2 * 128 * FAC_LD * sizeof(double), "the product tiles stage through the potrf block's LDS");
+  const int na = fac_tiles(a), nb2 = b.m > 0 ? fac_tiles(b) : 0;
+  hipLaunchKernelGGL(k_fac_potrf, dim3(na + nb2 + 1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, a, b, na, Lm, J, MP, kb, status);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // Blocked right-looking Cholesky of the padded matrix in p.Lm (lower block triangle filled, J zeroed) and, if wanted, the
 // inverse J = L^-1 (torch.cholesky, dsp/utils.py:239).  Diagonal blocks of J are always produced (the panel solve
 // multiplies by them).  The inverse is right-looking too, J[i,j] = -J_ii sum_{j <= k < i} L[i,k] J[k,j]:
@@ -1518,6 +1595,8 @@ static BigFork& big_fork() {
 // so every product has k = 128 (no split-k, no scratch) and each rides in a launch the factorisation makes anyway
 // (launch_gemm_pair_ft_ff: the row product beside the panel product, the push beside the trailing update): the inverse
 // costs ONE launch at the very end instead of 3 (nb - 1) launches after the factorisation (330 us at M = 1000).
+// Launches per 128-column step (round 6): [panel + inverse row] (k_fac_pair), [trailing update + push + the NEXT diagonal
+// block] (k_fac_potrf); k_big_potrf alone only for block 0.
 static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool want_inverse, hipStream_t st) {
   const int MP = p.MP, nb = MP / 128;
   double* Lm = ws + p.Lm;
@@ -1525,8 +1604,10 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
   FacJob none;
   none.m = 0; none.n = 0; none.shape = 2;
   for (int kb = 0; kb < nb; ++kb) {
-    hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
-    LAUNCH_CHECK();
+    if (kb == 0) {   // (the later diagonal blocks ride in the previous step's update launch: k_fac_potrf)
+      hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
+      LAUNCH_CHECK();
+    }
     const int rem = MP - (kb + 1) * 128;
     double* Jk = J + (size_t)kb * 128 * MP;                          // block row kb of J
     const double* Jkk = Jk + (size_t)kb * 128;
@@ -1543,7 +1624,7 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
       // Acc[i, 0:kb+1] += L[i,kb] J[kb, 0:kb+1]
       const FacJob push = fac_job_args(panel, MP, Jk, MP, J + (size_t)(kb + 1) * 128 * MP, MP, rem, 128 * (kb + 1), 0, 2, 1.0, 1.0);
       if (int rc = launch_fac_pair(pan, row ? inv_row : none, st)) return rc;
-      if (int rc = launch_fac_pair(upd, want_inverse ? push : none, st)) return rc;
+      if (int rc = launch_fac_potrf(upd, want_inverse ? push : none, Lm, J, MP, kb + 1, status, st)) return rc;
     } else if (row) {
       if (int rc = launch_fac_pair(inv_row, none, st)) return rc;
     }
