@@ -259,8 +259,7 @@ struct FacJob {
 #define FAC_LD 68
 #define FAC_LDS_BYTES ((size_t)160 * FAC_LD * sizeof(double))
 
-// SC1: the result is stored write-through (st_agent): a workgroup of the SAME launch reads it (k_fac_potrf's diagonal tiles)
-template <int WM, int WN, bool TB, bool SC1 = false>
+template <int WM, int WN, bool TB>
 __device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double* As, double* Bs) {
   constexpr int TM = 32 * WM, TN = 32 * WN;
   constexpr int NA = TM * 32 / 256;                 // d2 loads per thread for a [TM][64] half of A (8 .. 16 .. 4)
@@ -346,23 +345,17 @@ __device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
-        st_maybe<SC1>(g.C + (size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r,
-                      g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr]);
+        g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr];
 }
 
-template <bool SC1 = false>
 __device__ __forceinline__ void fac_job(const FacJob& g, int L, double* As, double* Bs) {
   const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
   const int gx = g.n / TN, bx = L % gx, by = L / gx;
   const int i0 = by * TM, j0 = bx * TN;
   if (g.lower && j0 > i0) return;
-  if constexpr (SC1) {   // (the trailing update's tiles only)
-    fac_tile<2, 2, true, true>(g, i0, j0, As, Bs);
-  } else {
-    if (g.shape == 0) { if (g.tb) fac_tile<1, 4, true>(g, i0, j0, As, Bs); else fac_tile<1, 4, false>(g, i0, j0, As, Bs); }
-    else if (g.shape == 1) { if (g.tb) fac_tile<4, 1, true>(g, i0, j0, As, Bs); else fac_tile<4, 1, false>(g, i0, j0, As, Bs); }
-    else { if (g.tb) fac_tile<2, 2, true>(g, i0, j0, As, Bs); else fac_tile<2, 2, false>(g, i0, j0, As, Bs); }
-  }
+  if (g.shape == 0) { if (g.tb) fac_tile<1, 4, true>(g, i0, j0, As, Bs); else fac_tile<1, 4, false>(g, i0, j0, As, Bs); }
+  else if (g.shape == 1) { if (g.tb) fac_tile<4, 1, true>(g, i0, j0, As, Bs); else fac_tile<4, 1, false>(g, i0, j0, As, Bs); }
+  else { if (g.tb) fac_tile<2, 2, true>(g, i0, j0, As, Bs); else fac_tile<2, 2, false>(g, i0, j0, As, Bs); }
 }
 
 __global__ __launch_bounds__(256) void k_fac_pair(FacJob a, FacJob b, int na) {
@@ -1015,23 +1008,55 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // Round 6: step kb's trailing update (+ the inverse's push) and the NEXT diagonal block's factorisation in ONE launch.
-// k_big_potrf(kb + 1) needs three 64 x 64 tiles of the update -- the lower tiles of the next diagonal block -- and used to wait
-// for all of them (105 at the first step) and for a launch boundary; now those three tiles are workgroups 0-2, they store
-// write-through and count themselves in status[4] (the hand-off protocol of tgp_prep.hpp), workgroup 3 polls that word and runs
-// the diagonal block beside the rest of the update.  Producers carry the lowest indices (dispatch order: no deadlock); the
+// k_big_potrf(kb + 1) needs the update of the next diagonal block only and used to wait for all of the update's tiles (105 at
+// the first step) and for a launch boundary; now that block's ten lower 32 x 32 tiles are workgroups 0-9 (diag_tile32), they
+// store write-through and count themselves in status[4] (the hand-off protocol of tgp_prep.hpp), workgroup 10 polls that word
+// and runs the diagonal block beside the rest of the update.  Producers carry the lowest indices (dispatch order: no deadlock); the
 // potrf workgroup clears the word (the next launch finds it zero); a wait that expires is reported like the fused path's
 // (status[0] = TGP_STATUS_SYNC_TIMEOUT, sticky count in status[3]).  One block size for both roles: the k = 128 products are
 // 4-wave tiles, so waves 4-7 of their workgroups leave at once (S_BARRIER waits on the surviving waves of a workgroup only).
-// Per step: 3 launches -> 2, and the diagonal block off the update's tail: the chain of a step 50 -> ~41 us.
+// Per step: 3 launches -> 2, and the diagonal block off the update's tail.
 // ---------------------------------------------------------------------------------------------------
-enum { FP_WORD = 4 };   // status[4]: diagonal tiles of the running update that are in memory
+enum { FP_WORD = 4, FP_NDIAG = 10 };   // status[4]: tiles of the next diagonal block that are in memory (10 lower 32 x 32 tiles)
+#define FD_LD 132
+// One 32 x 32 tile (i0, j0) of C -= A A^T over k = 128 in ONE stage (4 waves x 16 x 16; A = the panel, rows i0.. and j0..):
+// the tiles in front of the next diagonal block are latency, not work -- one memory round trip, 32 MFMAs per wave, a
+// write-through store (a 64 x 64 tile of fac_tile: two round trips and 128 MFMAs per wave, as long as the whole update launch).
+__device__ __forceinline__ void diag_tile32(const FacJob& g, int i0, int j0, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+  d2 ra[8], rb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;            // 64 d2 per row of 128 k
+    ra[u] = *reinterpret_cast<const d2*>(g.A + (size_t)(i0 + x) * g.lda + 2 * k2);
+    rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)(j0 + x) * g.ldb + 2 * k2);
+  }
+  double cold[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) cold[rr] = g.C[(size_t)(i0 + wi + q + 4 * rr) * g.ldc + j0 + wj + r];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    *reinterpret_cast<d2*>(As + x * FD_LD + 2 * k2) = ra[u];
+    *reinterpret_cast<d2*>(Bs + x * FD_LD + 2 * k2) = rb[u];
+  }
+  __syncthreads();
+  d4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 32; ++s) acc = TGP_MFMA(As[(wi + r) * FD_LD + 4 * s + q], Bs[(wj + r) * FD_LD + 4 * s + q], acc);
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+    st_agent(g.C + (size_t)(i0 + wi + q + 4 * rr) * g.ldc + j0 + wj + r, g.alpha * acc[rr] + g.beta * cold[rr]);
+}
+
 __global__ __launch_bounds__(POTRF_THREADS) void k_fac_potrf(FacJob a, FacJob b, int na, double* __restrict__ Lm,
                                                               double* __restrict__ Jm, int ld, int kb, int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int id = blockIdx.x;
-  if (id == 3) {
+  if (id == FP_NDIAG) {
     if (threadIdx.x < 64) {
-      const int v = sync_wait(status + FP_WORD, [](int x) { return x >= 3; });
+      const int v = sync_wait(status + FP_WORD, [](int x) { return x >= FP_NDIAG; });
       if (threadIdx.x == 0) {
         if (v == (int)0x80000000) {
           __hip_atomic_store(status, (int32_t)TGP_STATUS_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1046,15 +1071,18 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_fac_potrf(FacJob a, FacJob b,
   }
   if (threadIdx.x >= 256) return;
   double* As = reinterpret_cast<double*>(smem_raw);
-  double* Bs = As + 128 * FAC_LD;
   const int gx = a.n / 64;
-  if (id < 3) {
-    fac_job<true>(a, id == 0 ? 0 : gx + id - 1, As, Bs);   // tiles (0,0), (1,0), (1,1) of the trailing matrix
+  if (id < FP_NDIAG) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;          // lower 32 x 32 tile (ti, tj) of the next diagonal block
+    const int tj = id - ti * (ti + 1) / 2;
+    diag_tile32(a, 32 * ti, 32 * tj, As, As + 32 * FD_LD);
     handoff_barrier();
     if (threadIdx.x == 0) sync_add(status + FP_WORD, 1);
     return;
   }
-  const int t = id - 4, nd = na - 3;
+  double* Bs = As + 128 * FAC_LD;
+  const int t = id - FP_NDIAG - 1, nd = na - 3;          // the update's other tiles: (0,0), (1,0), (1,1) of 64 are the block's
   if (t < nd) fac_job(a, t < gx - 1 ? t + 1 : t + 3, As, Bs);
   else fac_job(b, t - nd, As, Bs);
 }
@@ -1582,7 +1610,7 @@ static int launch_fac_potrf(const FacJob& a, const FacJob& b, double* Lm, double
   }
   static_assert(POTRF_LDS_BYTES >= 2 * 128 * FAC_LD * sizeof(double), "the product tiles stage through the potrf block's LDS");
   const int na = fac_tiles(a), nb2 = b.m > 0 ? fac_tiles(b) : 0;
-  hipLaunchKernelGGL(k_fac_potrf, dim3(na + nb2 + 1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, a, b, na, Lm, J, MP, kb, status);
+  hipLaunchKernelGGL(k_fac_potrf, dim3(na - 3 + nb2 + FP_NDIAG + 1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, a, b, na, Lm, J, MP, kb, status);
   LAUNCH_CHECK();
   return 0;
 }
