@@ -257,6 +257,7 @@ struct FacJob {
   double alpha, beta;
 };
 #define FAC_LD 68
+enum { FP_WORD = 4 };   // status[4]: producers of the diagonal block a workgroup of the same launch waits for (k_big_kmm_potrf, k_fac_potrf)
 #define FAC_LDS_BYTES ((size_t)160 * FAC_LD * sizeof(double))
 
 template <int WM, int WN, bool TB>
@@ -609,7 +610,8 @@ static int launch_gemm_pair_ft_ff(const GemmArgs& a_in, const GemmArgs& b_in, hi
 // ---------------------------------------------------------------------------------------------------
 // prepare kernels
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_big_hdr(BigPlan p, tgp_model md, double* __restrict__ ws, int32_t* __restrict__ status) {
+// (block 0 of k_big_hdr_zs: nothing below depends on the other blocks of that launch, nor they on it)
+__device__ __forceinline__ void big_hdr_block(const BigPlan& p, const tgp_model& md, double* __restrict__ ws, int32_t* __restrict__ status) {
   const int tid = threadIdx.x;
   if (tid < 16) {
     const double l = tid < p.D ? softplus_d(md.raw_ls[tid]) : 1.0;
@@ -630,8 +632,10 @@ __global__ __launch_bounds__(256) void k_big_hdr(BigPlan p, tgp_model md, double
   for (int i = p.N + tid; i < p.NP; i += 256) { ws[p.mub + i] = 0.0; ws[p.vb + i] = 0.0; }
 }
 
-// Zs, padded m, Zaug = [Zs, Zs^2, 1, 0...]; one thread per Zaug element
-__global__ __launch_bounds__(256) void k_big_zs(BigPlan p, tgp_model md, double* __restrict__ ws) {
+// Zs, padded m, Zaug = [Zs, Zs^2, 1, 0...]; one thread per Zaug element.  Block 0 also writes the header scalars and clears the
+// status words (round 6: one launch instead of k_big_hdr -> k_big_zs; the two never depended on each other)
+__global__ __launch_bounds__(256) void k_big_hdr_zs(BigPlan p, tgp_model md, double* __restrict__ ws, int32_t* __restrict__ status) {
+  if (blockIdx.x == 0) big_hdr_block(p, md, ws, status);
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int row = (int)(e >> 7), c = (int)(e & 127);
   if (row >= p.MP) return;
@@ -674,32 +678,51 @@ __global__ __launch_bounds__(256) void k_big_kl(BigPlan p, tgp_model md, double*
   if (threadIdx.x == 0) ws[p.klpart + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// K_MM (+ jitter, identity on the padding), the to-be-factorised copy (lower block triangle), J = 0, masked L_q
-__global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double* __restrict__ ws, int32_t* __restrict__ status) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int MP = p.MP, M = p.M, DP = p.DP;
-  const int row = (int)(e / MP), col = (int)(e % MP);
+// K_MM (+ jitter, identity on the padding), the to-be-factorised copy (lower block triangle), J = 0, masked L_q: element e.
+// The first diagonal block of the to-be-factorised copy and of J belongs to the workgroup that factorises it in the same launch
+// (k_big_kmm_potrf): nothing of Lm is written there, of J only the tiles above the diagonal tiles (which that workgroup never writes).
+// (DPC: the padded input dimension as a compile-time constant -- 2 DPC loads in flight at once instead of a loop of dependent
+//  round trips; with one workgroup per CU there is no other wave to hide them behind)
+// FIRST: only the element of the to-be-factorised copy, written through (st_agent) -- the first diagonal block on its way to the
+// workgroup that factorises it in the same launch.
+template <int DPC, bool FIRST = false>
+__device__ __forceinline__ void big_kmm_element(const BigPlan& p, const tgp_model& md, double* __restrict__ ws,
+                                                int32_t* __restrict__ status, int row, int col) {
+  const int MP = p.MP, M = p.M, DP = DPC;
+  const size_t e = (size_t)row * MP + col;
   double k, lq = 0.0;
   if (row < M && col < M) {
     const double* zr = ws + p.Zs + (size_t)row * DP;
     const double* zc = ws + p.Zs + (size_t)col * DP;
+    double zrv[DPC], zcv[DPC];
+#pragma unroll
+    for (int d = 0; d < DPC; ++d) { zrv[d] = zr[d]; zcv[d] = zc[d]; }
     double d2 = 0.0;
-    for (int d = 0; d < DP; ++d) {
-      const double t = zr[d] - zc[d];
+#pragma unroll
+    for (int d = 0; d < DPC; ++d) {
+      const double t = zrv[d] - zcv[d];
       d2 += t * t;
     }
     k = cov_value(p.kernel, ws[p.hdr + H_S2], d2);
-    if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = cov_gweight(p.kernel, ws[p.hdr + H_S2], d2);
-    if (k != k) status[1] = 1;
     if (row == col) k += md.jitter;
-    if (col <= row) lq = md.Lam[(size_t)row * M + col];
+    if constexpr (!FIRST) {
+      if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = cov_gweight(p.kernel, ws[p.hdr + H_S2], d2);
+      if (k != k) status[1] = 1;
+      if (col <= row) lq = md.Lam[(size_t)row * M + col];
+    }
   } else {
     k = row == col ? 1.0 : 0.0;
-    if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = 0.0;
+    if constexpr (!FIRST)
+      if (p.kernel != TGP_KERNEL_SCALE_RBF) ws[p.Kmmg + e] = 0.0;
+  }
+  if constexpr (FIRST) {
+    st_agent(ws + p.Lm + e, k);
+    return;
   }
   ws[p.Kmm + e] = k;
-  ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
-  ws[p.J + e] = 0.0;
+  const bool first = row < 128 && col < 128;
+  if (!first) ws[p.Lm + e] = (row >> 7) >= (col >> 7) ? k : 0.0;
+  if (!first || (col >> 4) > (row >> 4)) ws[p.J + e] = 0.0;
   ws[p.Lq + e] = lq;
 }
 
@@ -713,7 +736,10 @@ __global__ __launch_bounds__(256) void k_big_kmm(BigPlan p, tgp_model md, double
 // LDS, [2 + 3 j ..] window j: entry / own work done / after the window's barrier; [40] end.  Block kb = 1 of the last
 // factorisation.
 __device__ unsigned long long g_potrf_stamps[8 * 48];
-#define BSTAMP(i) do { if (kb == 1 && lane == 0) g_potrf_stamps[wave * 48 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef TGP_STAMP_KB
+#define TGP_STAMP_KB 1
+#endif
+#define BSTAMP(i) do { if (kb == TGP_STAMP_KB && lane == 0) g_potrf_stamps[wave * 48 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define BSTAMP(i) do { } while (0)
 #endif
@@ -721,8 +747,10 @@ __device__ unsigned long long g_potrf_stamps[8 * 48];
 #define POTRF_LD 129
 #define POTRF_LDS_BYTES ((128 * POTRF_LD + 8 * 256) * sizeof(double))
 
-// SHARED_IN: the block was written by workgroups of the SAME launch (k_fac_potrf) -- it is read past the L2 (ld_agent)
-template <bool SHARED_IN>
+// Where the block comes from.  PB_SHARED: written by workgroups of the SAME launch (k_fac_potrf, k_big_kmm_potrf) -- read past
+// the L2 (ld_agent).
+enum { PB_GLOBAL = 0, PB_SHARED = 1 };
+template <int IN>
 __device__ __forceinline__ void potrf_block(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
                                             int32_t* __restrict__ status, unsigned char* smem_raw) {
   double* A = reinterpret_cast<double*>(smem_raw);  // 128 x 129: lower = block -> L ; strict-upper TILES hold J^T tiles
@@ -754,10 +782,10 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Lm, double* __r
     const int col = tid & 127, rsub = tid >> 7, ct = col >> 4;
     double v[32];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      v[k] = 0.0;
-      if (ct <= (k >> 2)) v[k] = ld_maybe<SHARED_IN>(Lb + (size_t)(4 * k + rsub) * ld + col);
-    }
+      for (int k = 0; k < 32; ++k) {
+        v[k] = 0.0;
+        if (ct <= (k >> 2)) v[k] = ld_maybe<IN == PB_SHARED>(Lb + (size_t)(4 * k + rsub) * ld + col);
+      }
 #pragma unroll
     for (int k = 0; k < 32; ++k)
       if (ct <= (k >> 2)) A[(4 * k + rsub) * LD + col] = v[k];
@@ -1003,7 +1031,49 @@ __device__ __forceinline__ void potrf_block(double* __restrict__ Lm, double* __r
 __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict__ Lm, double* __restrict__ Jm, int ld, int kb,
                                                               int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  potrf_block<false>(Lm, Jm, ld, kb, status, smem_raw);
+  potrf_block<PB_GLOBAL>(Lm, Jm, ld, kb, status, smem_raw);
+}
+
+// K_MM and the factorisation of its first diagonal block in ONE launch (round 6).  Workgroups 0-31 first form the 128 x 128
+// block (4 rows each, one element per thread, written through) and count themselves in status[4]; workgroup 32 polls that word and
+// factorises the block (PB_SHARED) while all the others (grid-stride over whole rows, one workgroup per CU: the block's LDS sets
+// the occupancy) write K_MM, the to-be-factorised copy outside that block, J = 0 and the masked L_q.  Same protocol and the same
+// dispatch-order argument as k_fac_potrf (the producers are workgroups 0-31, the consumer is workgroup 32).  The chain's head was k_big_hdr -> k_big_zs -> k_big_kmm -> k_big_potrf
+// (4.7 + 5.0 + 18.4 + 4.6 gap + 33 us); now k_big_hdr_zs -> this.
+enum { KP_NFIRST = 32 };
+template <int DPC>
+__device__ __forceinline__ void big_kmm_rows(const BigPlan& p, const tgp_model& md, double* __restrict__ ws,
+                                             int32_t* __restrict__ status, int w, int nw) {
+  if (w < KP_NFIRST) {
+    big_kmm_element<DPC, true>(p, md, ws, status, 4 * w + (int)(threadIdx.x >> 7), (int)(threadIdx.x & 127));
+    handoff_barrier();
+    if (threadIdx.x == 0) sync_add(status + FP_WORD, 1);
+  }
+  for (int row = w; row < p.MP; row += nw)
+    for (int col = threadIdx.x; col < p.MP; col += POTRF_THREADS) big_kmm_element<DPC>(p, md, ws, status, row, col);
+}
+__global__ __launch_bounds__(POTRF_THREADS) void k_big_kmm_potrf(BigPlan p, tgp_model md, double* __restrict__ ws,
+                                                                  int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (blockIdx.x == KP_NFIRST) {   // (behind its producers in dispatch order)
+    if (threadIdx.x < 64) {
+      const int v = sync_wait(status + FP_WORD, [](int x) { return x >= KP_NFIRST; });
+      if (threadIdx.x == 0) {
+        if (v == (int)0x80000000) {
+          __hip_atomic_store(status, (int32_t)TGP_STATUS_SYNC_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(status + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sync_st(status + FP_WORD, 0);
+      }
+    }
+    __syncthreads();
+    potrf_block<PB_SHARED>(ws + p.Lm, ws + p.J, p.MP, 0, status, smem_raw);
+    return;
+  }
+  const int w = (int)blockIdx.x - ((int)blockIdx.x > KP_NFIRST ? 1 : 0), nw = (int)gridDim.x - 1;
+  if (p.DP == 4) big_kmm_rows<4>(p, md, ws, status, w, nw);
+  else if (p.DP == 8) big_kmm_rows<8>(p, md, ws, status, w, nw);
+  else big_kmm_rows<16>(p, md, ws, status, w, nw);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1017,7 +1087,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_big_potrf(double* __restrict_
 // 4-wave tiles, so waves 4-7 of their workgroups leave at once (S_BARRIER waits on the surviving waves of a workgroup only).
 // Per step: 3 launches -> 2, and the diagonal block off the update's tail.
 // ---------------------------------------------------------------------------------------------------
-enum { FP_WORD = 4, FP_NDIAG = 10 };   // status[4]: tiles of the next diagonal block that are in memory (10 lower 32 x 32 tiles)
+enum { FP_NDIAG = 10 };   // the next diagonal block's 10 lower 32 x 32 tiles count themselves in status[FP_WORD]
 #define FD_LD 132
 // One 32 x 32 tile (i0, j0) of C -= A A^T over k = 128 in ONE stage (4 waves x 16 x 16; A = the panel, rows i0.. and j0..):
 // the tiles in front of the next diagonal block are latency, not work -- one memory round trip, 32 MFMAs per wave, a
@@ -1066,7 +1136,7 @@ __global__ __launch_bounds__(POTRF_THREADS) void k_fac_potrf(FacJob a, FacJob b,
       }
     }
     __syncthreads();
-    potrf_block<true>(Lm, Jm, ld, kb, status, smem_raw);
+    potrf_block<PB_SHARED>(Lm, Jm, ld, kb, status, smem_raw);
     return;
   }
   if (threadIdx.x >= 256) return;
@@ -1625,14 +1695,15 @@ static int launch_fac_potrf(const FacJob& a, const FacJob& b, double* Lm, double
 // costs ONE launch at the very end instead of 3 (nb - 1) launches after the factorisation (330 us at M = 1000).
 // Launches per 128-column step (round 6): [panel + inverse row] (k_fac_pair), [trailing update + push + the NEXT diagonal
 // block] (k_fac_potrf); k_big_potrf alone only for block 0.
-static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool want_inverse, hipStream_t st) {
+// `first_done`: block 0 was factorised by the launch that wrote the matrix (k_big_kmm_potrf).
+static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool want_inverse, hipStream_t st, bool first_done = false) {
   const int MP = p.MP, nb = MP / 128;
   double* Lm = ws + p.Lm;
   double* J = ws + p.J;
   FacJob none;
   none.m = 0; none.n = 0; none.shape = 2;
   for (int kb = 0; kb < nb; ++kb) {
-    if (kb == 0) {   // (the later diagonal blocks ride in the previous step's update launch: k_fac_potrf)
+    if (kb == 0 && !first_done) {   // (the later diagonal blocks ride in the previous step's update launch: k_fac_potrf)
       hipLaunchKernelGGL(k_big_potrf, dim3(1), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, Lm, J, MP, kb, status);
       LAUNCH_CHECK();
     }
@@ -1678,19 +1749,26 @@ static int big_prepare(const BigPlan& p, const tgp_model& md, double* ws, int32_
   BigFork& fk = big_fork();
   if (int rc = fk.init()) return rc;
   hipStream_t sx = fk.aux;
-  hipLaunchKernelGGL(k_big_hdr, dim3(1), dim3(256), 0, st, p, md, ws, status);
+  hipLaunchKernelGGL(k_big_hdr_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws, status);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_big_zs, dim3((unsigned)((size_t)MP * BIG_XW / 256)), dim3(256), 0, st, p, md, ws);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_big_kmm, dim3((unsigned)(mm / 256)), dim3(256), 0, st, p, md, ws, status);
-  LAUNCH_CHECK();
+  {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_big_kmm_potrf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)POTRF_LDS_BYTES);
+      if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k_big_kmm_potrf, dim3(256), dim3(POTRF_THREADS), POTRF_LDS_BYTES, st, p, md, ws, status);
+    LAUNCH_CHECK();
+  }
   // ---- fork: what needs only the variational parameters (KL, S = Lq Lq^T - I) runs beside the factorisation.  The
   //      factorisation is ISSUED FIRST: a captured graph keeps the first-created successor of a fork on the parent's
   //      hardware queue and moves the later ones to another -- with the auxiliary branch created first the critical
   //      chain hopped queues behind k_big_kmm and again in front of the row phase, ~10 us of dependency latency each
   //      time (q1 -> q4 -> q1 -> q4 in the kernel timeline; now one hop, where the row phase meets the early K') ----
   if (hipError_t e = hipEventRecord(fk.ev[0], st); e != hipSuccess) return set_error(e, __FILE__, __LINE__);
-  if (int rc = big_factorise(p, ws, status, true, st)) return rc;
+  if (int rc = big_factorise(p, ws, status, true, st, true)) return rc;
   if (md.jitter_ladder > 0.0) {  // the device-side retry ladder: returns at once unless the factorisation failed
     hipLaunchKernelGGL(k_big_ladder, dim3(1), dim3(LADDER_THREADS), 0, st, p, md, ws, status);
     LAUNCH_CHECK();
