@@ -38,8 +38,8 @@
  *                   launch count themselves in status[4] once their tile of K_MM is in global memory, status[5] counts
  *                   the blocks that have left; the M x M backward launch counts its finished column blocks in bits 16-23
  *                   and its finished row-block halves in bits 24-31 of status[6], and the blocks that have left in status[7];
- *                   M > 128: the trailing-update tiles that the next diagonal block of the factorisation waits for count
- *                   themselves in status[4]);
+ *                   M > 128: the workgroups that produce the diagonal block a factorising workgroup of the same launch
+ *                   waits for -- the first block of K_MM, then the trailing update's tiles -- count themselves in status[4]);
  *                   the library leaves them zero at the end of every
  *                   call, the caller must not touch them while a call is in flight.  A caller built against the
  *                   int32[4] status of ABI versions <= 100 must grow the buffer: check tgp_version() >= 101,
