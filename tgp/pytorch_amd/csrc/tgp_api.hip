@@ -166,11 +166,15 @@ static int elbo_step_impl(const tgp_model* model, const double* X, const double*
     general = !rows_train_lds_fits(pl, fp.nslots);
   }
   if (general) {
-    if (int rc = launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st))
+    const bool lam_early = adam != nullptr && (phases & TGP_PHASE_BACKWARD) && ad.lam_n > 0;
+    if (int rc = launch_big_step(md, fp, X, Y, rowp, out, *grads, mu, v, status, ws, workspace_bytes / sizeof(double), phases, st,
+                                 lam_early ? &ad : nullptr))
       return rc;
-    if (adam != nullptr)   // general-M path: the update stays a launch of its own
+    if (adam != nullptr)   // general-M path: the update is a launch of its own -- except Lam's entries (the bulk: M^2 of the
+                           // M^2 + M (D + 1) + ... parameters), which the kernel that forms their gradient updated beside the K_MM chain
       return launch_adam_dev(adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq, adam->n, adam->lr, adam->beta1,
-                             adam->beta2, adam->eps, 0.0, adam->step_dev, adam->maximize, st);
+                             adam->beta2, adam->eps, 0.0, adam->step_dev, adam->maximize, st, 0, lam_early ? ad.lam_off : 0,
+                             lam_early ? ad.lam_n : 0);
     return 0;
   }
   Plan p;

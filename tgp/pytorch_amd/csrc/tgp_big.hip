@@ -1402,7 +1402,10 @@ __global__ __launch_bounds__(256) void k_big_lbar(BigPlan p, double* __restrict_
 }
 
 // dELBO/dLam = 2 tril(G Lq) - kl (Lq - diag(1/Lam_ii)); R2 = 2 G Lq is in S_
-__global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, double* __restrict__ gLam, const double* __restrict__ GL) {
+// `upd`: torch.optim.Adam on Lam's entries in the thread that forms their gradient (k_adam_dev's arithmetic; the step counter
+// is read here and advanced by the tail update behind k_big_final) -- M^2 of the parameters leave the end of the step's chain
+__global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, double* __restrict__ gLam, const double* __restrict__ GL,
+                                                  AdamDev ad, int upd) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int M = p.M;
   if (e >= (size_t)M * M) return;
@@ -1413,6 +1416,17 @@ __global__ __launch_bounds__(256) void k_big_glam(BigPlan p, tgp_model md, doubl
     x = GL[(size_t)row * p.MP + col] - md.kl_scale * (col == row ? lam - 1.0 / lam : lam);   // GL = 2 G Lq
   }
   gLam[e] = x;
+  if (upd) {
+    const double step = (double)(ad.step_dev[0] + 1);
+    const double bc1 = 1.0 - exp_fast(step * ad.ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ad.ln_b2));
+    const long i = ad.lam_off + (long)e;
+    const double gi = ad.sign * x;
+    const double mi = ad.b1 * ad.m[i] + (1.0 - ad.b1) * gi;
+    const double vi = ad.b2 * ad.v[i] + (1.0 - ad.b2) * gi * gi;
+    ad.m[i] = mi;
+    ad.v[i] = vi;
+    ad.p[i] -= (ad.lr / bc1) * mi / (sqrt(vi) / bc2s + ad.eps);
+  }
 }
 
 // Q <- Phi(Q) + Phi(Q)^T in place (Phi: lower triangle, diagonal halved)
@@ -1851,7 +1865,7 @@ int launch_big_moments(const tgp_model& md, const double* X, double* mu, double*
 
 int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
-                    uint32_t phases, hipStream_t st) {
+                    uint32_t phases, hipStream_t st, const AdamDev* adam) {
   BigPlan p;
   if (int rc = make_big_plan(p, md.N, md.D, md.M, md.S, md.nblk, md.P, md.RP, md.lik, md.kernel, md.plan)) return rc;
   if (ws_doubles < p.total) return TGP_E_WORKSPACE;
@@ -2004,7 +2018,8 @@ int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, co
       if (int rc = gemm_mm_on(false, false, gemm_args(ws + p.G, MP, ws + p.Lq, MP, dl, MP, MP, MP, MP, 2.0, 0.0, TRI_B_LOWER), dl + mm, cap,
                               fk.aux))
         return rc;
-      hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, fk.aux, p, md, g.Lam, dl);
+      hipLaunchKernelGGL(k_big_glam, dim3((unsigned)(((size_t)p.M * p.M + 255) / 256)), dim3(256), 0, fk.aux, p, md, g.Lam, dl,
+                         adam != nullptr ? *adam : AdamDev(), adam != nullptr ? 1 : 0);
       LAUNCH_CHECK();
     }
     if (int rc = big_join(st)) return rc;   // dLam

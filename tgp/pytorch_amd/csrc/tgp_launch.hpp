@@ -63,7 +63,7 @@ int launch_rows(const Plan& p, const tgp_model& md, const FlowProg& fp, const do
 size_t big_workspace_doubles(int N, int D, int M, int S, int nblk, int P, int RP, int kernel, int plan = 0);
 int launch_big_step(const tgp_model& md, const FlowProg& fp, const double* X, const double* Y, const double* rowp,
                     double* out, const tgp_grads& g, double* mu, double* v, int32_t* status, double* ws, size_t ws_doubles,
-                    uint32_t phases, hipStream_t st);
+                    uint32_t phases, hipStream_t st, const AdamDev* adam = nullptr);
 int launch_big_moments(const tgp_model& md, const double* X, double* mu, double* v, int32_t* status, double* ws,
                        size_t ws_doubles, hipStream_t st);
 size_t big_cholesky_workspace_doubles(int M);
@@ -101,7 +101,7 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
                 double beta1, double beta2, double eps, double weight_decay, int step, int maximize, hipStream_t st);
 int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
-                    hipStream_t st, int64_t n_plain = 0);
+                    hipStream_t st, int64_t n_plain = 0, int64_t skip_off = 0, int64_t skip_n = 0);
 size_t lik_workspace_doubles(int N, int P, int RP);
 int launch_gather_rows(const double* X, const double* Y, int N, int D, const int32_t* index, int32_t* cursor, int offset,
                        int nrows, int advance, int wrap, double* Xb, double* Yb, hipStream_t st);

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const 
                                                    double* __restrict__ m, double* __restrict__ v, int64_t n, double lr,
                                                    double b1, double b2, double eps, double wd,
                                                    int32_t* __restrict__ step_dev, double sign, int64_t n_plain,
-                                                   double ln_b1, double ln_b2) {
+                                                   double ln_b1, double ln_b2, int64_t skip_off, int64_t skip_n) {
   const double step = (double)(step_dev[0] + 1);
   // beta^step = exp(step ln beta), ln beta from the host: the library pow() is ~300 dependent f64 instructions per
   // call and every thread made two of them -- 3 of this kernel's 4.3 us (relative error of the power <= 1e-14 at
@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) void k_adam_dev(double* __restrict__ p, const 
   const double bc1 = 1.0 - exp_fast(step * ln_b1), bc2s = sqrt(1.0 - exp_fast(step * ln_b2));
   // grid-stride: the launcher caps the grid (the ticket below is one atomic per workgroup on ONE word, ~12 ns each:
   // the 4 096 workgroups of a 1 M-parameter buffer spent 50 us queueing for it)
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  // [skip_off, skip_off + skip_n): entries another launch of this step has updated already (general-M path: Lam, in k_big_glam)
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n - skip_n; j += (int64_t)gridDim.x * 256) {
+    const int64_t i = j < skip_off ? j : j + skip_n;
     double gi = sign * g[i];
     if (wd != 0.0 && i >= n_plain) gi += wd * p[i];  // weight decay only on the tail group
     const double mi = b1 * m[i] + (1.0 - b1) * gi;
@@ -507,10 +509,10 @@ int launch_adam(double* params, const double* grads, double* exp_avg, double* ex
 
 int launch_adam_dev(double* params, const double* grads, double* exp_avg, double* exp_avg_sq, int64_t n, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int32_t* step_dev, int maximize,
-                    hipStream_t st, int64_t n_plain) {
-  const int64_t nb = (n + 255) / 256;
+                    hipStream_t st, int64_t n_plain, int64_t skip_off, int64_t skip_n) {
+  const int64_t nb = (n - skip_n + 255) / 256 > 0 ? (n - skip_n + 255) / 256 : 1;
   hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)(nb < 512 ? nb : 512)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq,
-                     n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0, n_plain, log(beta1), log(beta2));
+                     n, lr, beta1, beta2, eps, weight_decay, step_dev, maximize ? -1.0 : 1.0, n_plain, log(beta1), log(beta2), skip_off, skip_n);
   LAUNCH_CHECK();
   return 0;
 }
