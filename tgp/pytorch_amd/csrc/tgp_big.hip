@@ -349,7 +349,90 @@ __device__ __forceinline__ void fac_tile(const FacJob& g, int i0, int j0, double
         g.C[(size_t)(i0 + wi + 16 * a + q + 4 * rr) * g.ldc + j0 + wj + 16 * b + r] = g.alpha * acc[a][b][rr] + g.beta * cold[a][b][rr];
 }
 
+// Round 6: the panel and the inverse row as SINGLE-STAGE tiles (all 128 k in LDS at once: one memory round trip instead of two
+// -- these launches sit on the factorisation's chain and are latency, not work).  16 x 128 resp. 128 x 16 output tiles keep the
+// in-place safety of the 32-wide ones (whole rows resp. whole columns) and fit: (128 + 16) rows x FS_LD doubles = 152 KB.
+#define FS_LD 132
+#define FS_LDS_BYTES ((size_t)144 * FS_LD * sizeof(double))
+// shape 3: C[i0 .. i0+16, 0 .. 128) = alpha A[i0 .. i0+16, :] B^T, B stored [n][k] (tb), in place over A
+__device__ __forceinline__ void fac_tile_pan16(const FacJob& g, int i0, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  d2 ra[4], rb[32];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    ra[u] = *reinterpret_cast<const d2*>(g.A + (size_t)(i0 + x) * g.lda + 2 * k2);
+  }
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)x * g.ldb + 2 * k2);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    *reinterpret_cast<d2*>(As + x * FS_LD + 2 * k2) = ra[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    *reinterpret_cast<d2*>(Bs + x * FS_LD + 2 * k2) = rb[u];
+  }
+  __syncthreads();
+  d4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const double af = As[r * FS_LD + 4 * s + q];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[b] = TGP_MFMA(af, Bs[(32 * wave + 16 * b + r) * FS_LD + 4 * s + q], acc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) g.C[(size_t)(i0 + q + 4 * rr) * g.ldc + 32 * wave + 16 * b + r] = g.alpha * acc[b][rr];
+}
+// shape 4: C[0 .. 128, j0 .. j0+16) = alpha A B[:, j0 .. j0+16), A [128][128], B stored [k][n], in place over B
+__device__ __forceinline__ void fac_tile_row16(const FacJob& g, int j0, double* As, double* Bs) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  d2 ra[32], rb[4];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    ra[u] = *reinterpret_cast<const d2*>(g.A + (size_t)x * g.lda + 2 * k2);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, kk = e >> 3, x2 = e & 7;            // 8 d2 per k row of 16 columns
+    rb[u] = *reinterpret_cast<const d2*>(g.B + (size_t)kk * g.ldb + j0 + 2 * x2);
+  }
+#pragma unroll
+  for (int u = 0; u < 32; ++u) {
+    const int e = tid + 256 * u, x = e >> 6, k2 = e & 63;
+    *reinterpret_cast<d2*>(As + x * FS_LD + 2 * k2) = ra[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + 256 * u, kk = e >> 3, x2 = e & 7;
+    Bs[(2 * x2) * FS_LD + kk] = rb[u][0];
+    Bs[(2 * x2 + 1) * FS_LD + kk] = rb[u][1];
+  }
+  __syncthreads();
+  d4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const double bf = Bs[r * FS_LD + 4 * s + q];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) acc[a] = TGP_MFMA(As[(32 * wave + 16 * a + r) * FS_LD + 4 * s + q], bf, acc[a]);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) g.C[(size_t)(32 * wave + 16 * a + q + 4 * rr) * g.ldc + j0 + r] = g.alpha * acc[a][rr];
+}
+
 __device__ __forceinline__ void fac_job(const FacJob& g, int L, double* As, double* Bs) {
+  if (g.shape == 3) { fac_tile_pan16(g, 16 * L, As, As + 16 * FS_LD); return; }
+  if (g.shape == 4) { fac_tile_row16(g, 16 * L, As, As + 128 * FS_LD); return; }
   const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
   const int gx = g.n / TN, bx = L % gx, by = L / gx;
   const int i0 = by * TM, j0 = bx * TN;
@@ -369,6 +452,8 @@ __global__ __launch_bounds__(256) void k_fac_pair(FacJob a, FacJob b, int na) {
 }
 
 static int fac_tiles(const FacJob& g) {
+  if (g.shape == 3) return g.m / 16;
+  if (g.shape == 4) return g.n / 16;
   const int TM = g.shape == 0 ? 32 : (g.shape == 1 ? 128 : 64), TN = g.shape == 0 ? 128 : (g.shape == 1 ? 32 : 64);
   return (g.m / TM) * (g.n / TN);
 }
@@ -384,12 +469,13 @@ static int launch_fac_pair(const FacJob& a, const FacJob& b, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fac_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(2 * 128 * FAC_LD * sizeof(double)));
+                                       (int)FS_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return set_error(e, __FILE__, __LINE__); }
     attr_done = true;
   }
   const int na = fac_tiles(a), nb2 = b.m > 0 ? fac_tiles(b) : 0;
-  hipLaunchKernelGGL(k_fac_pair, dim3(na + nb2), dim3(256), 2 * 128 * FAC_LD * sizeof(double), st, a, b, na);
+  static_assert(FS_LDS_BYTES >= 2 * 128 * FAC_LD * sizeof(double), "both tile families stage through one allocation");
+  hipLaunchKernelGGL(k_fac_pair, dim3(na + nb2), dim3(256), FS_LDS_BYTES, st, a, b, na);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1724,13 +1810,13 @@ static int big_factorise(const BigPlan& p, double* ws, int32_t* status, bool wan
     const int rem = MP - (kb + 1) * 128;
     double* Jk = J + (size_t)kb * 128 * MP;                          // block row kb of J
     const double* Jkk = Jk + (size_t)kb * 128;
-    // J[kb, 0:kb] = -J_kk Acc[kb, 0:kb]  in place (128 x 32 tiles: a workgroup owns its columns)
-    const FacJob inv_row = fac_job_args(Jkk, MP, Jk, MP, Jk, MP, 128, 128 * kb, 0, 1, -1.0, 0.0);
+    // J[kb, 0:kb] = -J_kk Acc[kb, 0:kb]  in place (128 x 16 single-stage tiles: a workgroup owns its columns)
+    const FacJob inv_row = fac_job_args(Jkk, MP, Jk, MP, Jk, MP, 128, 128 * kb, 0, 4, -1.0, 0.0);
     const bool row = want_inverse && kb >= 1;
     if (rem > 0) {
       double* panel = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)kb * 128;
-      // L[i,kb] = K[i,kb] J_kk^T  in place (32 x 128 tiles: a workgroup owns its rows)
-      const FacJob pan = fac_job_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 1, 0, 1.0, 0.0);
+      // L[i,kb] = K[i,kb] J_kk^T  in place (16 x 128 single-stage tiles: a workgroup owns its rows)
+      const FacJob pan = fac_job_args(panel, MP, Jkk, MP, panel, MP, rem, 128, 1, 3, 1.0, 0.0);
       // trailing update K[i,j] -= L[i,kb] L[j,kb]^T, lower part (64 x 64 tiles)
       double* trail = Lm + (size_t)(kb + 1) * 128 * MP + (size_t)(kb + 1) * 128;
       const FacJob upd = fac_job_args(panel, MP, panel, MP, trail, MP, rem, rem, 1, 2, -1.0, 1.0, 1);
