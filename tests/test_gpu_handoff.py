@@ -131,3 +131,35 @@ def test_a_hand_off_timeout_is_sticky_and_skips_the_update():
         eng.check_status()
     eng.status[3] = 0                             # handled: the caller clears the sticky word
     eng.check_status()
+
+
+def test_general_path_hand_offs_leave_the_words_zero_and_a_timeout_is_sticky():
+    """Round 6: the general-M factorisation hands diagonal blocks over INSIDE launches (k_big_kmm_potrf, k_fac_potrf: status[4]).
+    A healthy step leaves status[4..7] zero and status[3] untouched; with status[4] poisoned (sign bit: the count can never reach
+    its target) the factorising workgroup's wait expires within seconds, the event is counted in status[3] (sticky),
+    check_status() raises HandoffTimeoutError, the word is zero again, and the next steps are healthy."""
+    from tgp.pytorch_amd import ops
+    eng = _engine(700, 5, 300, "sal2", seed=5)      # M = 300: three 128-column steps, every merged launch of the chain
+    eng.elbo()
+    torch.cuda.synchronize()
+    st = eng.status.cpu().tolist()
+    assert st[0] == 0 and st[3] == 0 and st[4:] == [0, 0, 0, 0], st
+    ref = eng.fp.out[:3].clone()
+    eng.status[4] = -2 ** 31
+    t = time.time()
+    eng.elbo()
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    st = eng.status.cpu().tolist()
+    assert st[3] >= 1 and st[4:] == [0, 0, 0, 0], st
+    assert dt < 20.0, "a bounded wait took %.1f s" % dt
+    with pytest.raises(ops.HandoffTimeoutError):
+        eng.check_status()
+    sticky = st[3]
+    eng.elbo()
+    torch.cuda.synchronize()
+    st = eng.status.cpu().tolist()
+    assert st[0] == 0 and st[3] == sticky and st[4:] == [0, 0, 0, 0], st
+    assert torch.equal(eng.fp.out[:3], ref)          # same parameters: the healthy step is the first one bit for bit
+    eng.status[3] = 0
+    eng.check_status()
