@@ -1,13 +1,16 @@
 """One-off randomized parity sweep (not part of the test suite): random shapes -- incl. the row-kernel selection edges -- through
 the C ABI against the CPU oracle, with the assertions of tests/test_gpu_parity.py (values 1e-9, gradients 1e-7).
-Usage: python tools/probes/random_parity_sweep.py [n_cases] [seed]"""
+Usage: python tools/probes/random_parity_sweep.py [n_cases] [seed] [case list | -] [big]
+`big` (round 6): the general-M path -- M in 129 .. 640 (1-5 steps of the blocked factorisation: k_big_kmm_potrf, k_fac_potrf and
+the single-stage panel tiles at every depth), both kernels, row chunks of 256 / 512 rows or one chunk."""
 import os, sys, random, time, traceback, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import tgp_oracle as orc       # checker only
 import test_gpu_parity as T
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-only = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else None
+only = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 and sys.argv[3] != "-" else None
+big = len(sys.argv) > 4 and sys.argv[4] == "big"
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 flows = [None, "sal1", "sal2", "sal3", "tanh1x1", "tanh3x2", "tanh5x6", "idsal3"]
 edges = [3968, 3969, 3984, 4000, 4306, 7936, 7937, 8611, 10240, 10241]
@@ -18,18 +21,27 @@ for c in range(n_cases):
     flow = rng.choice(flows)
     S = rng.choice([5, 8, 20, 32])
     N = rng.choice(edges) if c % 3 == 0 else rng.randint(M, 3000)      # (the oracle's generator draws Z from the rows: N >= M)
+    kernel, plan = "scale_rbf", 0
+    if big:
+        from tgp.pytorch_amd import lib as _L
+        M = rng.choice([129, 130, 160, 200, 255, 256, 257, 300, 384, 385, 500, 512, 640])
+        D = rng.choice([4, 5, 8, 9, 13, 16])                            # (fewer dimensions: K_MM of hundreds of points is singular)
+        N = rng.randint(M, 2500)
+        kernel = rng.choice(["scale_rbf", "scale_rbf", "scale_matern32"])
+        plan = rng.choice([0, 0, _L.plan_chunk_rows(256), _L.plan_chunk_rows(512), _L.plan_chunk_rows(256) | _L.PLAN_NO_CHUNK_OVERLAP])
     if only is not None and c not in only: continue
     t = time.time()
     prob = orc.synthetic_problem(N, D, M, seed=100 + c, flow=flow, S=S)
     (elbo, ell, kld), og = orc.elbo_and_grads(prob["X"], prob["Y"], prob["params"], prob["N_total"], prob["program"],
-                                              prob["xs"], prob["ws"], prob["rowp"])
+                                              prob["xs"], prob["ws"], prob["rowp"], **({"kernel": kernel} if big else {}))
     g = dict(prob)
+    g["kernel"] = kernel
     g.update(ELBO=elbo, ELL=ell, KLD=kld, g_Z=og["Z"], g_raw_lengthscale=og["raw_lengthscale"],
              g_raw_outputscale=og["raw_outputscale"], g_m=og["m"], g_Lam=og["Lam"], g_log_var_noise=og["log_var_noise"])
     if "theta" in og: g["g_theta"] = og["theta"]
     if "rowp" in og: g["g_rowp"] = og["rowp"]
     try:
-        out, grads, status, _ = T.run_hip(g)
+        out, grads, status, _ = T.run_hip(g, plan=plan) if big else T.run_hip(g)
         if int(status[0]) > 0:
             # a numerically singular K_MM (few input dimensions, many inducing points): LAPACK and the blocked MFMA
             # factorisation may disagree on whether the unjittered Cholesky passes; not a parity failure
@@ -49,5 +61,6 @@ for c in range(n_cases):
             res = "ill-conditioned, not judged (cond(K_MM) %.1e; %s)" % (cond, detail)
         else:
             res = "FAIL %s  cond(K_MM) %.1e" % (detail, cond); bad += 1
-    print("case %2d N=%5d D=%2d M=%3d S=%2d flow=%-8s %s  (%.1f s)" % (c, N, D, M, S, flow, res, time.time() - t), flush=True)
+    print("case %2d N=%5d D=%2d M=%3d S=%2d flow=%-8s %s%s  (%.1f s)" % (c, N, D, M, S, flow, ("%s plan=%d " % (kernel, plan)) if big else "", res,
+                                                                        time.time() - t), flush=True)
 print("failures:", bad)
